@@ -1,0 +1,161 @@
+"""Golden-fixture generator.  Runs ONLY in the build container (needs /root/reference).
+
+    python tests/golden/make_golden.py [--only NAME ...] [--skip-real]
+
+Every fixture is *data*: inputs captured after the unmodified reference's
+``CreateAllInstantiate`` plus the outputs of its ``SimCity`` loop
+(``oracle/ref_harness.py``).  Tiny cities carry full vectors (per-order assignment,
+per-tick observations, per-tick idle lists / arrival dicts in container order); the two
+real-shape cases (N=4139, C=192, V=10 000, O=200 000 - BASELINE.json configs[1] and
+configs[3] at one replica) carry per-tick observations, counters, per-order status/wait
+and SHA-256 digests of the per-order vectors; their city is regenerated from the seed by
+``vehicles_dispatch_simulator_amd.synth`` (the generator asserts the regenerated tables
+equal what the reference loaded).
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from vehicles_dispatch_simulator_amd import synth  # noqa: E402
+import ref_harness as rh  # noqa: E402
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def policy_factory(N, every=3, min_idle=3, moves=2, salt=17):
+    """A deterministic DispatchFunction body for the harness (the reference's hook is empty)."""
+    def policy(S, tick):
+        if tick % every != 0:
+            return []
+        out = []
+        for c in S.Clusters:
+            n = len(c.IdleVehicles)
+            if n >= min_idle:
+                for m in range(min(moves, n - 1)):
+                    veh = c.IdleVehicles[(tick * 7 + m * 3 + c.ID) % n]
+                    if any(veh is v for v, _ in out):
+                        continue
+                    target = int((tick * 2654435761 + c.ID * 40503 + m * salt) % N)
+                    out.append((veh, target))
+        return out
+    return policy
+
+
+TINY = {
+    # name: dict(city kwargs, orders, run kwargs)
+    "tiny_grid": dict(city=dict(seed=101, N=300, mode="grid", side_m=3200), O=2500, oseed=1,
+                      run=dict(V=120, seed=11, cluster_mode="Grid", side_m=3200, service_m=3200)),
+    "tiny_grid_nbr_scarce": dict(city=dict(seed=102, N=280, mode="grid", side_m=3200), O=3000, oseed=2,
+                                 run=dict(V=24, seed=12, cluster_mode="Grid", side_m=3200, service_m=8000, neighbor_can_server=True)),
+    "tiny_kmeans": dict(city=dict(seed=103, N=320, C=12), O=2500, oseed=3,
+                        run=dict(V=150, seed=13, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
+    "tiny_kmeans_dfs0": dict(city=dict(seed=104, N=300, C=12), O=2500, oseed=4,
+                             run=dict(V=60, seed=14, cluster_mode="KmeansClustering", side_m=3200, service_m=3200, neighbor_can_server=True)),
+    "tiny_kmeans_dfs1": dict(city=dict(seed=105, N=300, C=12), O=3000, oseed=5,
+                             run=dict(V=60, seed=15, cluster_mode="SpectralClustering", side_m=3200, service_m=4800, neighbor_can_server=True)),
+    "tiny_kmeans_dfs2": dict(city=dict(seed=106, N=300, C=12), O=3000, oseed=6,
+                             run=dict(V=50, seed=16, cluster_mode="SpectralClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
+    "tiny_empty_clusters_dfs2": dict(city=dict(seed=107, N=260, C=12), O=2500, oseed=7, empty=[3, 8],
+                                     run=dict(V=40, seed=17, cluster_mode="TransportationClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
+    "tiny_dispatch": dict(city=dict(seed=108, N=300, C=12), O=2500, oseed=8, dispatch=True,
+                          run=dict(V=140, seed=18, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
+    "tiny_dispatch_dfs2": dict(city=dict(seed=109, N=300, C=12), O=3000, oseed=9, dispatch=True,
+                               run=dict(V=70, seed=19, cluster_mode="KmeansClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
+    "tiny_two_orders": dict(city=dict(seed=110, N=120, C=12), O=2, oseed=10,
+                            run=dict(V=30, seed=20, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
+}
+
+REAL = {
+    "real_kmeans192": dict(city=dict(seed=2016, N=4139, C=192), O=200000, oseed=1101,
+                           run=dict(V=10000, seed=1234, cluster_mode="KmeansClustering", side_m=800, service_m=800)),
+    "real_spectral192_dfs2": dict(city=dict(seed=2016, N=4139, C=192), O=200000, oseed=1101,
+                                  run=dict(V=10000, seed=1234, cluster_mode="SpectralClustering", side_m=800, service_m=2000, neighbor_can_server=True)),
+}
+
+
+def build_city(spec):
+    city = synth.make_city(**spec["city"])
+    if spec.get("empty"):
+        # Transportation-shape: some cluster ids own no node (reference: 99999 sentinel, simulator.py:608-609)
+        lab = city.node2cluster.copy()
+        for e in spec["empty"]:
+            lab[lab == e] = (e + 1) % city.C
+        city.node2cluster = lab
+        city.neighbors = synth.cluster_neighbors_from_cost(city.cost, lab, city.C)
+    return city
+
+
+def generate(name, spec, real=False):
+    t0 = time.time()
+    city = build_city(spec)
+    start, pick, dele = synth.make_orders(spec["oseed"], city.N, spec["O"])
+    run = dict(spec["run"])
+    pol = policy_factory(city.N) if spec.get("dispatch") else None
+    out = rh.run_reference(city, start, pick, dele, dispatch_policy=pol, capture_lists=not real, **run)
+    # the generator's tables must be exactly what the reference loaded / derived
+    assert out["cost_is_integral"]
+    assert (out["cost"] == city.cost).all() and (out["node2cluster"] == city.node2cluster).all()
+    nbr = [out["nbr_idx"][out["nbr_off"][c]:out["nbr_off"][c + 1]].tolist() for c in range(city.C)]
+    assert nbr == [list(x) for x in city.neighbors], "neighbour lists differ from the reference's"
+    import random
+    assert (synth.init_vehicle_nodes(random.Random(run["seed"]), city.N, run["V"]) == out["veh_node"]).all()
+    assert (out["veh_cluster"] == city.node2cluster[out["veh_node"]]).all()
+    meta = dict(city_seed=np.int64(spec["city"]["seed"]), city_mode=np.str_(spec["city"].get("mode", "cluster")),
+                city_side_m=np.float64(spec["city"].get("side_m", 800.0)),
+                empty=np.array(spec.get("empty", []), dtype=np.int32),
+                order_seed=np.int64(spec["oseed"]), cluster_mode=np.str_(run["cluster_mode"]),
+                side_m=np.float64(run["side_m"]), service_m=np.float64(run["service_m"]))
+    out.update(meta)
+    out["sha_status"], out["sha_vehicle"], out["sha_wait"] = np.str_(sha(out["o_status"])), np.str_(sha(out["o_vehicle"])), np.str_(sha(out["o_wait"].astype(np.int32)))
+    if real:
+        # city regenerated from the seed on the test side; keep orders (post ReadOrder sort) compactly
+        for k in ("cost", "node2cluster", "veh_cluster"):
+            out.pop(k)
+        out["o_pickup"] = out["o_pickup"].astype(np.uint16)
+        out["o_delivery"] = out["o_delivery"].astype(np.uint16)
+        out["o_release_min"] = out["o_release_min"].astype(np.int16)
+        out["veh_node"] = out["veh_node"].astype(np.uint16)
+        out["o_vehicle_head"] = out["o_vehicle"][:8192].copy()
+        out.pop("o_vehicle")
+        out.pop("o_value")
+        out["o_wait"] = out["o_wait"].astype(np.int16)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s ticks=%d orders=%d reject=%d wait=%d dispatch=%d ref_sim=%.1fs total=%.1fs size=%.0fKB" % (
+        name, out["n_ticks"], out["order_num"], out["reject_num"], out["wait_sum"], out["dispatch_num"],
+        out["ref_sim_s"], time.time() - t0, os.path.getsize(path) / 1024))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*")
+    ap.add_argument("--skip-real", action="store_true")
+    a = ap.parse_args()
+    if not rh.reference_available():
+        raise SystemExit("reference not mounted: golden fixtures can only be generated in the build container")
+    for name, spec in TINY.items():
+        if a.only and name not in a.only:
+            continue
+        generate(name, spec)
+    if not a.skip_real:
+        for name, spec in REAL.items():
+            if a.only and name not in a.only:
+                continue
+            generate(name, spec, real=True)
+
+
+if __name__ == "__main__":
+    main()

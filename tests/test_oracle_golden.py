@@ -1,0 +1,78 @@
+"""Pins the CPU oracle (oracle/vds_oracle.c) against vectors captured from the unmodified
+reference (tests/golden/make_golden.py): per-order assignment, per-tick observations,
+per-tick idle lists / arrival dicts in container order, final counters.  Bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import dispatch_by_tick, golden_names, load_golden, make_oracle
+
+TINY = golden_names("tiny_")
+REAL = golden_names("real_")
+
+
+def replay(g, check_lists):
+    o = make_oracle(g)
+    T = o.num_ticks
+    assert T == int(g["n_ticks"])
+    disp = dispatch_by_tick(g)
+    for t in range(T):
+        o.begin_tick()
+        obs = o.obs()
+        c = o.counters()
+        assert c["order_num"] == g["t_order_num"][t] and c["reject_num"] == g["t_reject_num"][t], t
+        assert c["wait_sum"] == g["t_wait_sum"][t], t
+        np.testing.assert_array_equal(obs["idle_pre"], g["t_idle_pre"][t])
+        np.testing.assert_array_equal(obs["idle_post"], g["t_idle_post"][t])
+        np.testing.assert_array_equal(obs["supply"], g["t_supply"][t])
+        np.testing.assert_array_equal(obs["cl_orders"], g["t_cl_orders"][t])
+        np.testing.assert_array_equal(obs["inflight"], g["t_inflight"][t])
+        if check_lists:
+            L = o.lists()
+            np.testing.assert_array_equal(L["idle_off"], g["l_idle_off"][t])
+            np.testing.assert_array_equal(L["idle_veh"], g["l_idle_veh"][t])
+            np.testing.assert_array_equal(L["arr_off"], g["l_arr_off"][t])
+            np.testing.assert_array_equal(L["arr_veh"], g["l_arr_veh"][t])
+            np.testing.assert_array_equal(L["arr_min"], g["l_arr_min"][t])
+        if t in disp:
+            rows = np.array(disp[t])
+            o.dispatch(rows[:, 1], rows[:, 4])
+        np.testing.assert_array_equal(o.obs()["idle_now"], g["t_idle_after_dispatch"][t])
+        o.end_tick()
+    return o
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_oracle_matches_reference_tiny(name):
+    g = load_golden(name)
+    o = replay(g, check_lists=True)
+    od = o.orders()
+    np.testing.assert_array_equal(od["status"], g["o_status"])
+    np.testing.assert_array_equal(od["vehicle"], g["o_vehicle"])
+    np.testing.assert_array_equal(od["wait"], g["o_wait"])
+    np.testing.assert_array_equal(od["value"], g["o_value"])
+    c = o.counters()
+    for k in ("order_num", "reject_num", "wait_sum", "dispatch_num", "dispatch_cost", "sum_order_value"):
+        assert c[k] == int(g[k]), k
+    assert c["matched"] == int((g["o_status"] == 1).sum())
+    # quirk Q1: the last order of the day is never processed
+    assert od["status"][-1] == 0 and c["order_num"] == g["o_status"].size - 1
+
+
+def test_tiny_fixtures_present():
+    assert len(TINY) >= 10
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", REAL)
+def test_oracle_matches_reference_real_shape(name):
+    import hashlib
+    g = load_golden(name)
+    o = replay(g, check_lists=False)
+    od = o.orders()
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(od["status"]) == str(g["sha_status"])
+    assert sha(od["vehicle"]) == str(g["sha_vehicle"])
+    assert sha(od["wait"]) == str(g["sha_wait"])
+    c = o.counters()
+    for k in ("order_num", "reject_num", "wait_sum", "sum_order_value"):
+        assert c[k] == int(g[k]), k
