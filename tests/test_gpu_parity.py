@@ -1,0 +1,162 @@
+"""Parity of the HIP tick path (through the C ABI) against the CPU oracle and the golden vectors
+captured from the unmodified reference.  Integer bookkeeping: bit-exact, per tick:
+counters, per-cluster observations, idle lists in list order, arrival dicts in insertion order,
+and per-order (status, vehicle, wait) at the end of the day."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import dispatch_by_tick, golden_names, load_golden, make_oracle
+from oracle.oracle import Oracle
+from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth
+
+pytestmark = pytest.mark.gpu
+
+TINY = golden_names("tiny_")
+
+
+def make_env(g, R, **kw):
+    env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=int(g["V"]),
+                             depth_limit=int(g["depth_limit"]), neighbor_can_server=bool(g["neighbor_can_server"]), **kw)
+    env.load_orders(g["o_release_min"], g["o_pickup"], g["o_delivery"])
+    return env
+
+
+def check_lists(env, r, o, t):
+    L, G = o.lists(), env.lists(r)
+    np.testing.assert_array_equal(G["idle_off"], L["idle_off"], err_msg="tick %d replica %d idle_off" % (t, r))
+    np.testing.assert_array_equal(G["idle_veh"], L["idle_veh"], err_msg="tick %d replica %d idle order" % (t, r))
+    np.testing.assert_array_equal(G["arr_off"], L["arr_off"], err_msg="tick %d replica %d arr_off" % (t, r))
+    np.testing.assert_array_equal(G["arr_veh"], L["arr_veh"], err_msg="tick %d replica %d arrival dict order" % (t, r))
+    np.testing.assert_array_equal(G["arr_min"], L["arr_min"])
+    veh = o.vehicles()
+    n = L["idle_off"][-1]
+    np.testing.assert_array_equal(G["idle_node"][:n], veh["loc"][L["idle_veh"][:n]])
+    na = L["arr_off"][-1]
+    np.testing.assert_array_equal(G["arr_node"][:na], veh["dest"][L["arr_veh"][:na]])
+    np.testing.assert_array_equal(G["arr_order"][:na], veh["order"][L["arr_veh"][:na]])
+
+
+def run_day(g, R, same_init, list_every=1, **kw):
+    V, N = int(g["V"]), int(g["N"])
+    valid = g["node2cluster"] >= 0
+    init = np.empty((R, V), dtype=np.int32)
+    init[0] = g["veh_node"]
+    for r in range(1, R):
+        init[r] = g["veh_node"] if same_init else synth.init_vehicle_nodes(random.Random(1000 + r), N, V, valid)
+    env = make_env(g, R, **kw)
+    env.reset(init)
+    oracles = []
+    for r in range(R):
+        o = make_oracle(g)
+        o.reset(init[r])
+        oracles.append(o)
+    T = env.T
+    assert T == int(g["n_ticks"]) == oracles[0].num_ticks
+    disp = dispatch_by_tick(g)
+    for t in range(T):
+        env.step()
+        for o in oracles:
+            o.begin_tick()
+        ob = env.obs()
+        cn = env.counters()
+        for r, o in enumerate(oracles):
+            oo, oc = o.obs(), o.counters()
+            for a, b in (("idle_pre", "idle_pre"), ("idle_now", "idle_post"), ("supply", "supply"), ("cl_orders", "cl_orders"), ("inflight", "inflight")):
+                np.testing.assert_array_equal(ob[a][r], oo[b], err_msg="tick %d replica %d obs %s" % (t, r, a))
+            for i, k in enumerate(("order_num", "reject_num", "matched", "wait_sum", "dispatch_num", "dispatch_cost")):
+                assert cn[r, i] == oc[k], (t, r, k, cn[r, i], oc[k])
+            assert cn[r, 7] == oc["evals"], (t, r, "evals")
+        # replica 0 also against the reference's own per-tick record
+        np.testing.assert_array_equal(ob["supply"][0], g["t_supply"][t])
+        np.testing.assert_array_equal(ob["idle_now"][0], g["t_idle_post"][t])
+        assert cn[0, 0] == g["t_order_num"][t] and cn[0, 1] == g["t_reject_num"][t] and cn[0, 3] == g["t_wait_sum"][t]
+        if t % list_every == 0 or t in disp:
+            for r, o in enumerate(oracles):
+                check_lists(env, r, o, t)
+        if t in disp:
+            rows = np.array(disp[t])
+            L = oracles[0].lists()
+            pos = []
+            for veh, cl in zip(rows[:, 1], rows[:, 2]):
+                seg = L["idle_veh"][L["idle_off"][cl]:L["idle_off"][cl + 1]]
+                pos.append(int(np.flatnonzero(seg == veh)[0]))
+            nrep = R if same_init else 1
+            rep = np.repeat(np.arange(nrep), len(rows))
+            env.apply_dispatch(rep, np.tile(rows[:, 2], nrep), np.tile(pos, nrep), np.tile(rows[:, 4], nrep))
+            for o in oracles[:nrep]:
+                o.dispatch(rows[:, 1], rows[:, 4])
+            for r, o in enumerate(oracles):
+                check_lists(env, r, o, t)
+            np.testing.assert_array_equal(env.obs()["idle_now"][0], g["t_idle_after_dispatch"][t])
+        env.advance()
+        for o in oracles:
+            o.end_tick()
+    env.sync()
+    od = env.orders()
+    for r, o in enumerate(oracles):
+        oo = o.orders()
+        np.testing.assert_array_equal(od["status"][r], oo["status"])
+        np.testing.assert_array_equal(od["vehicle"][r], oo["vehicle"])
+        np.testing.assert_array_equal(od["wait"][r], oo["wait"])
+    np.testing.assert_array_equal(od["status"][0], g["o_status"])
+    np.testing.assert_array_equal(od["vehicle"][0], g["o_vehicle"])
+    np.testing.assert_array_equal(od["wait"][0], g["o_wait"])
+    cn = env.counters()
+    for r, o in enumerate(oracles):
+        oc = o.counters()
+        assert cn[r, 6] == oc["sum_order_value"]
+    assert cn[0, 6] == int(g["sum_order_value"]) and cn[0, 0] == int(g["order_num"]) and cn[0, 1] == int(g["reject_num"])
+    assert cn[0, 4] == int(g["dispatch_num"]) and cn[0, 5] == int(g["dispatch_cost"])
+    tot = env.total_counters()
+    np.testing.assert_array_equal(tot[:6], cn[:, :6].sum(axis=0))
+    env.close()
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_tiny_golden_per_tick(name):
+    g = load_golden(name)
+    run_day(g, R=3, same_init=bool(len(g["dispatch_log"])))
+
+
+@pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_kmeans_dfs2"])
+def test_many_replicas_ragged(name):
+    """R not a multiple of the workgroup's replica run; every replica its own vehicle seed."""
+    g = load_golden(name)
+    run_day(g, R=37, same_init=False, list_every=29)
+
+
+def test_small_caps_overflow_is_reported():
+    g = load_golden("tiny_kmeans")
+    env = make_env(g, 2, idle_cap=64, inflight_cap=64, inbox_cap=64)
+    init = np.tile(np.full(int(g["V"]), int(np.flatnonzero(g["node2cluster"] == 0)[0]), dtype=np.int32), (2, 1))
+    with pytest.raises(Exception, match="idle table overflow"):
+        env.reset(init)   # 150 vehicles in one cluster > idle_cap 64
+    env.close()
+
+
+def test_all_vehicles_in_one_cluster_oversize_bucket():
+    """> 256 idle vehicles in one cluster exercises the deferred 16-slot kernel."""
+    g = load_golden("tiny_kmeans")
+    V = 600
+    g = dict(g)
+    g["V"] = np.int64(V)
+    node = int(np.flatnonzero(g["node2cluster"] == 5)[0])
+    nodes5 = np.flatnonzero(g["node2cluster"] == 5)
+    init = nodes5[np.arange(V) % nodes5.size].astype(np.int32)[None, :].repeat(2, axis=0)
+    env = make_env(g, 2, idle_cap=640)
+    env.reset(init)
+    o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], int(g["depth_limit"]), False,
+               g["o_release_min"], g["o_pickup"], g["o_delivery"], V)
+    o.reset(init[0])
+    for t in range(env.T):
+        env.step(); o.begin_tick()
+        if t % 10 == 0:
+            check_lists(env, 1, o, t)
+        env.advance(); o.end_tick()
+    od, oo = env.orders(), o.orders()
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(od[k][1], oo[k])
+    assert node >= 0
+    env.close()

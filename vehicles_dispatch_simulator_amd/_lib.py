@@ -1,0 +1,81 @@
+"""ctypes binding of ``libvds.so`` (``include/vds.h``) - the only way the package reaches the GPU.
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible the
+calls raise, loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvds.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+NUM_COUNTERS = 8
+COUNTER_NAMES = ("order_num", "reject_num", "matched", "wait_sum", "dispatch_num", "dispatch_cost", "sum_order_value", "evals")
+
+
+class VdsConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("replicas", C.c_int32), ("vehicles", C.c_int32),
+        ("tick_minutes", C.c_int32), ("neighbor_can_server", C.c_int32), ("pickup_reject_threshold", C.c_int64),
+        ("idle_cap", C.c_int32), ("inflight_cap", C.c_int32), ("inbox_cap", C.c_int32), ("count_evals", C.c_int32),
+    ]
+
+
+# every symbol include/vds.h declares: name -> (restype, argtypes)
+_VP, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
+SYMBOLS = {
+    "vds_version": (_I32, []),
+    "vds_config_init": (None, [C.POINTER(VdsConfig)]),
+    "vds_create": (C.c_int, [C.POINTER(VdsConfig), C.POINTER(_VP)]),
+    "vds_destroy": (C.c_int, [_VP]),
+    "vds_last_error": (C.c_char_p, [_VP]),
+    "vds_set_stream": (C.c_int, [_VP, _VP]),
+    "vds_load_static": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP, _I32]),
+    "vds_load_orders": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),
+    "vds_num_ticks": (C.c_int, [_VP, C.POINTER(_I32)]),
+    "vds_reset": (C.c_int, [_VP, _VP]),
+    "vds_step": (C.c_int, [_VP]),
+    "vds_apply_dispatch": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    "vds_advance": (C.c_int, [_VP]),
+    "vds_run": (C.c_int, [_VP, _I32]),
+    "vds_sync": (C.c_int, [_VP]),
+    "vds_clock": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "vds_read_obs": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "vds_obs_device": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "vds_read_counters": (C.c_int, [_VP, _VP]),
+    "vds_reduce_counters": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    "vds_read_orders": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
+    "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),
+    "vds_read_work": (C.c_int, [_VP, _VP]),
+}
+TEST_SYMBOLS = {"vds_selftest_wave_min": (C.c_int, [_VP, _VP, _VP, _I32])}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile ``csrc/*.hip`` for gfx950 into ``libvds.so`` (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vds.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libvds.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C vehicles_dispatch_simulator_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in {**SYMBOLS, **TEST_SYMBOLS}.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,92 @@
+// Device-side data model of libvds (gfx950 / CDNA4 only).
+//
+// Everything is Struct-of-Arrays in HBM, laid out CLUSTER-major: the unit of parallel work
+// is one (cluster, replica) "bucket", and a workgroup owns one cluster for a run of
+// replicas, so that the cluster's cost block sits in LDS once and every bucket access is a
+// contiguous, coalesced segment.
+//
+//   hdr   [C][R][8]  int32   bucket header (see HDR_* below)
+//   cnt   [C][R][8]  int64   bucket-owned partial counters (no atomics; reduced over C on read)
+//   idle  [C][R][idle_cap]   {veh, loc_local}      Cluster.IdleVehicles, kept in LIST ORDER
+//   fl    [C][R][fl_cap]     {veh, id, arrive, meta} Cluster.VehiclesArrivetime (unordered slots,
+//                                                   dict order is carried by the entry key)
+//   inbox [2][C][R][in_cap]  same entry; arrivals posted by OTHER buckets during tick t land in
+//                                                   parity (t+1)&1 and are drained by the owner at t+1
+//   out_veh/out_wait [R][Oq] per-order result, indexed by bucket-sorted order position q
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vds {
+
+// bucket header dwords
+enum {
+    HDR_IDLE = 0,    // len(IdleVehicles)
+    HDR_FL = 1,      // entries in fl (owner-private part of VehiclesArrivetime)
+    HDR_INBOX0 = 2,  // inbox fill, parity 0 (atomic target of other buckets)
+    HDR_INBOX1 = 3,  // inbox fill, parity 1
+    HDR_SE0 = 4,     // SupplyExpect accumulator, parity 0 (atomic target)
+    HDR_SE1 = 5,     // SupplyExpect accumulator, parity 1
+    HDR_IDLE_PRE = 6,   // PerMatchIdleVehicles of the last tick
+    HDR_ORDERS = 7,     // len(Cluster.Orders) of the last tick
+    HDR_WORDS = 8
+};
+
+// bucket counter slots (int64)
+enum {
+    CNT_ORDERS = 0, CNT_REJECTS = 1, CNT_WAIT = 2, CNT_VALUE = 3,
+    CNT_EVALS = 4, CNT_ARRIVALS = 5, CNT_DISPATCH = 6, CNT_DISPATCH_COST = 7, CNT_WORDS = 8
+};
+
+// sticky device error bits (err[0])
+enum { ERR_IDLE_CAP = 1, ERR_FL_CAP = 2, ERR_INBOX_CAP = 4, ERR_DISPATCH = 8 };
+
+// in-flight entry: x = vehicle, y = id (order id, or dispatch sequence number),
+// z = arrival minute, w = meta = insert_tick << 16 | is_dispatch << 15 | dest_local.
+// Dict insertion order == ascending key (insert_tick, is_dispatch, id).
+__host__ __device__ inline int meta_pack(int tick, int is_dispatch, int dest_local) {
+    return (tick << 16) | (is_dispatch << 15) | dest_local;
+}
+__host__ __device__ inline int meta_dest(int w) { return w & 0x7FFF; }
+__host__ __device__ inline int meta_is_dispatch(int w) { return (w >> 15) & 1; }
+__host__ __device__ inline unsigned long long entry_key(int id, int w) {
+    return ((unsigned long long)((unsigned)w >> 15) << 32) | (unsigned)id;
+}
+
+// sorted order record: x = order id, y = pick_local | dest_local << 16,
+// z = dest_cluster | pick_cluster << 16, w = OrderValue
+struct Static {
+    int N, C, V, R, Oq, T;
+    int tick_minutes, now0;          // RealExpTime at tick 0
+    long long reject_threshold;
+    int idle_cap, fl_cap, in_cap;
+    int count_evals;
+    int max_nc;                      // largest cluster (nodes)
+    const int *cost;                 // [N*N]
+    const int *node2cluster;         // [N]
+    const int *node_local;           // [N]
+    const int *cl_off;               // [C+1]
+    const int *cl_nodes;             // [sum n_c]
+    const long long *blk_off;        // [C+1]
+    const int *blk;                  // [sum n_c^2]  blk[c][p][l] = cost[node_p * N + node_l]
+    const int *dfs_off;              // [C+1]
+    const int *dfs_seq;              // visit sequence excluding the start cluster
+    const int4 *so_rec;              // [Oq]
+    const int *bkt_off;              // [T*C + 1]
+    const int *tick_off;             // [T+1] into ord_q
+    const int *ord_q;                // [Oq] processed orders in id order -> q
+};
+
+struct State {
+    int *hdr;
+    long long *cnt;
+    uint2 *idle;
+    int4 *fl;
+    int4 *inbox;
+    int *out_veh;
+    int *out_wait;
+    int *err;
+    int *work;   // [2] oversize-bucket counters by tick parity, then [2][C*R] bucket indices
+};
+
+}  // namespace vds
