@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on BASELINE.json's metric: env-steps x replicas / s.
+
+    python bench.py --gpus N --steps K --warmup W            (N == 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A *step* is one pass of the tick path over one batch of synthetic input: one whole simulated
+day (T = 148 ticks: Update -> Match -> SupplyExpect each) of R replicas per GPU on
+BASELINE.json configs[1] (192 clusters, 10k vehicles, ~200k orders/day), inputs resident in
+HBM.  Replicas shard across GPUs with no data-path collective (weak scaling: R per GPU is
+fixed); the only collective is an RCCL all-reduce of the int64[8] aggregate counters per day.
+
+The one JSON line printed by rank 0 also carries
+  roofline      dominant kernel k_tick: algorithmic bytes per launch (SURVEY.md 8(d) byte model)
+                / average launch duration (HIP events on the kernel's stream) vs 8 TB/s HBM;
+  cpu_baseline  the CPU oracle (a C port of the reference algorithm, 1 thread) timed on this
+                host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+
+def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 64):
+    """The oracle (kind "port": C restatement of the reference's Python loop) on this host, one
+    thread, whole days of single replicas of the same workload until ~budget_s of CPU work."""
+    from oracle.oracle import Oracle
+    o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server,
+               w.release_min, w.pickup, w.delivery, w.vehicles)
+    days, ticks, evals = 0, 0, 0
+    t0 = time.perf_counter()
+    while days < max_days and (time.perf_counter() - t0) < budget_s:
+        o.reset(init_rows[days % len(init_rows)])
+        ticks += o.run_day()
+        evals += o.counters()["evals"]
+        days += 1
+    dt = time.perf_counter() - t0
+    return {"value": ticks / dt, "unit": "env-steps*replicas/s", "cores": 1, "kind": "port",
+            "sample": "%d single-replica days (%d ticks, %.3g match evaluations) of the same workload in %.1f s" % (days, ticks, evals, dt),
+            "match_evals_per_s": evals / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--replicas", type=int, default=1024, help="replicas PER GPU")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify replica 0 against the oracle after the run")
+    a = ap.parse_args()
+
+    import torch
+    from vehicles_dispatch_simulator_amd import workloads
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    R = a.replicas
+    if a.workload == "cfg2":
+        w = workloads.didi_day("cfg2")
+        wname = "configs[1]: %d replicas/GPU x 192 k-means clusters, 4139 nodes, 10k vehicles, 200k synthetic orders/day, no neighbour search" % R
+    else:
+        w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
+        wname = "configs[3]: %d replicas/GPU x 192 clusters with neighbour DFS depth 2, 10k vehicles, 200k orders/day" % R
+    init = w.vehicle_nodes(R, first_replica=rank * R)
+
+    stream = torch.cuda.current_stream()
+    env = w.make_env(R, device=local_rank, stream=stream.cuda_stream)
+    env.reset(init)           # uploads start nodes once; they stay resident
+    T = env.T
+    totals = torch.zeros(8, dtype=torch.int64, device="cuda")
+
+    def one_day():
+        env.reset_again()
+        env.run(T)
+        env.reduce_counters_into(totals.data_ptr())
+        if dist is not None:
+            dist.all_reduce(totals)   # RCCL: aggregate reward/metrics only (64 B)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_day()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_day()
+    fence()
+    elapsed = time.perf_counter() - t0
+    env.sync()                # surfaces capacity errors, if any
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    agg = totals.cpu().numpy()
+
+    # ---- roofline pass (rank 0): per-launch duration of the dominant kernel, HIP events on its stream
+    roofline = None
+    work = env.work()         # work of the last day on this rank
+    if rank == 0:
+        env.reset_again()
+        env.profile(True)
+        env.run(T)
+        ms = env.profile_read(cap=T + 8)
+        env.profile(False)
+        if ms.size:
+            bytes_day = workloads.algorithmic_bytes(work, w.vehicles)
+            per_launch_bytes = bytes_day / ms.size
+            avg_s = float(ms.mean()) * 1e-3
+            achieved = per_launch_bytes / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("workload") == a.workload and tj.get("replicas") == R:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "k_tick" if not w.neighbor_can_server else "k_match_dfs",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes,
+                        "avg_launch_ms": float(ms.mean()), "launches": int(ms.size),
+                        "match_evals_per_s": work["evals"] / (float(ms.sum()) * 1e-3)}
+
+    check = None
+    if a.check and rank == 0:
+        from oracle.oracle import Oracle
+        env.reset_again()
+        env.run(T)
+        got = env.orders(0, 2)
+        ok = True
+        for r in range(2):
+            o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server,
+                       w.release_min, w.pickup, w.delivery, w.vehicles)
+            o.reset(init[r]); o.run_day()
+            exp = o.orders()
+            ok = ok and all(np.array_equal(got[k][r], exp[k]) for k in ("status", "vehicle", "wait"))
+        check = bool(ok)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(w, init[: min(R, 16)])
+
+    if rank == 0:
+        env_steps = T * R * world * a.steps
+        out = {
+            "metric": "env-steps x replicas / sec (192-cluster, 10k vehicles)",
+            "value": env_steps / elapsed, "unit": "env-steps*replicas/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": wname, "replicas_per_gpu": R, "replicas_total": R * world, "ticks_per_step": T,
+                       "step": "one simulated day (T ticks) of all replicas incl. episode reset and counter all-reduce",
+                       "parallelism": "replica-sharded x%d, RCCL all-reduce of int64[8] metrics per day" % world},
+            "match_evals_per_s": float(work["evals"]) * world * a.steps / elapsed if work["evals"] else None,
+            "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if check is not None:
+            out["parity_check_vs_oracle"] = check
+        print(json.dumps(out))
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,10 @@ int vds_num_ticks(const vds_handle *h, int32_t *T);
  * vehicle order) + SimCity prologue (:1037-1043): tick = 0, counters = 0. */
 int vds_reset(vds_handle *h, const int32_t *veh_init_node);
 
+/* As vds_reset, but re-using the start nodes uploaded by the previous vds_reset (they stay
+ * resident in HBM): the episode restart an RL loop performs thousands of times. */
+int vds_reset_again(vds_handle *h);
+
 /* One SimCity iteration up to the Dispatch hook for every replica: UpdateFunction (:1006-1024),
  * MatchFunction (:900-975) incl. FindServerVehicleFunction (:978-996), SupplyExpectFunction
  * (:880-891) and the idle snapshots (:909-910, :1080-1081).  Asynchronous. */
@@ -153,6 +157,11 @@ int vds_read_counters(vds_handle *h, int64_t *out);
  * all-reduce across GPUs) and, if out != NULL, copied to the host. */
 int vds_reduce_counters(vds_handle *h, int64_t *out, void **dev_ptr);
 
+/* As vds_reduce_counters, delivering the int64 [VDS_NUM_COUNTERS] totals of this handle's
+ * replicas (raw device sums; VALUE_SUM = matched orders only) into caller-owned DEVICE memory,
+ * asynchronously on the handle's stream - the send buffer of the cross-GPU RCCL all-reduce. */
+int vds_reduce_counters_into(vds_handle *h, void *dev_out);
+
 /* Per-order results of replicas [r0, r0+nr): status uint8 (0 never processed - quirk Q1 :914-915,
  * 1 matched, 2 "Reject"), vehicle int32 (index into Vehicles or -1), wait int32
  * (Order.PickupWaitTime, -1 if none); each [nr*O], order-id-major per replica; NULL to skip. */
@@ -171,6 +180,13 @@ int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *i
  * accounting (DESIGN.md "algorithmic bytes"): int64 [8] = {ticks, orders processed, matches,
  * evaluations, arrivals, dispatches, 0, 0} summed over replicas. */
 int vds_read_work(vds_handle *h, int64_t *out);
+
+/* Kernel timing for roofline accounting: while enabled, every vds_step brackets its main tick
+ * kernel with a HIP event pair on the handle's stream.  vds_profile_read synchronises, writes up
+ * to cap per-launch durations in milliseconds (oldest first), sets *n to the number written and
+ * clears the record. */
+int vds_profile_enable(vds_handle *h, int32_t on);
+int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n);
 
 /* Library/ABI version: (major << 16) | minor. */
 int32_t vds_version(void);

@@ -37,6 +37,7 @@ SYMBOLS = {
     "vds_load_orders": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),
     "vds_num_ticks": (C.c_int, [_VP, C.POINTER(_I32)]),
     "vds_reset": (C.c_int, [_VP, _VP]),
+    "vds_reset_again": (C.c_int, [_VP]),
     "vds_step": (C.c_int, [_VP]),
     "vds_apply_dispatch": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "vds_advance": (C.c_int, [_VP]),
@@ -47,6 +48,9 @@ SYMBOLS = {
     "vds_obs_device": (C.c_int, [_VP, C.POINTER(_VP)]),
     "vds_read_counters": (C.c_int, [_VP, _VP]),
     "vds_reduce_counters": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
+    "vds_reduce_counters_into": (C.c_int, [_VP, _VP]),
+    "vds_profile_enable": (C.c_int, [_VP, _I32]),
+    "vds_profile_read": (C.c_int, [_VP, _VP, _I32, C.POINTER(_I32)]),
     "vds_read_orders": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
     "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),
     "vds_read_work": (C.c_int, [_VP, _VP]),

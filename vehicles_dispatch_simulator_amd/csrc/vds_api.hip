@@ -19,6 +19,8 @@ void launch_dispatch(const Static &, const State &, int, int, const int *, const
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
 void launch_selftest_wave_min(const int *, int *, int, hipStream_t);
+void launch_tick_main(const Static &, const State &, int, int, int, hipStream_t);
+void launch_tick_big(const Static &, const State &, int, hipStream_t);
 }  // namespace vds
 
 using namespace vds;
@@ -53,6 +55,9 @@ struct vds_handle {
     int *d_actions = nullptr;
     size_t actions_cap = 0;
     int *d_selftest = nullptr;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
 };
 
 static int fail(vds_handle *h, int code, const char *fmt, ...) {
@@ -132,6 +137,7 @@ int vds_destroy(vds_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->dev_allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return VDS_OK;
@@ -349,6 +355,19 @@ int vds_num_ticks(const vds_handle *h, int32_t *T) {
     return VDS_OK;
 }
 
+static int reset_device(vds_handle *h) {
+    const Static &S = h->S;
+    HIPCHK(h, hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->D.out_veh, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->D.out_wait, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
+    launch_reset(S, h->D, h->d_veh_node, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
+    h->have_reset = true;
+    return VDS_OK;
+}
+
 int vds_reset(vds_handle *h, const int32_t *veh_init_node) {
     if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_reset: load static tables and orders first");
     if (!veh_init_node && h->S.V > 0) return fail(h, VDS_EINVAL, "vds_reset: null veh_init_node");
@@ -361,16 +380,42 @@ int vds_reset(vds_handle *h, const int32_t *veh_init_node) {
             return fail(h, VDS_ESTATE, "vds_reset: vehicle %zu starts on node %d which is in no cluster (:254)", i, node);
     }
     HIPCHK(h, hipMemcpyAsync(h->d_veh_node, veh_init_node, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.out_veh, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.out_wait, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
-    launch_reset(S, h->D, h->d_veh_node, h->stream);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // veh_init_node is caller-owned: do not retain it
-    h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
-    h->have_reset = true;
-    return vds_sync(h);
+    int rc = reset_device(h);
+    if (rc) return rc;
+    return vds_sync(h);   // veh_init_node is caller-owned: do not retain it; also reports idle_cap overflow
+}
+
+int vds_reset_again(vds_handle *h) {
+    if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_reset_again: needs a previous vds_reset");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return reset_device(h);   // asynchronous
+}
+
+int vds_profile_enable(vds_handle *h, int32_t on) {
+    if (!h) return VDS_EINVAL;
+    h->profiling = on != 0;
+    h->ev_used = 0;
+    return VDS_OK;
+}
+
+static hipEvent_t next_event(vds_handle *h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+
+int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
+    if (!h || !ms || !n) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int k = 0;
+    for (size_t i = 0; i + 1 < h->ev_used && k < cap; i += 2, ++k) HIPCHK(h, hipEventElapsedTime(&ms[k], h->ev_pool[i], h->ev_pool[i + 1]));
+    *n = k;
+    h->ev_used = 0;
+    return VDS_OK;
 }
 
 int vds_step(vds_handle *h) {
@@ -379,7 +424,16 @@ int vds_step(vds_handle *h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->t >= h->S.T) return fail(h, VDS_EINVAL, "vds_step: tick %d is past the end of the day (%d ticks, :1048)", h->t, h->S.T);
     if (!h->dfs_mode) {
-        launch_tick(h->S, h->D, h->t, true, h->rpw, h->lds_ints, h->stream);
+        if (h->profiling) {
+            hipEvent_t a = next_event(h), b = next_event(h);
+            if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
+            HIPCHK(h, hipEventRecord(a, h->stream));
+            vds::launch_tick_main(h->S, h->D, h->t, h->rpw, h->lds_ints, h->stream);
+            HIPCHK(h, hipEventRecord(b, h->stream));
+            vds::launch_tick_big(h->S, h->D, h->t, h->stream);
+        } else {
+            launch_tick(h->S, h->D, h->t, true, h->rpw, h->lds_ints, h->stream);
+        }
     } else {
         launch_tick(h->S, h->D, h->t, false, h->rpw, 0, h->stream);
         launch_match_dfs(h->S, h->D, h->t, h->stream);
@@ -541,6 +595,15 @@ int vds_reduce_counters(vds_handle *h, int64_t *out, void **dev_ptr) {
         tmp[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + (long long)h->S.R * (h->value_all - processed_value);
         memcpy(out, tmp, sizeof(tmp));
     }
+    return VDS_OK;
+}
+
+int vds_reduce_counters_into(vds_handle *h, void *dev_out) {
+    if (!h || !h->have_reset || !dev_out) return fail(h, VDS_EINVAL, "vds_reduce_counters_into: bad argument / call order");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    launch_reduce_counters(h->S, h->D, h->d_cnt_per, h->d_cnt_tot, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(dev_out, h->d_cnt_tot, CNT_WORDS * sizeof(long long), hipMemcpyDeviceToDevice, h->stream));
     return VDS_OK;
 }
 

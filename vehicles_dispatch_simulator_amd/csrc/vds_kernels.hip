@@ -609,6 +609,15 @@ void launch_tick(const Static &S, const State &D, int t, bool do_match, int rpw,
     }
 }
 
+void launch_tick_main(const Static &S, const State &D, int t, int rpw, int lds_ints, hipStream_t st) {
+    int chunks = (S.R + 4 * rpw - 1) / (4 * rpw);
+    hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * sizeof(int), st, S, D, t, rpw, lds_ints);
+}
+
+void launch_tick_big(const Static &S, const State &D, int t, hipStream_t st) {
+    hipLaunchKernelGGL(k_tick_big, dim3(256), dim3(256), 0, st, S, D, t);
+}
+
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
     hipLaunchKernelGGL(k_match_dfs, dim3(S.R), dim3(64), 0, st, S, D, t);
 }

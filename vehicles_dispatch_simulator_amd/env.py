@@ -101,6 +101,10 @@ class BatchedDispatchEnv:
             raise Exception("reset: expected %d start nodes, got %d" % (self.R * self.V, v.size))
         self._chk(self._lib.vds_reset(self._h, _p(v)))
 
+    def reset_again(self):
+        """Restart the episode from the start nodes already resident on the device (asynchronous)."""
+        self._chk(self._lib.vds_reset_again(self._h))
+
     def step(self):
         """Update -> Match -> SupplyExpect of the current tick for every replica (asynchronous)."""
         self._chk(self._lib.vds_step(self._h))
@@ -147,6 +151,19 @@ class BatchedDispatchEnv:
         p = C.c_void_p()
         self._chk(self._lib.vds_reduce_counters(self._h, _p(out), C.byref(p)))
         return (out, p.value) if want_device_ptr else out
+
+    def reduce_counters_into(self, dev_ptr: int):
+        """Raw int64[8] totals of this handle's replicas -> caller-owned device memory (async)."""
+        self._chk(self._lib.vds_reduce_counters_into(self._h, C.c_void_p(dev_ptr)))
+
+    def profile(self, on: bool):
+        self._chk(self._lib.vds_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, cap: int = 4096) -> np.ndarray:
+        ms = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32()
+        self._chk(self._lib.vds_profile_read(self._h, _p(ms), cap, C.byref(n)))
+        return ms[:n.value].copy()
 
     def work(self) -> Dict[str, int]:
         out = np.zeros(8, dtype=np.int64)

@@ -1,0 +1,79 @@
+"""Named synthetic workloads of BASELINE.json (`configs`), built from ``synth`` only - nothing
+here reads the reference tree, so they regenerate identically on the GPU box."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import synth
+from .env import neighbors_to_csr
+
+
+@dataclass
+class Workload:
+    name: str
+    city: synth.City
+    release_min: np.ndarray
+    pickup: np.ndarray
+    delivery: np.ndarray
+    vehicles: int
+    neighbor_can_server: bool
+    depth_limit: int
+    nbr_off: np.ndarray
+    nbr_idx: np.ndarray
+    veh_seed: int
+
+    def vehicle_nodes(self, replicas: int, first_replica: int = 0) -> np.ndarray:
+        """[replicas, V]; replica r (global index) draws from random.Random(veh_seed + r)."""
+        valid = self.city.node2cluster >= 0
+        return synth.make_vehicle_nodes(self.veh_seed + first_replica, self.city.N, self.vehicles, replicas,
+                                        None if valid.all() else valid)
+
+    def make_env(self, replicas: int, device: int = 0, stream: Optional[int] = None, **kw):
+        from .env import BatchedDispatchEnv
+        env = BatchedDispatchEnv(self.city.cost, self.city.node2cluster, self.nbr_off, self.nbr_idx, replicas=replicas,
+                                 vehicles=self.vehicles, depth_limit=self.depth_limit,
+                                 neighbor_can_server=self.neighbor_can_server, device=device, stream=stream, **kw)
+        env.load_orders(self.release_min, self.pickup, self.delivery)
+        return env
+
+
+def depth_limit_for(side_m: float, service_m: float) -> int:
+    """NeighborServerDeepLimit, ``simulator.py:290``."""
+    return int((service_m - (0.5 * side_m)) // side_m)
+
+
+def didi_day(name: str = "cfg2", *, N: int = 4139, C: int = 192, vehicles: int = 10000, orders: int = 200000,
+             neighbor: bool = False, service_m: float = 800.0, side_m: float = 800.0,
+             city_seed: int = 2016, order_seed: int = 1101, veh_seed: int = 1234) -> Workload:
+    """BASELINE.json configs[1] (``neighbor=False``) / configs[3] (``neighbor=True, service_m=2000``):
+    192 k-means-shaped clusters over 4,139 nodes, 10k vehicles, ~200k orders in one day."""
+    city = synth.make_city(city_seed, N=N, C=C, with_neighbors=neighbor)
+    start, pick, dele = synth.make_orders(order_seed, N, orders)
+    rel = synth.release_minutes(start)
+    rel = (rel - rel[0]).astype(np.int32)
+    off, idx = neighbors_to_csr(city.neighbors if neighbor else [[] for _ in range(city.C)])
+    return Workload(name=name, city=city, release_min=rel, pickup=pick, delivery=dele, vehicles=vehicles,
+                    neighbor_can_server=neighbor, depth_limit=depth_limit_for(side_m, service_m) if neighbor else 0,
+                    nbr_off=off, nbr_idx=idx, veh_seed=veh_seed)
+
+
+def tiny(name: str = "tiny", *, N: int = 300, C: int = 12, vehicles: int = 150, orders: int = 2500,
+         neighbor: bool = False, depth_limit: int = 2, seed: int = 7) -> Workload:
+    city = synth.make_city(seed, N=N, C=C, with_neighbors=True)
+    start, pick, dele = synth.make_orders(seed + 1, N, orders)
+    rel = synth.release_minutes(start)
+    rel = (rel - rel[0]).astype(np.int32)
+    off, idx = neighbors_to_csr(city.neighbors)
+    return Workload(name=name, city=city, release_min=rel, pickup=pick, delivery=dele, vehicles=vehicles,
+                    neighbor_can_server=neighbor, depth_limit=depth_limit if neighbor else 0, nbr_off=off, nbr_idx=idx,
+                    veh_seed=seed + 2)
+
+
+def algorithmic_bytes(work: dict, vehicles: int) -> int:
+    """SURVEY.md 8(d) byte model of the tick path: 16 B per (order, candidate) evaluation
+    (idle entry 8 + vehicle location 4 + cost 4), 24 B per processed order, 24 B per match,
+    4 B per vehicle per tick (arrival scan) and 28 B per arrival."""
+    return (16 * work["evals"] + 24 * work["orders"] + 24 * work["matches"] + 4 * vehicles * work["ticks"] + 28 * work["arrivals"])
