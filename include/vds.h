@@ -63,10 +63,12 @@ typedef struct vds_config {
     int64_t pickup_reject_threshold;  /* raw integer of PICKUPTIMEWINDOW (config/setting.py:7 ->
                                          600000000000): `cost > PICKUPTIMEWINDOW` (:943) compares
                                          the integer minute cost with this raw value */
-    int32_t idle_cap;                 /* slots per (replica, cluster) idle table; 0 = auto */
-    int32_t inflight_cap;             /* slots per (replica, cluster) arrival table; 0 = auto */
-    int32_t inbox_cap;                /* slots per (replica, cluster) per-tick arrival inbox; 0 = auto */
-    int32_t count_evals;              /* 1: maintain VDS_CNT_EVALS (default 1) */
+    int32_t idle_cap;                 /* slots per (replica, cluster) idle table, <= 1024; 0 = auto */
+    int32_t ring_cap;                 /* arrivals one (replica, cluster) can receive for ONE tick; 0 = auto */
+    int32_t ring_ticks;               /* arrival-ring horizon in ticks (power of two); trips that end later go
+                                         through the slower "far" tables; 0 = 32 */
+    int32_t far_cap;                  /* slots per (replica, cluster) far table; 0 = auto */
+    int32_t force_generic;            /* 1: never use the row-mapped fast kernel (testing) */
 } vds_config;
 
 /* Fill cfg with defaults (tick 10 min, threshold 6e11, caps auto). */

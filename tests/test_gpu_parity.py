@@ -114,29 +114,83 @@ def run_day(g, R, same_init, list_every=1, **kw):
     env.close()
 
 
+MODES = {
+    "fast": {},                              # row-mapped kernel (where the cost range allows) + arrival ring
+    "generic": {"force_generic": True},      # one wavefront per bucket
+    "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
+    "far_generic": {"ring_ticks": 4, "force_generic": True},
+}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", TINY)
-def test_tiny_golden_per_tick(name):
+def test_tiny_golden_per_tick(name, mode):
     g = load_golden(name)
-    run_day(g, R=3, same_init=bool(len(g["dispatch_log"])))
+    run_day(g, R=3, same_init=bool(len(g["dispatch_log"])), **MODES[mode])
 
 
-@pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_kmeans_dfs2"])
-def test_many_replicas_ragged(name):
+@pytest.mark.parametrize("mode", ["fast", "generic"])
+@pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid"])
+def test_many_replicas_ragged(name, mode):
     """R not a multiple of the workgroup's replica run; every replica its own vehicle seed."""
     g = load_golden(name)
-    run_day(g, R=37, same_init=False, list_every=29)
+    run_day(g, R=37, same_init=False, list_every=29, **MODES[mode])
+
+
+def _burst(g, n_orders):
+    """n identical orders in one minute, all vehicles parked on the pickup node: every match ends
+    its trip in the same cluster at the same tick (maximum pressure on one ring slot)."""
+    g = dict(g)
+    P = int(np.flatnonzero(g["node2cluster"] == 2)[0])
+    X = int(np.flatnonzero(g["node2cluster"] == 7)[0])
+    g["o_release_min"] = np.zeros(n_orders + 1, dtype=np.int32)
+    g["o_pickup"] = np.full(n_orders + 1, P, dtype=np.int32)
+    g["o_delivery"] = np.full(n_orders + 1, X, dtype=np.int32)
+    g["V"] = np.int64(120)
+    return g, P
+
+
+def test_tight_ring_cap_overflow_is_reported():
+    g, P = _burst(load_golden("tiny_kmeans"), 100)
+    env = make_env(g, 2, ring_cap=16, idle_cap=128)
+    env.reset(np.full((2, 120), P, dtype=np.int32))
+    with pytest.raises(Exception, match="arrival ring overflow"):
+        env.run(env.T)
+        env.sync()
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "generic", "far"])
+def test_burst_of_identical_orders(mode):
+    """100 identical orders / 120 co-located vehicles: ties everywhere, 100 arrivals in one slot."""
+    g, P = _burst(load_golden("tiny_kmeans"), 100)
+    env = make_env(g, 2, ring_cap=128, idle_cap=128, **MODES[mode])
+    init = np.full((2, 120), P, dtype=np.int32)
+    env.reset(init)
+    o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], 0, False, g["o_release_min"], g["o_pickup"], g["o_delivery"], 120)
+    o.reset(init[0])
+    for t in range(env.T):
+        env.step(); o.begin_tick()
+        check_lists(env, 1, o, t)
+        np.testing.assert_array_equal(env.obs()["supply"][1], o.obs()["supply"])
+        env.advance(); o.end_tick()
+    od, oo = env.orders(), o.orders()
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(od[k][0], oo[k])
+    env.close()
 
 
 def test_small_caps_overflow_is_reported():
     g = load_golden("tiny_kmeans")
-    env = make_env(g, 2, idle_cap=64, inflight_cap=64, inbox_cap=64)
+    env = make_env(g, 2, idle_cap=64)
     init = np.tile(np.full(int(g["V"]), int(np.flatnonzero(g["node2cluster"] == 0)[0]), dtype=np.int32), (2, 1))
     with pytest.raises(Exception, match="idle table overflow"):
         env.reset(init)   # 150 vehicles in one cluster > idle_cap 64
     env.close()
 
 
-def test_all_vehicles_in_one_cluster_oversize_bucket():
+@pytest.mark.parametrize("mode", ["fast", "generic"])
+def test_all_vehicles_in_one_cluster_oversize_bucket(mode):
     """> 256 idle vehicles in one cluster exercises the deferred 16-slot kernel."""
     g = load_golden("tiny_kmeans")
     V = 600
@@ -145,7 +199,7 @@ def test_all_vehicles_in_one_cluster_oversize_bucket():
     node = int(np.flatnonzero(g["node2cluster"] == 5)[0])
     nodes5 = np.flatnonzero(g["node2cluster"] == 5)
     init = nodes5[np.arange(V) % nodes5.size].astype(np.int32)[None, :].repeat(2, axis=0)
-    env = make_env(g, 2, idle_cap=640)
+    env = make_env(g, 2, idle_cap=640, **MODES[mode])
     env.reset(init)
     o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], int(g["depth_limit"]), False,
                g["o_release_min"], g["o_pickup"], g["o_delivery"], V)

@@ -20,7 +20,8 @@ class VdsConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("device", C.c_int32), ("replicas", C.c_int32), ("vehicles", C.c_int32),
         ("tick_minutes", C.c_int32), ("neighbor_can_server", C.c_int32), ("pickup_reject_threshold", C.c_int64),
-        ("idle_cap", C.c_int32), ("inflight_cap", C.c_int32), ("inbox_cap", C.c_int32), ("count_evals", C.c_int32),
+        ("idle_cap", C.c_int32), ("ring_cap", C.c_int32), ("ring_ticks", C.c_int32), ("far_cap", C.c_int32),
+        ("force_generic", C.c_int32),
     ]
 
 
@@ -55,7 +56,7 @@ SYMBOLS = {
     "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),
     "vds_read_work": (C.c_int, [_VP, _VP]),
 }
-TEST_SYMBOLS = {"vds_selftest_wave_min": (C.c_int, [_VP, _VP, _VP, _I32])}
+TEST_SYMBOLS = {"vds_selftest_dpp": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32])}
 
 _lib = None
 

@@ -12,15 +12,15 @@
 
 namespace vds {
 void launch_reset(const Static &, const State &, const int *, hipStream_t);
-void launch_tick(const Static &, const State &, int, bool, int, int, hipStream_t);
+void launch_tick_main(const Static &, const State &, int, int, hipStream_t);
+void launch_tick_work(const Static &, const State &, int, hipStream_t);
+void launch_update_only(const Static &, const State &, int, hipStream_t);
 void launch_match_dfs(const Static &, const State &, int, hipStream_t);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, hipStream_t);
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
-void launch_selftest_wave_min(const int *, int *, int, hipStream_t);
-void launch_tick_main(const Static &, const State &, int, int, int, hipStream_t);
-void launch_tick_big(const Static &, const State &, int, hipStream_t);
+void launch_selftest_dpp(const int *, int *, int *, int *, int *, int, hipStream_t);
 }  // namespace vds
 
 using namespace vds;
@@ -40,7 +40,7 @@ struct vds_handle {
     int last_stepped = -1;  // tick of the last vds_step
     int dispatch_seq = 0;
     int O = 0;              // all orders incl. never-processed ones
-    int lds_ints = 0, rpw = 4;
+    int lds_ints = 0;
     // host mirrors
     std::vector<int> node2cluster, node_local, cl_off, cl_nodes, cost_host;
     std::vector<int> so_id;              // q -> order id
@@ -108,7 +108,6 @@ void vds_config_init(vds_config *cfg) {
     cfg->vehicles = 6000;                               // config/setting.py:23
     cfg->tick_minutes = 10;                             // config/setting.py:6
     cfg->pickup_reject_threshold = 600000000000LL;      // config/setting.py:7 (raw integer, quirk Q3)
-    cfg->count_evals = 1;
 }
 
 const char *vds_last_error(const vds_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -168,7 +167,6 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
     S.N = N; S.C = C; S.V = h->cfg.vehicles; S.R = h->cfg.replicas;
     S.tick_minutes = h->cfg.tick_minutes;
     S.reject_threshold = h->cfg.pickup_reject_threshold;
-    S.count_evals = h->cfg.count_evals;
     h->node2cluster.assign(node2cluster, node2cluster + N);
     h->cl_off.assign(C + 1, 0);
     for (int n = 0; n < N; ++n) {
@@ -241,35 +239,53 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
     if ((rc = upload(h, &d, blk))) return rc; S.blk = d;
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;
     if ((rc = upload(h, &d, dfs_seq))) return rc; S.dfs_seq = d;
-    // capacities
-    const int V = S.V, R = S.R;
+    // fast-kernel preconditions: packed (cost << 7 | position) keys, no window rejects
+    {
+        int cmin = 0x7FFFFFFF, cmax = -0x7FFFFFFF - 1;
+        for (size_t i = 0; i < (size_t)N * N; ++i) { cmin = std::min(cmin, cost[i]); cmax = std::max(cmax, cost[i]); }
+        S.fast_ok = (cmin >= 0 && cmax < (1 << 23) && (long long)cmax <= S.reject_threshold) ? 1 : 0;
+        if (h->cfg.force_generic) S.fast_ok = 0;
+    }
+    // LDS budget for the cluster cost block
+    const int lds_budget_ints = (64 * 1024) / 4;
+    h->lds_ints = std::min(max_nc * max_nc, lds_budget_ints);
+    h->have_static = true;
+    return VDS_OK;
+}
+
+static int alloc_state(vds_handle *h, int O) {
+    Static &S = h->S;
+    State &D = h->D;
+    const int V = S.V, R = S.R, C = S.C;
     const int per = (V + C - 1) / C;
     int idle_cap = h->cfg.idle_cap > 0 ? h->cfg.idle_cap : std::min(round_up(std::max(V, 1), 64), round_up(4 * per + 64, 64));
-    int fl_cap = h->cfg.inflight_cap > 0 ? h->cfg.inflight_cap : std::min(round_up(std::max(V, 1), 64), round_up(3 * per + 64, 64));
-    int in_cap = h->cfg.inbox_cap > 0 ? h->cfg.inbox_cap : std::min(round_up(std::max(V, 1), 64), round_up(2 * per + 64, 64));
-    idle_cap = round_up(idle_cap, 64); fl_cap = round_up(fl_cap, 64); in_cap = round_up(in_cap, 64);
-    if (idle_cap > 1024) return fail(h, VDS_EINVAL, "vds_load_static: idle_cap=%d > 1024 slots per (replica, cluster) is not supported by the register-resident match kernel", idle_cap);
-    S.idle_cap = idle_cap; S.fl_cap = fl_cap; S.in_cap = in_cap;
+    idle_cap = round_up(idle_cap, 64);
+    if (idle_cap > 1024) return fail(h, VDS_EINVAL, "idle_cap=%d > 1024 slots per (replica, cluster) is not supported by the register-resident match kernels", idle_cap);
+    int H = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
+    if (H < 2 || (H & (H - 1))) return fail(h, VDS_EINVAL, "ring_ticks=%d must be a power of two >= 2", H);
+    const long long per_tick = ((long long)O + (long long)std::max(S.T, 1) * C - 1) / ((long long)std::max(S.T, 1) * C);
+    int ring_cap = h->cfg.ring_cap > 0 ? h->cfg.ring_cap : (int)std::min<long long>(round_up(std::max(V, 16), 16), round_up((int)std::min<long long>(10 * per_tick + 32, 60000), 16));
+    ring_cap = round_up(ring_cap, 16);
+    if (ring_cap > 65520) return fail(h, VDS_EINVAL, "ring_cap=%d > 65520 unsupported", ring_cap);
+    int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
+    S.idle_cap = idle_cap; S.fl_cap = far_cap; S.in_cap = far_cap; S.H = H; S.ring_cap = ring_cap;
     const size_t B = (size_t)C * R;
-    State &D = h->D;
+    int rc;
     if ((rc = dev_alloc(h, &D.hdr, B * HDR_WORDS))) return rc;
     if ((rc = dev_alloc(h, &D.cnt, B * CNT_WORDS))) return rc;
     if ((rc = dev_alloc(h, &D.idle, B * idle_cap))) return rc;
-    if ((rc = dev_alloc(h, &D.fl, B * fl_cap))) return rc;
-    if ((rc = dev_alloc(h, &D.inbox, 2 * B * in_cap))) return rc;
+    if ((rc = dev_alloc(h, &D.ring, (size_t)H * B * ring_cap))) return rc;
+    if ((rc = dev_alloc(h, &D.ring_cnt, (size_t)H * B))) return rc;
+    if ((rc = dev_alloc(h, &D.fl, B * far_cap))) return rc;
+    if ((rc = dev_alloc(h, &D.inbox, 2 * B * far_cap))) return rc;
     if ((rc = dev_alloc(h, &D.err, 4))) return rc;
     if ((rc = dev_alloc(h, &D.work, 2 + 2 * B))) return rc;
-    HIPCHK(h, hipMemset(D.work, 0, 2 * sizeof(int)));
     if ((rc = dev_alloc(h, &h->d_veh_node, (size_t)R * V))) return rc;
     if ((rc = dev_alloc(h, &h->d_obs, 5 * (size_t)R * C))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt_per, (size_t)R * CNT_WORDS))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt_tot, CNT_WORDS))) return rc;
     HIPCHK(h, hipMemset(D.err, 0, 4 * sizeof(int)));
-    // LDS budget for the cluster cost block: keep >= 2 workgroups per CU
-    const int lds_budget_ints = (64 * 1024) / 4;
-    h->lds_ints = std::min(max_nc * max_nc, lds_budget_ints);
-    h->rpw = 4;
-    h->have_static = true;
+    HIPCHK(h, hipMemset(D.work, 0, 2 * sizeof(int)));
     return VDS_OK;
 }
 
@@ -345,6 +361,7 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
     if ((rc = dev_alloc(h, &h->D.out_veh, (size_t)S.R * std::max(n_proc, 1)))) return rc;
     if ((rc = dev_alloc(h, &h->D.out_wait, (size_t)S.R * std::max(n_proc, 1)))) return rc;
+    if ((rc = alloc_state(h, O))) return rc;
     h->have_orders = true;
     return VDS_OK;
 }
@@ -359,6 +376,7 @@ static int reset_device(vds_handle *h) {
     const Static &S = h->S;
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.out_veh, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.out_wait, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
     launch_reset(S, h->D, h->d_veh_node, h->stream);
@@ -424,18 +442,17 @@ int vds_step(vds_handle *h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->t >= h->S.T) return fail(h, VDS_EINVAL, "vds_step: tick %d is past the end of the day (%d ticks, :1048)", h->t, h->S.T);
     if (!h->dfs_mode) {
+        hipEvent_t a = nullptr, b = nullptr;
         if (h->profiling) {
-            hipEvent_t a = next_event(h), b = next_event(h);
+            a = next_event(h); b = next_event(h);
             if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
             HIPCHK(h, hipEventRecord(a, h->stream));
-            vds::launch_tick_main(h->S, h->D, h->t, h->rpw, h->lds_ints, h->stream);
-            HIPCHK(h, hipEventRecord(b, h->stream));
-            vds::launch_tick_big(h->S, h->D, h->t, h->stream);
-        } else {
-            launch_tick(h->S, h->D, h->t, true, h->rpw, h->lds_ints, h->stream);
         }
+        launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
+        if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
+        launch_tick_work(h->S, h->D, h->t, h->stream);
     } else {
-        launch_tick(h->S, h->D, h->t, false, h->rpw, 0, h->stream);
+        launch_update_only(h->S, h->D, h->t, h->stream);
         launch_match_dfs(h->S, h->D, h->t, h->stream);
     }
     HIPCHK(h, hipGetLastError());
@@ -468,8 +485,9 @@ int vds_sync(vds_handle *h) {
     int err[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpy(err, h->D.err, sizeof(err), hipMemcpyDeviceToHost));
     if (err[0] & ERR_IDLE_CAP) return fail(h, VDS_ECAPACITY, "idle table overflow: more than idle_cap=%d idle vehicles in one (replica, cluster); raise vds_config.idle_cap", h->S.idle_cap);
-    if (err[0] & ERR_FL_CAP) return fail(h, VDS_ECAPACITY, "arrival table overflow: more than inflight_cap=%d vehicles heading to one (replica, cluster); raise vds_config.inflight_cap", h->S.fl_cap);
-    if (err[0] & ERR_INBOX_CAP) return fail(h, VDS_ECAPACITY, "arrival inbox overflow: more than inbox_cap=%d vehicles sent to one (replica, cluster) in one tick; raise vds_config.inbox_cap", h->S.in_cap);
+    if (err[0] & ERR_FL_CAP) return fail(h, VDS_ECAPACITY, "far-arrival table overflow: more than far_cap=%d vehicles on trips longer than the ring horizon to one (replica, cluster); raise vds_config.far_cap", h->S.fl_cap);
+    if (err[0] & ERR_INBOX_CAP) return fail(h, VDS_ECAPACITY, "far-arrival inbox overflow: more than far_cap=%d long trips sent to one (replica, cluster) in one tick; raise vds_config.far_cap", h->S.in_cap);
+    if (err[0] & ERR_RING_CAP) return fail(h, VDS_ECAPACITY, "arrival ring overflow: more than ring_cap=%d vehicles due in one (replica, cluster) in one tick; raise vds_config.ring_cap", h->S.ring_cap);
     if (err[0] & ERR_DISPATCH) return fail(h, VDS_ESTATE, "dispatch of an idle position that does not exist (or listed twice)");
     return VDS_OK;
 }
@@ -685,10 +703,14 @@ int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *i
         }
     }
     if (want_arr) {
-        const int np = (h->last_stepped + 1) & 1;   // parity holding posts not yet drained
-        std::vector<int4> fl((size_t)C * S.fl_cap), inb((size_t)C * S.in_cap);
+        const int np = (h->last_stepped + 1) & 1;   // parity holding far posts not yet drained
+        const int H = S.H;
+        std::vector<int4> fl((size_t)C * S.fl_cap), inb((size_t)C * S.in_cap), ring((size_t)H * C * S.ring_cap);
+        std::vector<int> rcnt((size_t)H * C);
         HIPCHK(h, hipMemcpy2D(fl.data(), S.fl_cap * sizeof(int4), h->D.fl + (size_t)replica * S.fl_cap, (size_t)R * S.fl_cap * sizeof(int4), S.fl_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy2D(inb.data(), S.in_cap * sizeof(int4), h->D.inbox + ((size_t)np * C * R + replica) * S.in_cap, (size_t)R * S.in_cap * sizeof(int4), S.in_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy2D(ring.data(), S.ring_cap * sizeof(int4), h->D.ring + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(int4), S.ring_cap * sizeof(int4), (size_t)H * C, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy2D(rcnt.data(), sizeof(int), h->D.ring_cnt + replica, (size_t)R * sizeof(int), sizeof(int), (size_t)H * C, hipMemcpyDeviceToHost));
         int n = 0;
         arr_off[0] = 0;
         std::vector<int4> ent;
@@ -698,8 +720,13 @@ int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *i
             const int q = h->last_stepped < 0 ? 0 : hdr[(size_t)c * HDR_WORDS + HDR_INBOX0 + np];
             for (int j = 0; j < f; ++j) ent.push_back(fl[(size_t)c * S.fl_cap + j]);
             for (int j = 0; j < q; ++j) ent.push_back(inb[(size_t)c * S.in_cap + j]);
+            for (int sl = 0; sl < H; ++sl) {
+                const int k = rcnt[(size_t)sl * C + c] & 0xFFFF;
+                for (int j = 0; j < k; ++j) ent.push_back(ring[((size_t)sl * C + c) * S.ring_cap + j]);
+            }
             std::sort(ent.begin(), ent.end(), [](const int4 &a, const int4 &b) { return entry_key(a.y, a.w) < entry_key(b.y, b.w); });
             for (const int4 &e : ent) {
+                if (n >= S.V) return fail(h, VDS_ESTATE, "vds_read_lists: more in-flight entries than vehicles");
                 arr_veh[n] = e.x;
                 if (arr_min) arr_min[n] = e.z;
                 if (arr_order) arr_order[n] = meta_is_dispatch(e.w) ? -1 : e.y;
@@ -712,19 +739,28 @@ int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *i
     return VDS_OK;
 }
 
-// Test hook (not part of the drop-in surface): runs the DPP wave-min reduction on `nwaves` x 64
-// int32 values and returns the per-wave minima.
-int vds_selftest_wave_min(vds_handle *h, const int32_t *in, int32_t *out, int32_t nwaves) {
-    if (!h || !in || !out || nwaves < 1) return VDS_EINVAL;
+// Test hook (not part of the drop-in surface): runs the DPP primitives on `nwaves` x 64 int32
+// values: out_wave [nwaves] wave minima; out_rowmin / out_rowsum / out_rowscan [nwaves*64] per-lane
+// 16-lane-row min, row sum and row inclusive scan (the latter two of value & 0xFFFF).
+int vds_selftest_dpp(vds_handle *h, const int32_t *in, int32_t *out_wave, int32_t *out_rowmin, int32_t *out_rowsum,
+                     int32_t *out_rowscan, int32_t nwaves) {
+    if (!h || !in || !out_wave || !out_rowmin || !out_rowsum || !out_rowscan || nwaves < 1) return VDS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    int *din = nullptr, *dout = nullptr;
-    HIPCHK(h, hipMalloc((void **)&din, (size_t)nwaves * 64 * sizeof(int)));
-    HIPCHK(h, hipMalloc((void **)&dout, (size_t)nwaves * sizeof(int)));
-    HIPCHK(h, hipMemcpy(din, in, (size_t)nwaves * 64 * sizeof(int), hipMemcpyHostToDevice));
-    launch_selftest_wave_min(din, dout, nwaves, h->stream);
+    const size_t n = (size_t)nwaves * 64;
+    int *din = nullptr, *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+    HIPCHK(h, hipMalloc((void **)&din, n * sizeof(int)));
+    HIPCHK(h, hipMalloc((void **)&d0, (size_t)nwaves * sizeof(int)));
+    HIPCHK(h, hipMalloc((void **)&d1, n * sizeof(int)));
+    HIPCHK(h, hipMalloc((void **)&d2, n * sizeof(int)));
+    HIPCHK(h, hipMalloc((void **)&d3, n * sizeof(int)));
+    HIPCHK(h, hipMemcpy(din, in, n * sizeof(int), hipMemcpyHostToDevice));
+    launch_selftest_dpp(din, d0, d1, d2, d3, nwaves, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, dout, (size_t)nwaves * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(din); (void)hipFree(dout);
+    HIPCHK(h, hipMemcpy(out_wave, d0, (size_t)nwaves * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out_rowmin, d1, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out_rowsum, d2, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out_rowscan, d3, n * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(d3);
     return VDS_OK;
 }
 

@@ -1,48 +1,47 @@
 // Device-side data model of libvds (gfx950 / CDNA4 only).
 //
 // Everything is Struct-of-Arrays in HBM, laid out CLUSTER-major: the unit of parallel work
-// is one (cluster, replica) "bucket", and a workgroup owns one cluster for a run of
-// replicas, so that the cluster's cost block sits in LDS once and every bucket access is a
+// is one (cluster, replica) "bucket"; a workgroup owns one cluster for a run of consecutive
+// replicas, so the cluster's cost block sits in LDS once and every bucket access is a
 // contiguous, coalesced segment.
 //
-//   hdr   [C][R][8]  int32   bucket header (see HDR_* below)
-//   cnt   [C][R][8]  int64   bucket-owned partial counters (no atomics; reduced over C on read)
-//   idle  [C][R][idle_cap]   {veh, loc_local}      Cluster.IdleVehicles, kept in LIST ORDER
-//   fl    [C][R][fl_cap]     {veh, id, arrive, meta} Cluster.VehiclesArrivetime (unordered slots,
-//                                                   dict order is carried by the entry key)
-//   inbox [2][C][R][in_cap]  same entry; arrivals posted by OTHER buckets during tick t land in
-//                                                   parity (t+1)&1 and are drained by the owner at t+1
-//   out_veh/out_wait [R][Oq] per-order result, indexed by bucket-sorted order position q
+//   hdr      [C][R][8]           int32  bucket header (HDR_* below)
+//   cnt      [C][R][8]           int64  bucket-owned partial counters (no atomics; reduced on read)
+//   idle     [C][R][idle_cap]    {veh, loc_local}   Cluster.IdleVehicles, kept in LIST ORDER
+//   ring     [H][C][R][ring_cap] arrival entries indexed by ARRIVAL TICK mod H: the in-flight part of
+//                                Cluster.VehiclesArrivetime.  A tick only touches the slot that is
+//                                due; other buckets append with one atomic on ring_cnt.
+//   ring_cnt [H][C][R]           low 16 bits: entries in the slot, high 16: those carrying an order
+//                                (SupplyExpect of the previous tick reads the high half)
+//   fl/inbox                     "far" entries whose arrival lies >= H ticks ahead (rare): owner-private
+//                                list + double-buffered inbox, migrated into the ring when they get near
+//   out_veh/out_wait [R][Oq]     per-order result, indexed by bucket-sorted order position q
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace vds {
 
-// bucket header dwords
 enum {
-    HDR_IDLE = 0,    // len(IdleVehicles)
-    HDR_FL = 1,      // entries in fl (owner-private part of VehiclesArrivetime)
-    HDR_INBOX0 = 2,  // inbox fill, parity 0 (atomic target of other buckets)
-    HDR_INBOX1 = 3,  // inbox fill, parity 1
-    HDR_SE0 = 4,     // SupplyExpect accumulator, parity 0 (atomic target)
-    HDR_SE1 = 5,     // SupplyExpect accumulator, parity 1
+    HDR_IDLE = 0,       // len(IdleVehicles)
+    HDR_FL = 1,         // far list fill
+    HDR_INBOX0 = 2,     // far inbox fill, parity 0 (atomic target of other buckets)
+    HDR_INBOX1 = 3,     // far inbox fill, parity 1
     HDR_IDLE_PRE = 6,   // PerMatchIdleVehicles of the last tick
     HDR_ORDERS = 7,     // len(Cluster.Orders) of the last tick
     HDR_WORDS = 8
 };
 
-// bucket counter slots (int64)
 enum {
     CNT_ORDERS = 0, CNT_REJECTS = 1, CNT_WAIT = 2, CNT_VALUE = 3,
     CNT_EVALS = 4, CNT_ARRIVALS = 5, CNT_DISPATCH = 6, CNT_DISPATCH_COST = 7, CNT_WORDS = 8
 };
 
 // sticky device error bits (err[0])
-enum { ERR_IDLE_CAP = 1, ERR_FL_CAP = 2, ERR_INBOX_CAP = 4, ERR_DISPATCH = 8 };
+enum { ERR_IDLE_CAP = 1, ERR_FL_CAP = 2, ERR_INBOX_CAP = 4, ERR_DISPATCH = 8, ERR_RING_CAP = 16 };
 
-// in-flight entry: x = vehicle, y = id (order id, or dispatch sequence number),
-// z = arrival minute, w = meta = insert_tick << 16 | is_dispatch << 15 | dest_local.
+// arrival entry: x = vehicle, y = id (order id, or dispatch sequence number), z = arrival minute,
+// w = meta = insert_tick << 16 | is_dispatch << 15 | dest_local.
 // Dict insertion order == ascending key (insert_tick, is_dispatch, id).
 __host__ __device__ inline int meta_pack(int tick, int is_dispatch, int dest_local) {
     return (tick << 16) | (is_dispatch << 15) | dest_local;
@@ -59,9 +58,10 @@ struct Static {
     int N, C, V, R, Oq, T;
     int tick_minutes, now0;          // RealExpTime at tick 0
     long long reject_threshold;
-    int idle_cap, fl_cap, in_cap;
-    int count_evals;
-    int max_nc;                      // largest cluster (nodes)
+    int idle_cap, fl_cap, in_cap;    // fl_cap / in_cap: far list / far inbox
+    int H, ring_cap;                 // arrival ring: H ticks (power of two) x ring_cap entries
+    int fast_ok;                     // costs fit the packed (cost << 7 | pos) fast kernel and never exceed the reject threshold
+    int max_nc;
     const int *cost;                 // [N*N]
     const int *node2cluster;         // [N]
     const int *node_local;           // [N]
@@ -81,12 +81,14 @@ struct State {
     int *hdr;
     long long *cnt;
     uint2 *idle;
+    int4 *ring;
+    int *ring_cnt;
     int4 *fl;
     int4 *inbox;
     int *out_veh;
     int *out_wait;
     int *err;
-    int *work;   // [2] oversize-bucket counters by tick parity, then [2][C*R] bucket indices
+    int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
 };
 
 }  // namespace vds

@@ -40,7 +40,8 @@ class BatchedDispatchEnv:
     def __init__(self, cost, node2cluster, nbr_off, nbr_idx, *, replicas: int, vehicles: int,
                  depth_limit: int = 0, neighbor_can_server: bool = False, tick_minutes: int = 10,
                  reject_threshold: int = PICKUP_REJECT_THRESHOLD, device: int = 0,
-                 idle_cap: int = 0, inflight_cap: int = 0, inbox_cap: int = 0, stream: Optional[int] = None):
+                 idle_cap: int = 0, ring_cap: int = 0, ring_ticks: int = 0, far_cap: int = 0,
+                 force_generic: bool = False, stream: Optional[int] = None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.VdsConfig()
@@ -48,7 +49,8 @@ class BatchedDispatchEnv:
         cfg.device, cfg.replicas, cfg.vehicles = int(device), int(replicas), int(vehicles)
         cfg.tick_minutes, cfg.neighbor_can_server = int(tick_minutes), int(bool(neighbor_can_server))
         cfg.pickup_reject_threshold = int(reject_threshold)
-        cfg.idle_cap, cfg.inflight_cap, cfg.inbox_cap = int(idle_cap), int(inflight_cap), int(inbox_cap)
+        cfg.idle_cap, cfg.ring_cap, cfg.ring_ticks, cfg.far_cap = int(idle_cap), int(ring_cap), int(ring_ticks), int(far_cap)
+        cfg.force_generic = int(bool(force_generic))
         rc = self._lib.vds_create(C.byref(cfg), C.byref(self._h))
         if rc:
             msg = self._lib.vds_last_error(None).decode()
