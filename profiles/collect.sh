@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collect rocprofv3 evidence for bench.py on the GPU box (run through gpurun).
+#   bash profiles/collect.sh <tag> [bench args...]
+# Writes raw CSVs under gpurun_out/prof_<tag>/ ; summarise with profiles/summarise.py
+export TMPDIR=/tmp
+TAG=$1; shift
+O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+rm -rf $O; mkdir -p $O
+B="python bench.py --no-cpu-baseline $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq -- $B --steps 1 --warmup 0 > $O/sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 0 > $O/sq2.log 2>&1
+tail -1 $O/stats.log | cut -c1-300

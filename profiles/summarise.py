@@ -1,0 +1,36 @@
+"""Summarise the raw rocprofv3 CSVs of profiles/collect.sh into profiles/<tag>/ (committed).
+
+    python profiles/summarise.py <tag> [kernel-substring]
+"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+import pandas as pd
+
+tag = sys.argv[1]
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_tick_rows"
+src = os.path.join("gpurun_out", "prof_" + tag)
+dst = os.path.join("profiles", tag)
+os.makedirs(dst, exist_ok=True)
+st = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(st, os.path.join(dst, "kernel_stats.csv"))
+out = {"_note": "rocprofv3 --pmc, one pass per group (FETCH_SIZE | WRITE_SIZE | SQ_* ...), per-launch means for kernels matching '%s'; "
+                "FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads by up to 2x on gfx950 "
+                "(MI355X_MICROARCH.md, HBM section); SQ_*_CYCLES are quad-cycles summed over waves" % kern}
+for name in ("fetch", "write", "sq", "sq2"):
+    fs = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    if not fs:
+        continue
+    df = pd.read_csv(fs[0])
+    k = df[df["Kernel_Name"].str.contains(kern, regex=False)]
+    g = k.groupby("Counter_Name")["Counter_Value"].agg(["mean", "count"])
+    for n, row in g.iterrows():
+        out[n] = {"mean_per_launch": float(row["mean"]), "launches": int(row["count"])}
+    if len(k):
+        out["_dispatch"] = {c: int(k[c].iloc[0]) for c in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size")}
+json.dump(out, open(os.path.join(dst, "pmc_%s.json" % kern), "w"), indent=1)
+print(open(os.path.join(dst, "kernel_stats.csv")).read()[:1500])
+print(json.dumps(out, indent=1))

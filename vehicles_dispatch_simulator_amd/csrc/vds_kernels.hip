@@ -120,6 +120,64 @@ __global__ __launch_bounds__(256) void k_reset(Static S, State D, const int *veh
     if (lane < CNT_WORDS) D.cnt[b * CNT_WORDS + lane] = 0;
 }
 
+// k_reset_fast: one workgroup per replica - a stable counting sort of the vehicles by cluster through
+// LDS: each wavefront owns a contiguous quarter of the vehicle range (so vehicle order is kept),
+// pass A counts per (wave, cluster), a prefix over the waves gives every wave its base position in
+// each idle list, pass B places the vehicles chunk by chunk (lanes of one cluster are ranked with a
+// ballot).  Needs 4*C ints of LDS; bigger cities use k_reset.
+__global__ __launch_bounds__(256) void k_reset_fast(Static S, State D, const int *veh_node) {
+    extern __shared__ int lds_dyn[];
+    const int r = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int C = S.C;
+    const int seg = (((S.V + 3) / 4) + WAVE - 1) / WAVE * WAVE;
+    const int v0 = min(S.V, wave * seg), v1 = min(S.V, v0 + seg);
+    const int *vn = veh_node + (size_t)r * S.V;
+    int *mine = lds_dyn + wave * C;
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) lds_dyn[i] = 0;
+    __syncthreads();
+    for (int base = v0; base < v1; base += WAVE) {
+        const int v = base + lane;
+        if (v < v1) atomicAdd(&mine[S.node2cluster[vn[v]]], 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int t0 = lds_dyn[c], t1 = lds_dyn[C + c], t2 = lds_dyn[2 * C + c], t3 = lds_dyn[3 * C + c];
+        lds_dyn[c] = 0; lds_dyn[C + c] = t0; lds_dyn[2 * C + c] = t0 + t1; lds_dyn[3 * C + c] = t0 + t1 + t2;
+        int total = t0 + t1 + t2 + t3;
+        if (total > S.idle_cap) { atomicOr(&D.err[0], ERR_IDLE_CAP); total = S.idle_cap; }
+        const size_t b = (size_t)c * S.R + r;
+        int4 *h4 = reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS);
+        h4[0] = make_int4(total, 0, 0, 0);
+        h4[1] = make_int4(0, 0, 0, 0);
+        int4 *c4 = reinterpret_cast<int4 *>(D.cnt + b * CNT_WORDS);
+        c4[0] = make_int4(0, 0, 0, 0); c4[1] = make_int4(0, 0, 0, 0); c4[2] = make_int4(0, 0, 0, 0); c4[3] = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int base = v0; base < v1; base += WAVE) {
+        const int v = base + lane;
+        const bool valid = v < v1;
+        const int node = valid ? vn[v] : 0;
+        const int cl = valid ? S.node2cluster[node] : -1;
+        const unsigned nl = valid ? (unsigned)S.node_local[node] : 0u;
+        unsigned long long remaining = ballot(valid);
+        while (remaining) {
+            const int leader = __ffsll((long long)remaining) - 1;
+            const int lc = rdlane(cl, leader);
+            const unsigned long long same = ballot(cl == lc);
+            const int bs = mine[lc];
+            if (cl == lc) {
+                const int pos = bs + popc64(same & lanemask_lt());
+                if (pos < S.idle_cap) D.idle[((size_t)lc * S.R + r) * S.idle_cap + pos] = make_uint2((unsigned)v, nl);
+            }
+            wave_fence();
+            if (lane == leader) mine[lc] = bs + popc64(same);
+            wave_fence();
+            remaining &= ~same;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Arrival posting.  An entry goes to the ring slot of the tick at which UpdateFunction will see
 // `arrive <= RealExpTime` (:1016) - or, when that is >= H ticks away, to the destination's far inbox.
@@ -423,26 +481,39 @@ __global__ __launch_bounds__(256) void k_tick_work(Static S, State D, int t) {
 //     candidate value = (cost << 7 | position) | dead-mask,   row-wide DPP min -> winner.
 // Preconditions (Static.fast_ok): 0 <= cost < 2^23 and max cost <= reject threshold.  Waves whose
 // rows exceed the register tables, or own far arrivals, push their buckets to the worklist.
-#define ROW_SCR 128   // idle scratch entries per row
-#define ROW_KEYS 64   // arrival keys per row
+#define ROW_MAXM 128  // idle entries per bucket the register tables hold (J = 8)
+#define ROW_KEYS 64   // arrivals per bucket per tick
 
 template <int J>
 __device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const int *lds_blk, int nc,
-                                           const uint2 *scr_row, int r, bool rowvalid, size_t b, int m, int A, int mnew,
-                                           uint2 *idle, int recy_wave) {
+                                           const int4 *lds_rec, const uint2 *arr_row, int r, bool rowvalid, size_t b, int m, int A,
+                                           uint2 *idle, long long cntv) {
     const int lane = lane_id();
     const int l16 = lane & 15;
+    const int rowbase = lane & 48;
+    const int mnew = m + A;
     unsigned veh[J];
     int loc[J], dead[J];
+    // existing entries straight from HBM (16-byte loads, two list entries each), arrivals from the LDS scratch
+#pragma unroll
+    for (int s = 0; s < J; s += 2) {
+        const int pos = l16 * J + s;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (pos < m) e = *reinterpret_cast<const uint4 *>(idle + pos);
+        veh[s] = e.x; loc[s] = (int)e.y; veh[s + 1] = e.z; loc[s + 1] = (int)e.w;
+    }
 #pragma unroll
     for (int s = 0; s < J; ++s) {
         const int pos = l16 * J + s;
-        uint2 e = make_uint2(0u, 0u);
-        if (pos < mnew) e = scr_row[pos];
-        veh[s] = e.x;
-        loc[s] = (int)e.y;
+        if (pos >= m && pos < mnew) {
+            const uint2 e = arr_row[pos - m];
+            veh[s] = e.x; loc[s] = (int)e.y;
+        }
+        if (pos >= mnew) loc[s] = 0;
         dead[s] = pos < mnew ? 0 : IMAX;
     }
+    int recy = 0;
+    if (lane < k) recy = lds_rec[lane].y;
     int navail = mnew, evals = 0;
     int res[4] = {IMAX, IMAX, IMAX, IMAX};
 #pragma unroll
@@ -450,7 +521,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (jj * 16 >= k) break;
         const int kk = min(16, k - jj * 16);
         for (int ji = 0; ji < kk; ++ji) {
-            const int p = rdlane(recy_wave, jj * 16 + ji) & 0xFFFF;
+            const int p = rdlane(recy, jj * 16 + ji) & 0xFFFF;
             const int *row = lds_blk + p * nc;
             int best = IMAX;
 #pragma unroll
@@ -475,13 +546,19 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (jj * 16 >= k) break;
         const int j = jj * 16 + l16;
         const bool has = rowvalid && j < k;
-        int4 rr = make_int4(0, 0, 0, 0);
-        if (has) rr = S.so_rec[q0 + j];
+        const int4 rr = lds_rec[j < k ? j : 0];
         const int rv = res[jj];
         const bool matched = has && rv != IMAX;
         const int wait = rv >> 7;
+        const int wpos = rv & 127;
+        // vehicle id of the winner: pull veh[wpos % J] from row lane wpos / J
+        const int src = (rowbase + (wpos / J)) << 2;
         int vid = -1;
-        if (matched) vid = (int)scr_row[rv & 127].x;
+#pragma unroll
+        for (int s = 0; s < J; ++s) {
+            const int got = __builtin_amdgcn_ds_bpermute(src, (int)veh[s]);
+            vid = (matched && (wpos % J) == s) ? got : vid;
+        }
         if (has) {
             const size_t o = (size_t)r * S.Oq + q0 + j;
             D.out_veh[o] = vid;
@@ -526,72 +603,67 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (l16 == CNT_VALUE) d = vsum;
         if (l16 == CNT_EVALS) d = evals;
         if (l16 == CNT_ARRIVALS) d = A;
-        if (l16 < CNT_WORDS && d != 0) D.cnt[b * CNT_WORDS + l16] += d;
+        if (l16 < CNT_WORDS && d != 0) D.cnt[b * CNT_WORDS + l16] = cntv + d;
     }
 }
 
 __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     extern __shared__ int lds_dyn[];
-    // dynamic LDS: [4 waves][4 rows][ROW_SCR] uint2 | [4 waves][4 rows][ROW_KEYS] u64 | cost block
-    uint2 *scr_all = reinterpret_cast<uint2 *>(lds_dyn);
-    unsigned long long *key_all = reinterpret_cast<unsigned long long *>(scr_all + 16 * ROW_SCR);
-    int *lds_blk = reinterpret_cast<int *>(key_all + 16 * ROW_KEYS);
+    // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
+    // the ranked arrivals) | cost block
+    int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
+    unsigned long long *scr_all = reinterpret_cast<unsigned long long *>(lds_rec + 64);
+    int *lds_blk = reinterpret_cast<int *>(scr_all + 16 * ROW_KEYS);
     const int c = blockIdx.x % S.C;
     const int chunk = blockIdx.x / S.C;
     const int wave = threadIdx.x >> 6;
     const int lane = lane_id();
     const int g = lane >> 4, l16 = lane & 15;
-    const int nc = S.cl_off[c + 1] - S.cl_off[c];
-    const int q0 = S.bkt_off[(size_t)t * S.C + c];
-    const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
     const int p = t & 1;
-    const int now = S.now0 + t * S.tick_minutes;
-    const bool blk_fits = nc * nc <= lds_ints;
-    if (blk_fits && k > 0) {
-        const int *blk_g = S.blk + S.blk_off[c];
-        for (int i = threadIdx.x; i < nc * nc; i += blockDim.x) lds_blk[i] = blk_g[i];
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.work[p ^ 1] = 0;   // next tick's worklist
-
     const int r = (chunk * 4 + wave) * 4 + g;
-    const bool rowvalid = r < S.R;
-    if (__builtin_amdgcn_readfirstlane(r) >= S.R) return;          // whole wave out of range
+    bool rowvalid = r < S.R;
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
-    const int *hdr = D.hdr + b * HDR_WORDS;
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
+    // bucket header words first: their latency hides behind the cost-block staging
     int m = 0, far = 0, A = 0;
+    long long cntv = 0;
     if (rowvalid) {
+        const int *hdr = D.hdr + b * HDR_WORDS;
         m = hdr[HDR_IDLE];
         far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
         A = D.ring_cnt[si] & 0xFFFF;
+        if (l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];
     }
-    const int mnew = m + A;
-    const bool bad = rowvalid && (far != 0 || A > ROW_KEYS || A > S.ring_cap || mnew > ROW_SCR || mnew > S.idle_cap);
-    if (ballot(bad) != 0 || k > 64 || !blk_fits) {
-        // hand the wave's buckets to the generic kernel (nothing has been modified yet)
-        if (rowvalid && l16 == 0) {
-            int slot = atomicAdd(&D.work[p], 1);
-            D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
-        }
-        return;
+    const int nc = S.cl_off[c + 1] - S.cl_off[c];
+    const int q0 = S.bkt_off[(size_t)t * S.C + c];
+    const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
+    const int now = S.now0 + t * S.tick_minutes;
+    const bool blk_fits = nc * nc <= lds_ints;
+    const bool wg_ok = blk_fits && k <= 64;
+    if (wg_ok && k > 0) {
+        const int *blk_g = S.blk + S.blk_off[c];
+        for (int i = threadIdx.x; i < nc * nc; i += blockDim.x) lds_blk[i] = blk_g[i];
+        if ((int)threadIdx.x < k) lds_rec[threadIdx.x] = S.so_rec[q0 + threadIdx.x];
     }
-    uint2 *idle = D.idle + b * S.idle_cap;
-    uint2 *scr_row = scr_all + (wave * 4 + g) * ROW_SCR;
-    unsigned long long *key_row = key_all + (wave * 4 + g) * ROW_KEYS;
-    const bool big = ballot(mnew > 64) != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.work[p ^ 1] = 0;   // next tick's worklist
+    __syncthreads();
 
-    // existing idle entries -> LDS scratch (lane-major order == list order)
-    if (big) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { const int pos = l16 * 8 + s; if (pos < m) scr_row[pos] = idle[pos]; }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { const int pos = l16 * 4 + s; if (pos < m) scr_row[pos] = idle[pos]; }
+    // rows the register tables cannot hold (or that own far arrivals) go to the generic kernel, untouched
+    const int mnew0 = m + A;
+    const bool bad = rowvalid && (!wg_ok || far != 0 || A > ROW_KEYS || A > S.ring_cap || mnew0 > ROW_MAXM || mnew0 > S.idle_cap);
+    if (bad && l16 == 0) {
+        int slot = atomicAdd(&D.work[p], 1);
+        D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
     }
-    // arrivals of this tick (UpdateFunction :1014-1024): rank by dict insertion key, append
-    const unsigned long long anyA = ballot(A > 0);
-    if (anyA) {
+    if (bad) { rowvalid = false; m = 0; A = 0; }
+    if (ballot(rowvalid) == 0) return;
+    uint2 *idle = D.idle + b * S.idle_cap;
+    unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
+    uint2 *arr_row = reinterpret_cast<uint2 *>(key_row);
+    const bool big = ballot(m + A > 64) != 0;
+
+    // arrivals of this tick (UpdateFunction :1014-1024): rank by dict insertion key
+    if (ballot(A > 0) != 0) {
         const int4 *ring = D.ring + si * S.ring_cap;
         int4 e[4];
         unsigned long long key[4];
@@ -612,19 +684,17 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
 #pragma unroll
             for (int a = 0; a < 4; ++a) rank[a] += (ok && kk < key[a]) ? 1 : 0;
         }
+        wave_fence();   // every key has been read: the scratch now takes the ranked arrivals
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int idx = a * 16 + l16;
-            if (idx < A) scr_row[m + rank[a]] = make_uint2((unsigned)e[a].x, (unsigned)meta_dest(e[a].w));
+            if (idx < A) arr_row[rank[a]] = make_uint2((unsigned)e[a].x, (unsigned)meta_dest(e[a].w));
         }
         if (rowvalid && l16 == 0 && A > 0) D.ring_cnt[si] = 0;
+        wave_fence();
     }
-    wave_fence();
-    // the wave-level copy of the bucket's order records (shared by the four replicas)
-    int recy = 0;
-    if (lane < k) recy = S.so_rec[q0 + lane].y;
-    if (big) rows_match<8>(S, D, t, now, q0, k, lds_blk, nc, scr_row, r, rowvalid, b, m, A, mnew, idle, recy);
-    else rows_match<4>(S, D, t, now, q0, k, lds_blk, nc, scr_row, r, rowvalid, b, m, A, mnew, idle, recy);
+    if (big) rows_match<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv);
+    else rows_match<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -835,11 +905,15 @@ __global__ void k_total_counters(int R, const long long *per, long long *tot) {
 // ---------------------------------------------------------------------------------------
 // launchers (called from vds_api.hip)
 void launch_reset(const Static &S, const State &D, const int *veh_node, hipStream_t st) {
-    dim3 grid(S.C * ((S.R + 3) / 4));
-    hipLaunchKernelGGL(k_reset, grid, dim3(256), 0, st, S, D, veh_node);
+    if (S.C <= 8192) {
+        hipLaunchKernelGGL(k_reset_fast, dim3(S.R), dim3(256), (size_t)4 * S.C * sizeof(int), st, S, D, veh_node);
+    } else {
+        dim3 grid(S.C * ((S.R + 3) / 4));
+        hipLaunchKernelGGL(k_reset, grid, dim3(256), 0, st, S, D, veh_node);
+    }
 }
 
-static int rows_lds_bytes(int lds_ints) { return 16 * ROW_SCR * 8 + 16 * ROW_KEYS * 8 + lds_ints * 4; }
+static int rows_lds_bytes(int lds_ints) { return 64 * 16 + 16 * ROW_KEYS * 8 + lds_ints * 4; }
 
 // main kernel of a non-DFS tick (the one bench.py brackets with events)
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
