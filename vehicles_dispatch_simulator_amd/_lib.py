@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvds.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("VDS_LIB", "libvds.so"))   # VDS_LIB=libvds_prof.so: instrumented build
 CSRC = os.path.join(_HERE, "csrc")
 
 NUM_COUNTERS = 8
@@ -56,7 +56,7 @@ SYMBOLS = {
     "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),
     "vds_read_work": (C.c_int, [_VP, _VP]),
 }
-TEST_SYMBOLS = {"vds_selftest_dpp": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32])}
+TEST_SYMBOLS = {"vds_debug_ablate": (C.c_int, [_VP, _I32]), "vds_debug_read_prof": (C.c_int, [_VP, _VP]), "vds_selftest_dpp": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32])}
 
 _lib = None
 

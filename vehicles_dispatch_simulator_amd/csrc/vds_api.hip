@@ -21,6 +21,8 @@ void launch_dispatch(const Static &, const State &, int, int, const int *, const
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
 void launch_selftest_dpp(const int *, int *, int *, int *, int *, int, hipStream_t);
+void set_ablate(int, hipStream_t);
+void read_prof(unsigned long long *, hipStream_t);
 }  // namespace vds
 
 using namespace vds;
@@ -193,8 +195,11 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
     std::vector<long long> blk_off(C + 1, 0);
     for (int c = 0; c < C; ++c) {
         long long nc = h->cl_off[c + 1] - h->cl_off[c];
-        blk_off[c + 1] = blk_off[c] + nc * nc;
+        blk_off[c + 1] = blk_off[c] + (nc * nc + 3) / 4 * 4;   // 16-byte aligned blocks
     }
+    if (blk_off[C] >= (1ll << 31)) return fail(h, VDS_EINVAL, "vds_load_static: cluster cost blocks exceed 2^31 entries");
+    std::vector<int4> cdesc(C);
+    for (int c = 0; c < C; ++c) cdesc[c] = make_int4(h->cl_off[c + 1] - h->cl_off[c], (int)blk_off[c], 0, 0);
     std::vector<int> blk((size_t)blk_off[C]);
     for (int c = 0; c < C; ++c) {
         int nc = h->cl_off[c + 1] - h->cl_off[c];
@@ -237,6 +242,13 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
     if ((rc = upload(h, &d, h->cl_nodes))) return rc; S.cl_nodes = d;
     if ((rc = upload(h, &dl, blk_off))) return rc; S.blk_off = dl;
     if ((rc = upload(h, &d, blk))) return rc; S.blk = d;
+    { int4 *d4c; if ((rc = upload(h, &d4c, cdesc))) return rc; S.cdesc = d4c; }
+    {
+        std::vector<int> corder(C);
+        for (int c = 0; c < C; ++c) corder[c] = c;
+        std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cdesc[a].x > cdesc[b].x; });
+        if ((rc = upload(h, &d, corder))) return rc; S.corder = d;
+    }
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;
     if ((rc = upload(h, &d, dfs_seq))) return rc; S.dfs_seq = d;
     // fast-kernel preconditions: packed (cost << 7 | position) keys, no window rejects
@@ -248,7 +260,7 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
     }
     // LDS budget for the cluster cost block
     const int lds_budget_ints = (64 * 1024) / 4;
-    h->lds_ints = std::min(max_nc * max_nc, lds_budget_ints);
+    h->lds_ints = std::min((max_nc * max_nc + 3) / 4 * 4, lds_budget_ints);
     h->have_static = true;
     return VDS_OK;
 }
@@ -359,8 +371,7 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
     if ((rc = upload(h, &d, bkt_off))) return rc; S.bkt_off = d;
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
-    if ((rc = dev_alloc(h, &h->D.out_veh, (size_t)S.R * std::max(n_proc, 1)))) return rc;
-    if ((rc = dev_alloc(h, &h->D.out_wait, (size_t)S.R * std::max(n_proc, 1)))) return rc;
+    if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(n_proc, 1)))) return rc;
     if ((rc = alloc_state(h, O))) return rc;
     h->have_orders = true;
     return VDS_OK;
@@ -377,8 +388,7 @@ static int reset_device(vds_handle *h) {
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.out_veh, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.out_wait, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->D.out, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int2), h->stream));
     launch_reset(S, h->D, h->d_veh_node, h->stream);
     HIPCHK(h, hipGetLastError());
     h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
@@ -647,11 +657,9 @@ int vds_read_orders(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int3
     int rc = vds_sync(h);
     if (rc) return rc;
     const int Oq = S.Oq, O = h->O;
-    std::vector<int> veh((size_t)nr * std::max(Oq, 1)), wt((size_t)nr * std::max(Oq, 1));
-    if (Oq > 0 && nr > 0) {
-        HIPCHK(h, hipMemcpy(veh.data(), h->D.out_veh + (size_t)r0 * Oq, (size_t)nr * Oq * sizeof(int), hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(wt.data(), h->D.out_wait + (size_t)r0 * Oq, (size_t)nr * Oq * sizeof(int), hipMemcpyDeviceToHost));
-    }
+    std::vector<int2> res((size_t)nr * std::max(Oq, 1));
+    if (Oq > 0 && nr > 0)
+        HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)r0 * Oq, (size_t)nr * Oq * sizeof(int2), hipMemcpyDeviceToHost));
     for (int r = 0; r < nr; ++r) {
         uint8_t *st = status ? status + (size_t)r * O : nullptr;
         int32_t *vv = vehicle ? vehicle + (size_t)r * O : nullptr;
@@ -664,10 +672,10 @@ int vds_read_orders(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int3
         for (int q = 0; q < Oq; ++q) {
             const int i = h->so_id[q];
             if (h->o_tick[i] > h->last_stepped) continue;        // cursor has not reached it yet
-            const int v = veh[(size_t)r * Oq + q];
-            if (st) st[i] = v >= 0 ? 1 : 2;
-            if (vv) vv[i] = v;
-            if (ww) ww[i] = v >= 0 ? wt[(size_t)r * Oq + q] : -1;
+            const int2 e = res[(size_t)r * Oq + q];
+            if (st) st[i] = e.x >= 0 ? 1 : 2;
+            if (vv) vv[i] = e.x;
+            if (ww) ww[i] = e.x >= 0 ? e.y : -1;
         }
     }
     return VDS_OK;
@@ -736,6 +744,24 @@ int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *i
             arr_off[c + 1] = n;
         }
     }
+    return VDS_OK;
+}
+
+// Bench hook (not part of the drop-in surface): timing-only ablation of the fast kernel; any non-zero
+// value makes results INVALID.  bit0 no arrival posts, bit1 no idle write-back, bit2 no match loop,
+// bit3 no result stores, bit4 no header/counter stores.
+int vds_debug_ablate(vds_handle *h, int32_t flags) {
+    if (!h) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    set_ablate(flags, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VDS_OK;
+}
+
+int vds_debug_read_prof(vds_handle *h, uint64_t *out16) {
+    if (!h || !out16) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    read_prof((unsigned long long *)out16, h->stream);
     return VDS_OK;
 }
 

@@ -15,7 +15,7 @@
 //                                (SupplyExpect of the previous tick reads the high half)
 //   fl/inbox                     "far" entries whose arrival lies >= H ticks ahead (rare): owner-private
 //                                list + double-buffered inbox, migrated into the ring when they get near
-//   out_veh/out_wait [R][Oq]     per-order result, indexed by bucket-sorted order position q
+//   out      [R][Oq] {veh, wait} per-order result, indexed by bucket-sorted order position q
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,11 +24,11 @@ namespace vds {
 
 enum {
     HDR_IDLE = 0,       // len(IdleVehicles)
-    HDR_FL = 1,         // far list fill
-    HDR_INBOX0 = 2,     // far inbox fill, parity 0 (atomic target of other buckets)
-    HDR_INBOX1 = 3,     // far inbox fill, parity 1
-    HDR_IDLE_PRE = 6,   // PerMatchIdleVehicles of the last tick
-    HDR_ORDERS = 7,     // len(Cluster.Orders) of the last tick
+    HDR_IDLE_PRE = 1,   // PerMatchIdleVehicles of the last tick
+    HDR_ORDERS = 2,     // len(Cluster.Orders) of the last tick
+    HDR_FL = 3,         // far list fill
+    HDR_INBOX0 = 4,     // far inbox fill, parity 0 (atomic target of other buckets)
+    HDR_INBOX1 = 5,     // far inbox fill, parity 1
     HDR_WORDS = 8
 };
 
@@ -67,8 +67,10 @@ struct Static {
     const int *node_local;           // [N]
     const int *cl_off;               // [C+1]
     const int *cl_nodes;             // [sum n_c]
-    const long long *blk_off;        // [C+1]
-    const int *blk;                  // [sum n_c^2]  blk[c][p][l] = cost[node_p * N + node_l]
+    const long long *blk_off;        // [C+1] (16-byte aligned starts)
+    const int *blk;                  // blk[c][p][l] = cost[node_p * N + node_l], each block padded to 4 ints
+    const int4 *cdesc;               // [C] {n_c, blk_off, 0, 0}: one load per workgroup
+    const int *corder;               // [C] clusters by descending size: heavy workgroups are dispatched first
     const int *dfs_off;              // [C+1]
     const int *dfs_seq;              // visit sequence excluding the start cluster
     const int4 *so_rec;              // [Oq]
@@ -85,8 +87,7 @@ struct State {
     int *ring_cnt;
     int4 *fl;
     int4 *inbox;
-    int *out_veh;
-    int *out_wait;
+    int2 *out;
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
 };

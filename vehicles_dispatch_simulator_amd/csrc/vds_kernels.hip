@@ -20,12 +20,36 @@
 // "lowest position wins": a match is a row-wide DPP min-reduction of (cost << 7 | position).
 // No MFMA: this is index / gather / scan work.
 #include "vds_device.h"
+#include <cstring>
 
 namespace vds {
 
 #define WAVE 64
 #define IMAX 0x7FFFFFFF
 #define WORK_FULL 0x80000000u
+
+// timing-only ablation switches (tests/bench ablation hook; results are INVALID when non-zero)
+__device__ int g_ablate = 0;
+#define PROF_WAVES (1 << 16)
+__device__ unsigned long long g_prof[PROF_WAVES * 8];   // bit7 of g_ablate: per-wave, per-section cycles of k_tick_rows
+#ifdef VDS_PROF
+#define PROF_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * 8 + (i)] += t_ - tprev; tprev = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PROF_STAMP(i) do { } while (0)
+#endif
+void read_prof(unsigned long long *out, hipStream_t st) {
+    (void)hipStreamSynchronize(st);
+    static unsigned long long host[PROF_WAVES * 8];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(host));
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (size_t w = 0; w < PROF_WAVES; ++w) {
+        for (int i = 0; i < 7; ++i) out[i] += host[w * 8 + i];
+        if (host[w * 8 + 6]) out[15]++;
+    }
+    memset(host, 0, sizeof(host));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, sizeof(host));
+}
+void set_ablate(int f, hipStream_t st) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &f, sizeof(int), 0, hipMemcpyHostToDevice, st); }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
@@ -340,8 +364,7 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
         }
         if (lane < kk) {
             const size_t o = (size_t)r * S.Oq + q0 + base + lane;
-            D.out_veh[o] = res_veh;
-            D.out_wait[o] = res_wait;
+            D.out[o] = make_int2(res_veh, res_wait);
             if (res_veh >= 0)   // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery)
                 post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
@@ -484,17 +507,9 @@ __global__ __launch_bounds__(256) void k_tick_work(Static S, State D, int t) {
 #define ROW_MAXM 128  // idle entries per bucket the register tables hold (J = 8)
 #define ROW_KEYS 64   // arrivals per bucket per tick
 
+// existing idle entries straight from HBM: 16-byte loads, two list entries each
 template <int J>
-__device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const int *lds_blk, int nc,
-                                           const int4 *lds_rec, const uint2 *arr_row, int r, bool rowvalid, size_t b, int m, int A,
-                                           uint2 *idle, long long cntv) {
-    const int lane = lane_id();
-    const int l16 = lane & 15;
-    const int rowbase = lane & 48;
-    const int mnew = m + A;
-    unsigned veh[J];
-    int loc[J], dead[J];
-    // existing entries straight from HBM (16-byte loads, two list entries each), arrivals from the LDS scratch
+__device__ __forceinline__ void rows_load_idle(const uint2 *idle, int l16, int m, unsigned (&veh)[J], int (&loc)[J]) {
 #pragma unroll
     for (int s = 0; s < J; s += 2) {
         const int pos = l16 * J + s;
@@ -502,6 +517,22 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (pos < m) e = *reinterpret_cast<const uint4 *>(idle + pos);
         veh[s] = e.x; loc[s] = (int)e.y; veh[s + 1] = e.z; loc[s + 1] = (int)e.w;
     }
+}
+
+template <int J>
+__device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const int *lds_blk, int nc,
+                                           const int4 *lds_rec, const uint2 *arr_row, int r, bool rowvalid, size_t b, int m, int A,
+                                           uint2 *idle, long long cntv, unsigned (&veh)[J], int (&loc)[J], bool prof, unsigned long long tprev, int pwave) {
+    const int lane = lane_id();
+    const int l16 = lane & 15;
+    const int rowbase = lane & 48;
+    const int mnew = m + A;
+#ifdef VDS_PROF
+    const int abl = g_ablate;
+#else
+    const int abl = 0;
+#endif
+    int dead[J];
 #pragma unroll
     for (int s = 0; s < J; ++s) {
         const int pos = l16 * J + s;
@@ -514,11 +545,12 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     }
     int recy = 0;
     if (lane < k) recy = lds_rec[lane].y;
+    PROF_STAMP(3);
     int navail = mnew, evals = 0;
     int res[4] = {IMAX, IMAX, IMAX, IMAX};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        if (jj * 16 >= k) break;
+        if (jj * 16 >= k || (abl & 4)) break;
         const int kk = min(16, k - jj * 16);
         for (int ji = 0; ji < kk; ++ji) {
             const int p = rdlane(recy, jj * 16 + ji) & 0xFFFF;
@@ -539,7 +571,9 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             navail -= hit ? 1 : 0;
         }
     }
-    // results, arrival posts, counters
+    PROF_STAMP(4);
+    // results; the ring-slot atomics of the matched orders are issued here, their dependent entry
+    // stores only after the compaction / header traffic below (hides the atomic round trip)
     int wsum = 0, vsum = 0, rej = 0;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -551,20 +585,25 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         const bool matched = has && rv != IMAX;
         const int wait = rv >> 7;
         const int wpos = rv & 127;
-        // vehicle id of the winner: pull veh[wpos % J] from row lane wpos / J
-        const int src = (rowbase + (wpos / J)) << 2;
+        const int src = (rowbase + (wpos / J)) << 2;   // winner's vehicle id: veh[wpos % J] of row lane wpos / J
         int vid = -1;
 #pragma unroll
         for (int s = 0; s < J; ++s) {
             const int got = __builtin_amdgcn_ds_bpermute(src, (int)veh[s]);
             vid = (matched && (wpos % J) == s) ? got : vid;
         }
-        if (has) {
-            const size_t o = (size_t)r * S.Oq + q0 + j;
-            D.out_veh[o] = vid;
-            D.out_wait[o] = matched ? wait : -1;
+        if (has && !(abl & 8)) D.out[(size_t)r * S.Oq + q0 + j] = make_int2(vid, matched ? wait : -1);
+        if (matched && !(abl & 1)) {
+            if (abl & 96) {   // timing-only: bit5 = atomic without the entry store, bit6 = entry store without the atomic
+                const int rel = wait + rr.w;
+                const int dd = rel <= 0 ? 1 : (rel + S.tick_minutes - 1) / S.tick_minutes;
+                const size_t i = ((size_t)((t + dd) & (S.H - 1)) * S.C + (rr.z & 0xFFFF)) * S.R + r;
+                if (abl & 32) { int o = atomicAdd(&D.ring_cnt[i], 0); if (o == 0x7FFFFFF1) D.err[1] = o; }
+                if (abl & 64) D.ring[i * S.ring_cap + (rr.x & 7)] = make_int4(vid, rr.x, now + rel, 0);
+            } else {
+                post_arrival(S, D, rr.z & 0xFFFF, r, t, now, vid, rr.x, now + wait + rr.w, 0, (int)((unsigned)rr.y >> 16));
+            }
         }
-        if (matched) post_arrival(S, D, rr.z & 0xFFFF, r, t, now, vid, rr.x, now + wait + rr.w, 0, (int)((unsigned)rr.y >> 16));
         wsum += matched ? wait : 0;
         vsum += matched ? rr.w : 0;
         rej += (has && !matched) ? 1 : 0;
@@ -572,6 +611,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     wsum = row_sum_i32(wsum);
     vsum = row_sum_i32(vsum);
     rej = row_sum_i32(rej);
+    PROF_STAMP(5);
     // order-preserving compaction of the survivors (:963); unchanged leading entries are not rewritten
     int alive = 0;
 #pragma unroll
@@ -579,7 +619,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     const int incl = row_incl_scan_i32(alive);
     const int mfin = row_sum_i32(alive);
     int wp = incl - alive;
-    if (rowvalid && (A > 0 || mfin != mnew)) {
+    if (rowvalid && (A > 0 || mfin != mnew) && !(abl & 2)) {
 #pragma unroll
         for (int s = 0; s < J; ++s) {
             const int pos = l16 * J + s;
@@ -589,13 +629,8 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             }
         }
     }
-    if (rowvalid) {
-        int *hdr = D.hdr + b * HDR_WORDS;
-        if (l16 == 0) {
-            hdr[HDR_IDLE] = mfin;
-            hdr[HDR_IDLE_PRE] = mnew;
-            hdr[HDR_ORDERS] = k;
-        }
+    if (rowvalid && !(abl & 16)) {
+        if (l16 < 3) D.hdr[b * HDR_WORDS + l16] = l16 == HDR_IDLE ? mfin : (l16 == HDR_IDLE_PRE ? mnew : k);
         long long d = 0;
         if (l16 == CNT_ORDERS) d = k;
         if (l16 == CNT_REJECTS) d = rej;
@@ -605,64 +640,22 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (l16 == CNT_ARRIVALS) d = A;
         if (l16 < CNT_WORDS && d != 0) D.cnt[b * CNT_WORDS + l16] = cntv + d;
     }
+    PROF_STAMP(6);
 }
 
-__global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int lds_ints) {
-    extern __shared__ int lds_dyn[];
-    // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
-    // the ranked arrivals) | cost block
-    int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
-    unsigned long long *scr_all = reinterpret_cast<unsigned long long *>(lds_rec + 64);
-    int *lds_blk = reinterpret_cast<int *>(scr_all + 16 * ROW_KEYS);
-    const int c = blockIdx.x % S.C;
-    const int chunk = blockIdx.x / S.C;
-    const int wave = threadIdx.x >> 6;
-    const int lane = lane_id();
-    const int g = lane >> 4, l16 = lane & 15;
-    const int p = t & 1;
-    const int r = (chunk * 4 + wave) * 4 + g;
-    bool rowvalid = r < S.R;
-    const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
-    const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
-    // bucket header words first: their latency hides behind the cost-block staging
-    int m = 0, far = 0, A = 0;
-    long long cntv = 0;
-    if (rowvalid) {
-        const int *hdr = D.hdr + b * HDR_WORDS;
-        m = hdr[HDR_IDLE];
-        far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
-        A = D.ring_cnt[si] & 0xFFFF;
-        if (l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];
-    }
-    const int nc = S.cl_off[c + 1] - S.cl_off[c];
-    const int q0 = S.bkt_off[(size_t)t * S.C + c];
-    const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
-    const int now = S.now0 + t * S.tick_minutes;
-    const bool blk_fits = nc * nc <= lds_ints;
-    const bool wg_ok = blk_fits && k <= 64;
-    if (wg_ok && k > 0) {
-        const int *blk_g = S.blk + S.blk_off[c];
-        for (int i = threadIdx.x; i < nc * nc; i += blockDim.x) lds_blk[i] = blk_g[i];
-        if ((int)threadIdx.x < k) lds_rec[threadIdx.x] = S.so_rec[q0 + threadIdx.x];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.work[p ^ 1] = 0;   // next tick's worklist
-    __syncthreads();
-
-    // rows the register tables cannot hold (or that own far arrivals) go to the generic kernel, untouched
-    const int mnew0 = m + A;
-    const bool bad = rowvalid && (!wg_ok || far != 0 || A > ROW_KEYS || A > S.ring_cap || mnew0 > ROW_MAXM || mnew0 > S.idle_cap);
-    if (bad && l16 == 0) {
-        int slot = atomicAdd(&D.work[p], 1);
-        D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
-    }
-    if (bad) { rowvalid = false; m = 0; A = 0; }
-    if (ballot(rowvalid) == 0) return;
+template <int J>
+__device__ __forceinline__ void rows_body(const Static &S, const State &D, int t, int now, int q0, int k, const int *lds_blk, int nc,
+                                          const int4 *lds_rec, unsigned long long *key_row, int r, bool rowvalid, size_t b, size_t si,
+                                          int m, int A, long long cntv, bool prof, unsigned long long tprev, int pwave) {
+    const int l16 = lane_id() & 15;
+    // 3. the idle list and this tick's arrivals: both loads in flight together
     uint2 *idle = D.idle + b * S.idle_cap;
-    unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
+    unsigned veh[J];
+    int loc[J];
+    rows_load_idle<J>(idle, l16, m, veh, loc);
     uint2 *arr_row = reinterpret_cast<uint2 *>(key_row);
-    const bool big = ballot(m + A > 64) != 0;
-
-    // arrivals of this tick (UpdateFunction :1014-1024): rank by dict insertion key
+    PROF_STAMP(1);
+    // 4. arrivals of this tick (UpdateFunction :1014-1024): rank by dict insertion key
     if (ballot(A > 0) != 0) {
         const int4 *ring = D.ring + si * S.ring_cap;
         int4 e[4];
@@ -678,11 +671,20 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
         wave_fence();
         const int Amax = max(max(rdlane(A, 0), rdlane(A, 16)), max(rdlane(A, 32), rdlane(A, 48)));
         int rank[4] = {0, 0, 0, 0};
-        for (int i = 0; i < Amax; ++i) {
-            const unsigned long long kk = key_row[i < A ? i : 0];
-            const bool ok = i < A;
+        if (Amax <= 16) {           // common case: one arrival per lane
+#pragma unroll 4
+            for (int i = 0; i < Amax; ++i) {
+                const unsigned long long kk = key_row[i];
+                rank[0] += (i < A && kk < key[0]) ? 1 : 0;
+            }
+        } else {
+#pragma unroll 2
+            for (int i = 0; i < Amax; ++i) {
+                const unsigned long long kk = key_row[i];
+                const bool ok = i < A;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) rank[a] += (ok && kk < key[a]) ? 1 : 0;
+                for (int a = 0; a < 4; ++a) rank[a] += (ok && kk < key[a]) ? 1 : 0;
+            }
         }
         wave_fence();   // every key has been read: the scratch now takes the ranked arrivals
 #pragma unroll
@@ -693,8 +695,91 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
         if (rowvalid && l16 == 0 && A > 0) D.ring_cnt[si] = 0;
         wave_fence();
     }
-    if (big) rows_match<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv);
-    else rows_match<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv);
+    PROF_STAMP(2);
+    rows_match<J>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
+}
+
+__global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+    extern __shared__ int lds_dyn[];
+    // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
+    // the ranked arrivals) | cost block
+    int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
+    unsigned long long *scr_all = reinterpret_cast<unsigned long long *>(lds_rec + 64);
+    int *lds_blk = reinterpret_cast<int *>(scr_all + 16 * ROW_KEYS);
+    // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
+    const int nchunks = gridDim.x / S.C;
+    const int c = S.corder[blockIdx.x / nchunks];
+    const int chunk = blockIdx.x % nchunks;
+    const int wave = threadIdx.x >> 6;
+    const int lane = lane_id();
+    const int g = lane >> 4, l16 = lane & 15;
+    const int p = t & 1;
+#ifdef VDS_PROF
+    const bool prof = (g_ablate & 128) != 0;
+    unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#else
+    const bool prof = false;
+    unsigned long long tprev = 0ull;
+#endif
+    const int pwave = (int)((blockIdx.x * 4 + wave) & (PROF_WAVES - 1));
+    const int r = (chunk * 4 + wave) * 4 + g;
+    bool rowvalid = r < S.R;
+    const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
+    const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
+    // 1. bucket header words
+    int m = 0, far = 0, A = 0;
+    long long cntv = 0;
+    if (rowvalid) {
+        const int *hdr = D.hdr + b * HDR_WORDS;
+        m = hdr[HDR_IDLE];
+        far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
+        A = D.ring_cnt[si] & 0xFFFF;
+        if (l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];
+    }
+    const int4 cd = S.cdesc[c];
+    const int nc = cd.x;
+    const int q0 = S.bkt_off[(size_t)t * S.C + c];
+    const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
+    const int now = S.now0 + t * S.tick_minutes;
+    const bool wg_ok = nc * nc <= lds_ints && k <= 64;
+    // rows the register tables cannot hold (or that own far arrivals) go to the generic kernel, untouched
+    const int mnew0 = m + A;
+    const bool bad = rowvalid && (!wg_ok || far != 0 || A > ROW_KEYS || A > S.ring_cap || mnew0 > ROW_MAXM || mnew0 > S.idle_cap);
+    if (bad && l16 == 0) {
+        int slot = atomicAdd(&D.work[p], 1);
+        D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
+    }
+    if (bad) { rowvalid = false; m = 0; A = 0; }
+    const bool any = ballot(rowvalid) != 0;
+    const bool big = ballot(m + A > 64) != 0;
+    // 2. stage the cluster's cost block and the bucket's order records in LDS
+    if (wg_ok && k > 0) {
+        // 16-byte loads, three in flight per thread before the first LDS store (blocks are padded to 4 ints)
+        const int4 *blk4 = reinterpret_cast<const int4 *>(S.blk + cd.y);
+        int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
+        const int n4 = (nc * nc + 3) >> 2;
+        int4 rec = make_int4(0, 0, 0, 0);
+        if ((int)threadIdx.x < k) rec = S.so_rec[q0 + threadIdx.x];
+        for (int i0 = 0; i0 < n4; i0 += 3 * 256) {
+            const int i = i0 + threadIdx.x;
+            int4 v0 = make_int4(0, 0, 0, 0), v1 = v0, v2 = v0;
+            if (i < n4) v0 = blk4[i];
+            if (i + 256 < n4) v1 = blk4[i + 256];
+            if (i + 512 < n4) v2 = blk4[i + 512];
+            if (i < n4) lds4[i] = v0;
+            if (i + 256 < n4) lds4[i + 256] = v1;
+            if (i + 512 < n4) lds4[i + 512] = v2;
+        }
+        if ((int)threadIdx.x < k) lds_rec[threadIdx.x] = rec;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.work[p ^ 1] = 0;   // next tick's worklist
+    __syncthreads();
+    if (!any) return;
+    // 3.-5. idle list + arrivals + match, specialised on the table depth
+    unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
+    PROF_STAMP(0);
+    if (big) rows_body<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+    else rows_body<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -789,8 +874,7 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
             }
         }
         if (lane == 0) {
-            D.out_veh[(size_t)r * S.Oq + q] = res_veh;
-            D.out_wait[(size_t)r * S.Oq + q] = res_wait;
+            D.out[(size_t)r * S.Oq + q] = make_int2(res_veh, res_wait);
             cnt[CNT_ORDERS] += 1;
             hdr[HDR_ORDERS] += 1;
             if (!matched) cnt[CNT_REJECTS] += 1;
