@@ -1,0 +1,54 @@
+"""World-construction loader against what the unmodified reference built
+from the same files (captured in the golden fixtures): node -> cluster, neighbour lists, DFS depth,
+cost matrix, order stream.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_golden
+from oracle.ref_harness import write_reference_data_dir
+from vehicles_dispatch_simulator_amd import synth, world
+
+
+def rebuild_inputs(g):
+    kw = dict(seed=int(g["city_seed"]), N=int(g["N"]), mode=str(g["city_mode"]))
+    if str(g["city_mode"]) == "grid":
+        kw["side_m"] = float(g["city_side_m"])
+    else:
+        kw["C"] = int(g["C"])
+    city = synth.make_city(**kw)
+    if len(g["empty"]):
+        lab = city.node2cluster.copy()
+        for e in g["empty"]:
+            lab[lab == e] = (e + 1) % city.C
+        city.node2cluster = lab
+    start, pick, dele = synth.make_orders(int(g["order_seed"]), city.N, g["o_pickup"].size)
+    return city, start, pick, dele
+
+
+@pytest.mark.parametrize("name", ["tiny_grid", "tiny_kmeans_dfs2", "tiny_empty_clusters_dfs2", "tiny_grid_nbr_scarce"])
+def test_loader_matches_reference_tables(name, tmp_path):
+    g = load_golden(name)
+    city, start, pick, dele = rebuild_inputs(g)
+    os.environ["TZ"] = "UTC"
+    import time
+    time.tzset()
+    write_reference_data_dir(str(tmp_path), city, start, pick, dele, n_drivers=int(g["V"]), cluster_mode=str(g["cluster_mode"]))
+    W = world.load_world(os.path.join(str(tmp_path), "data"), cluster_mode=str(g["cluster_mode"]), local_region_bound=synth.DEFAULT_BOUND,
+                         side_length_meter=float(g["side_m"]), vehicles_service_meter=float(g["service_m"]))
+    np.testing.assert_array_equal(W.cost, g["cost"])
+    np.testing.assert_array_equal(W.node2cluster, g["node2cluster"])
+    assert W.n_clusters == int(g["C"]) and W.depth_limit == int(g["depth_limit"])
+    nbr = [g["nbr_idx"][g["nbr_off"][c]:g["nbr_off"][c + 1]].tolist() for c in range(int(g["C"]))]
+    assert [list(x) for x in W.neighbors] == nbr
+    # the order stream: same minutes; within a minute the reference's unstable sort may permute
+    np.testing.assert_array_equal(W.o_release_min, g["o_release_min"])
+    key = lambda r, p, d: sorted(zip(r.tolist(), p.tolist(), d.tolist()))
+    assert key(W.o_release_min, W.o_pickup, W.o_delivery) == key(g["o_release_min"], g["o_pickup"], g["o_delivery"])
+
+
+def test_grid_boundary_node_raises():
+    with pytest.raises(Exception, match="error"):
+        b = synth.DEFAULT_BOUND
+        world._grid_assignment(np.array([b[0] + 1 * ((b[1] - b[0]) / 4)]), np.array([30.65]), b, 4, 3)

@@ -1,0 +1,44 @@
+"""Replica sharding across the GPUs of one node.
+
+Replicas are fully independent cities (no shared mutable state), so the hot path shards with NO
+data-path collective: rank g of G owns the contiguous replica range returned by ``shard`` and a
+private copy of the static tables.  The single collective is a ``sum`` all-reduce of the int64[8]
+aggregate counters (RCCL over xGMI on GPUs - backend "nccl" - or gloo on CPU in the tests);
+64 bytes per call, latency-bound, once per episode.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+RAW_COUNTER_NAMES = ("orders", "rejects", "wait_sum", "matched_value", "evals", "arrivals", "dispatches", "dispatch_cost")
+
+
+def shard(total_replicas: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """(first_replica, count) of ``rank``; the first ``total % world`` ranks take one extra."""
+    if not (0 <= rank < world_size):
+        raise Exception("rank %d outside world of %d" % (rank, world_size))
+    base, extra = divmod(total_replicas, world_size)
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def allreduce_counters(tensor, group=None):
+    """In-place sum of an int64[8] counter tensor over all ranks (no-op without a process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """The slowest rank's time: what the job's throughput is quoted on."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
