@@ -16,6 +16,7 @@ void launch_tick_main(const Static &, const State &, int, int, hipStream_t);
 void launch_tick_work(const Static &, const State &, int, hipStream_t);
 void launch_update_only(const Static &, const State &, int, hipStream_t);
 void launch_match_dfs(const Static &, const State &, int, hipStream_t);
+void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, hipStream_t);
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
@@ -461,8 +462,17 @@ int vds_step(vds_handle *h) {
         launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
         launch_tick_work(h->S, h->D, h->t, h->stream);
+    } else if (h->S.C <= 3072 && !h->cfg.force_generic) {   // 5 ints of LDS per cluster
+        hipEvent_t a = nullptr, b = nullptr;
+        if (h->profiling) {
+            a = next_event(h); b = next_event(h);
+            if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
+            HIPCHK(h, hipEventRecord(a, h->stream));
+        }
+        launch_tick_replica(h->S, h->D, h->t, h->stream);      // neighbour search: lower-bound rounds, one workgroup per replica
+        if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
     } else {
-        launch_update_only(h->S, h->D, h->t, h->stream);
+        launch_update_only(h->S, h->D, h->t, h->stream);       // serial reference form
         launch_match_dfs(h->S, h->D, h->t, h->stream);
     }
     HIPCHK(h, hipGetLastError());

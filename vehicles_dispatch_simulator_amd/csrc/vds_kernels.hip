@@ -886,6 +886,267 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
 }
 
 // ---------------------------------------------------------------------------------------
+// k_tick_replica: neighbour-search mode, exact and parallel.  One 512-thread workgroup owns ONE replica for
+// the tick.  Update runs bucket-parallel (one wavefront per cluster, strided).  Matching proceeds in
+// "lower-bound rounds": a bucket with m idle vehicles cannot run dry before its (m+1)-th pending order, and
+// no vehicle can be taken from another cluster before the first order that finds its own cluster dry, so
+//     LB = min over DFS-capable clusters of id(the (m_c+1)-th pending order of c)
+// is the first order that can trigger FindServerVehicleFunction (:936-940); every pending order with
+// id < LB is an ordinary own-cluster match, independent across clusters -> matched bucket-parallel.  Order
+// LB itself then searches the precomputed visit sequence with all wavefronts scanning candidate clusters
+// in parallel (winner = lexicographic min of (cost, visit position, list position) == the reference's first
+// strict minimum in visit order), the victim list shrinks, and the next round begins.
+#define REPL_THREADS 512
+#define REPL_WAVES (REPL_THREADS / WAVE)
+
+// own-cluster match of orders [qs, qs+n) for tables of any size (slow path: > 256 idle entries)
+__device__ void match_bucket_slow(const Static &S, const State &D, int r, int t, int now, int &m, int qs, int n,
+                                  const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
+                                  long long &evals, int &rejects) {
+    const int lane = lane_id();
+    for (int j = 0; j < n; ++j) {
+        const int4 rec = S.so_rec[qs + j];
+        evals += m;
+        int res_veh = -1, res_wait = -1;
+        if (m > 0) {
+            const int *row = blk + (size_t)(rec.y & 0xFFFF) * nc;
+            int lc = IMAX, lp = -1;
+            for (int base = 0; base < m; base += WAVE) {
+                const int i = base + lane;
+                if (i < m) {
+                    const int cst = row[idle[i].y];
+                    if (lp < 0 || cst < lc) { lc = cst; lp = i; }
+                }
+            }
+            const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
+            const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
+            if ((long long)minc <= S.reject_threshold) {
+                res_veh = (int)idle[minp].x;
+                res_wait = minc;
+                wave_fence();
+                // order-preserving removal
+                for (int base = minp; base < m - 1; base += WAVE) {
+                    const int i = base + lane;
+                    uint2 e = make_uint2(0u, 0u);
+                    if (i < m - 1) e = idle[i + 1];
+                    wave_fence();
+                    if (i < m - 1) idle[i] = e;
+                    wave_fence();
+                }
+                m--;
+                wait_sum += minc;
+                value_sum += rec.w;
+            }
+        }
+        if (res_veh < 0) rejects++;
+        if (lane == 0) {
+            D.out[(size_t)r * S.Oq + qs + j] = make_int2(res_veh, res_wait);
+            if (res_veh >= 0) post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
+        }
+        wave_fence();
+    }
+}
+
+// id of the order at sorted position q, or IMAX past the bucket's end
+__device__ __forceinline__ int order_id_or_inf(const Static &S, int q, int qend) { return q < qend ? S.so_rec[q].x : IMAX; }
+
+__global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D, int t) {
+    extern __shared__ int lds_dyn[];
+    const int C = S.C;
+    int *m_l = lds_dyn;               // [C] idle count
+    int *qcur_l = lds_dyn + C;        // [C] sorted position of the bucket's next pending order
+    int *qend_l = lds_dyn + 2 * C;    // [C] end of the bucket
+    int *next_l = lds_dyn + 3 * C;    // [C] id of the next pending order (IMAX: none)
+    int *dry_l = lds_dyn + 4 * C;     // [C] id of the first order that can find the cluster dry (IMAX: none / not DFS-capable)
+    __shared__ int s_lb, s_lbc;
+    __shared__ int s_cand[REPL_WAVES][4];
+    const int r = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int p = t & 1;
+    const int now = S.now0 + t * S.tick_minutes;
+    // ---- UpdateFunction, bucket-parallel
+    for (int c = wave; c < C; c += REPL_WAVES) {
+        const size_t b = (size_t)c * S.R + r;
+        int *hdr = D.hdr + b * HDR_WORDS;
+        int hv = lane < HDR_WORDS ? hdr[lane] : 0;
+        int m = rdlane(hv, HDR_IDLE);
+        const int f = rdlane(hv, HDR_FL), qin = rdlane(hv, HDR_INBOX0 + p);
+        int newf = f;
+        if (f + qin > 0) {
+            update_far(S, D, c, r, t, now, f, qin, D.fl + b * S.fl_cap, D.inbox + ((size_t)p * S.C * S.R + b) * S.in_cap, newf);
+            wave_fence();
+        }
+        const int A = drain_ring(S, D, b, t, m, D.idle + b * S.idle_cap);
+        const int q0 = S.bkt_off[(size_t)t * C + c], q1 = S.bkt_off[(size_t)t * C + c + 1];
+        if (lane == 0) {
+            hdr[HDR_IDLE] = m; hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
+            m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
+            next_l[c] = order_id_or_inf(S, q0, q1);
+            dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? order_id_or_inf(S, q0 + m, q1) : IMAX;
+        }
+        if (A > 0) add_counters(D.cnt + b * CNT_WORDS, 0, 0, 0, 0, 0, A);
+    }
+    __syncthreads();
+    // ---- MatchFunction in lower-bound rounds
+    for (;;) {
+        if (threadIdx.x == 0) { s_lb = IMAX; s_lbc = -1; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += REPL_THREADS)
+            if (dry_l[c] != IMAX) atomicMin(&s_lb, dry_l[c]);
+        __syncthreads();
+        const int LB = s_lb;
+        // all pending orders older than LB: ordinary own-cluster matches, bucket-parallel
+        for (int c = wave; c < C; c += REPL_WAVES) {
+            const int nx = next_l[c];
+            if (nx == LB && LB != IMAX && lane == 0) s_lbc = c;
+            if (nx >= LB) continue;
+            const int qc = qcur_l[c], qe = qend_l[c];
+            int n = 0;
+            for (int base = qc; base < qe; base += WAVE) {
+                const int j = base + lane;
+                const unsigned long long bm = ballot(j < qe && S.so_rec[j].x < LB);
+                n += popc64(bm);
+                if (bm != ~0ull) break;
+            }
+            const size_t b = (size_t)c * S.R + r;
+            uint2 *idle = D.idle + b * S.idle_cap;
+            const int nc = S.cl_off[c + 1] - S.cl_off[c];
+            const int *blk = S.blk + S.blk_off[c];
+            int m = m_l[c];
+            long long wait_sum = 0, value_sum = 0, evals = 0;
+            int rejects = 0;
+            if (m <= 64) match_bucket<1, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+            else if (m <= 128) match_bucket<2, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+            else if (m <= 256) match_bucket<4, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+            else match_bucket_slow(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+            add_counters(D.cnt + b * CNT_WORDS, n, rejects, wait_sum, value_sum, evals, 0);
+            if (lane == 0) {
+                D.hdr[b * HDR_WORDS + HDR_IDLE] = m;
+                m_l[c] = m; qcur_l[c] = qc + n;
+                const int nn = order_id_or_inf(S, qc + n, qe);
+                next_l[c] = nn;
+                dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? order_id_or_inf(S, qc + n + m, qe) : IMAX;
+                if (nn == LB && LB != IMAX) s_lbc = c;
+            }
+        }
+        __syncthreads();
+        if (LB == IMAX) break;
+        // ---- order LB: its own cluster is dry -> FindServerVehicleFunction over the visit sequence
+        const int pc = s_lbc;
+        const int q = qcur_l[pc];
+        if (m_l[pc] > 0) {
+            // not dry after all (an older order of this bucket was rejected by the pickup window, :943,
+            // without taking a vehicle): order LB is an ordinary own-cluster match
+            if (wave == 0) {
+                const size_t b = (size_t)pc * S.R + r;
+                int m = m_l[pc];
+                long long wait_sum = 0, value_sum = 0, evals = 0;
+                int rejects = 0;
+                match_bucket_slow(S, D, r, t, now, m, q, 1, S.blk + S.blk_off[pc], S.cl_off[pc + 1] - S.cl_off[pc], D.idle + b * S.idle_cap,
+                                  wait_sum, value_sum, evals, rejects);
+                add_counters(D.cnt + b * CNT_WORDS, 1, rejects, wait_sum, value_sum, evals, 0);
+                if (lane == 0) {
+                    D.hdr[b * HDR_WORDS + HDR_IDLE] = m; m_l[pc] = m; qcur_l[pc] = q + 1;
+                    next_l[pc] = order_id_or_inf(S, q + 1, qend_l[pc]);
+                    dry_l[pc] = order_id_or_inf(S, q + 1 + m, qend_l[pc]);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        const int4 rec = S.so_rec[q];
+        const int pnode = S.cl_nodes[S.cl_off[pc] + (rec.y & 0xFFFF)];
+        const int *crow = S.cost + (size_t)pnode * S.N;
+        int bc = IMAX, bsi = IMAX, bpos = -1, bcl = -1;
+        long long ev = 0;
+        // candidate clusters of this wavefront, two at a time so that their dependent load chains
+        // (idle entry -> node -> cost) overlap
+        const int s0 = S.dfs_off[pc], s1 = S.dfs_off[pc + 1];
+        for (int si = s0 + wave; si < s1; si += 2 * REPL_WAVES) {
+            const int siB = si + REPL_WAVES;
+            const int cA = S.dfs_seq[si];
+            const int cB = siB < s1 ? S.dfs_seq[siB] : cA;
+            const int mA = m_l[cA];
+            const int mB = siB < s1 ? m_l[cB] : 0;
+            if (mA == 0 && mB == 0) continue;
+            ev += mA + mB;
+            const uint2 *idA = D.idle + ((size_t)cA * S.R + r) * S.idle_cap, *idB = D.idle + ((size_t)cB * S.R + r) * S.idle_cap;
+            const int *ndA = S.cl_nodes + S.cl_off[cA], *ndB = S.cl_nodes + S.cl_off[cB];
+            int lcA = IMAX, lpA = -1, lcB = IMAX, lpB = -1;
+            const int mm = max(mA, mB);
+            for (int base = 0; base < mm; base += WAVE) {
+                const int i = base + lane;
+                unsigned la = 0, lb = 0;
+                if (i < mA) la = idA[i].y;
+                if (i < mB) lb = idB[i].y;
+                int na = 0, nb = 0;
+                if (i < mA) na = ndA[la];
+                if (i < mB) nb = ndB[lb];
+                int ca = IMAX, cb = IMAX;
+                if (i < mA) ca = crow[na];
+                if (i < mB) cb = crow[nb];
+                if (i < mA && (lpA < 0 || ca < lcA)) { lcA = ca; lpA = i; }
+                if (i < mB && (lpB < 0 || cb < lcB)) { lcB = cb; lpB = i; }
+            }
+            if (mA > 0) {
+                const int minc = wave_min_i32(lpA >= 0 ? lcA : IMAX);
+                if (bcl < 0 || minc < bc) {      // this wave's clusters come in increasing visit position
+                    const int minp = wave_min_i32((lpA >= 0 && lcA == minc) ? lpA : IMAX);
+                    bc = minc; bsi = si; bpos = minp; bcl = cA;
+                }
+            }
+            if (mB > 0) {
+                const int minc = wave_min_i32(lpB >= 0 ? lcB : IMAX);
+                if (bcl < 0 || minc < bc) {
+                    const int minp = wave_min_i32((lpB >= 0 && lcB == minc) ? lpB : IMAX);
+                    bc = minc; bsi = siB; bpos = minp; bcl = cB;
+                }
+            }
+        }
+        if (lane == 0) { s_cand[wave][0] = bc; s_cand[wave][1] = bsi; s_cand[wave][2] = bpos; s_cand[wave][3] = bcl; }
+        // evaluations of all scanned clusters count (:986-991 runs for every visited cluster)
+        if (lane == 0 && ev) atomicAdd((unsigned long long *)&D.cnt[((size_t)pc * S.R + r) * CNT_WORDS + CNT_EVALS], (unsigned long long)ev);
+        __syncthreads();
+        if (wave == 0) {
+            int wc = IMAX, wsi = IMAX, wpos = -1, wcl = -1;
+            for (int w = 0; w < REPL_WAVES; ++w) {
+                const int c0 = s_cand[w][0], sx = s_cand[w][1];
+                if (s_cand[w][3] >= 0 && (wcl < 0 || c0 < wc || (c0 == wc && sx < wsi))) { wc = c0; wsi = sx; wpos = s_cand[w][2]; wcl = s_cand[w][3]; }
+            }
+            const size_t bp = (size_t)pc * S.R + r;
+            long long *cnt = D.cnt + bp * CNT_WORDS;
+            int res_veh = -1, res_wait = -1;
+            const bool matched = wcl >= 0 && (long long)wc <= S.reject_threshold;
+            if (matched) {
+                const size_t bw = (size_t)wcl * S.R + r;
+                uint2 *widle = D.idle + bw * S.idle_cap;
+                const int mw = m_l[wcl];
+                res_veh = (int)widle[wpos].x;
+                res_wait = wc;
+                wave_fence();
+                list_remove(widle, mw, wpos);
+                if (lane == 0) {
+                    D.hdr[bw * HDR_WORDS + HDR_IDLE] = mw - 1;
+                    m_l[wcl] = mw - 1;
+                    if (S.dfs_off[wcl + 1] > S.dfs_off[wcl]) dry_l[wcl] = order_id_or_inf(S, qcur_l[wcl] + mw - 1, qend_l[wcl]);
+                    post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
+                }
+            }
+            if (lane == 0) {
+                D.out[(size_t)r * S.Oq + q] = make_int2(res_veh, res_wait);
+                cnt[CNT_ORDERS] += 1;
+                if (!matched) cnt[CNT_REJECTS] += 1;
+                else { cnt[CNT_WAIT] += res_wait; cnt[CNT_VALUE] += rec.w; }
+                qcur_l[pc] = q + 1;
+                next_l[pc] = order_id_or_inf(S, q + 1, qend_l[pc]);
+                dry_l[pc] = order_id_or_inf(S, q + 1, qend_l[pc]);     // m == 0: the very next order is dry again
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_dispatch: one wavefront per (replica, from_cluster) group of actions (host-sorted).
 // grp_off[g]..grp_off[g+1] index the group's actions; positions refer to the idle list as it
 // stands at call time.
@@ -1013,6 +1274,10 @@ void launch_tick_work(const Static &S, const State &D, int t, hipStream_t st) {
 void launch_update_only(const Static &S, const State &D, int t, hipStream_t st) {
     const int chunks = (S.R + 15) / 16;
     hipLaunchKernelGGL(k_tick<false>, dim3(S.C * chunks), dim3(256), 0, st, S, D, t, 0);
+}
+
+void launch_tick_replica(const Static &S, const State &D, int t, hipStream_t st) {
+    hipLaunchKernelGGL(k_tick_replica, dim3(S.R), dim3(REPL_THREADS), (size_t)5 * S.C * sizeof(int), st, S, D, t);
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
