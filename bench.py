@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
 
-def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 64):
+def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 2048):
     """The oracle (kind "port": C restatement of the reference's Python loop) on this host, one
     thread, whole days of single replicas of the same workload until ~budget_s of CPU work."""
     from oracle.oracle import Oracle
@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--replicas", type=int, default=1024, help="replicas PER GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify replica 0 against the oracle after the run")
     a = ap.parse_args()
@@ -85,9 +85,12 @@ def main():
     if a.workload == "cfg2":
         w = workloads.didi_day("cfg2")
         wname = "configs[1]: %d replicas/GPU x 192 k-means clusters, 4139 nodes, 10k vehicles, 200k synthetic orders/day, no neighbour search" % R
-    else:
+    elif a.workload == "cfg4":
         w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
         wname = "configs[3]: %d replicas/GPU x 192 clusters with neighbour DFS depth 2, 10k vehicles, 200k orders/day" % R
+    else:
+        w = workloads.stress()
+        wname = "configs[4] (stress): %d replicas/GPU x 2048 clusters, 16384 nodes, 100k vehicles, 2M synthetic orders/day" % R
     init = w.vehicle_nodes(R, first_replica=rank * R)
 
     stream = torch.cuda.current_stream()
@@ -147,7 +150,7 @@ def main():
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_tick" if not w.neighbor_can_server else "k_match_dfs",
+            roofline = {"bound": "hbm", "kernel": "k_tick_rows" if not w.neighbor_can_server else "k_tick_replica",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes,
                         "avg_launch_ms": float(ms.mean()), "launches": int(ms.size),
@@ -175,7 +178,7 @@ def main():
     if rank == 0:
         env_steps = T * R * world * a.steps
         out = {
-            "metric": "env-steps x replicas / sec (192-cluster, 10k vehicles)",
+            "metric": "env-steps x replicas / sec (192-cluster, 10k vehicles)" if a.workload != "cfg5" else "env-steps x replicas / sec (2048-cluster, 100k vehicles stress)",
             "value": env_steps / elapsed, "unit": "env-steps*replicas/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",

@@ -60,6 +60,13 @@ def didi_day(name: str = "cfg2", *, N: int = 4139, C: int = 192, vehicles: int =
                     nbr_off=off, nbr_idx=idx, veh_seed=veh_seed)
 
 
+def stress(name: str = "cfg5", *, N: int = 16384, C: int = 2048, vehicles: int = 100000, orders: int = 2000000,
+           city_seed: int = 2048, order_seed: int = 55, veh_seed: int = 99) -> Workload:
+    """BASELINE.json configs[4] per replica: 2048 clusters, 100k vehicles, 2M synthetic orders/day.  N = 16384
+    nodes (8 per cluster on average; the N x N int32 cost matrix is 1.07 GB), no neighbour search."""
+    return didi_day(name, N=N, C=C, vehicles=vehicles, orders=orders, city_seed=city_seed, order_seed=order_seed, veh_seed=veh_seed)
+
+
 def tiny(name: str = "tiny", *, N: int = 300, C: int = 12, vehicles: int = 150, orders: int = 2500,
          neighbor: bool = False, depth_limit: int = 2, seed: int = 7) -> Workload:
     city = synth.make_city(seed, N=N, C=C, with_neighbors=True)
