@@ -964,6 +964,11 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int p = t & 1;
     const int now = S.now0 + t * S.tick_minutes;
+#ifdef VDS_PROF
+    const bool prof = (g_ablate & 128) != 0;
+    unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int pwave = (int)((blockIdx.x * REPL_WAVES + wave) & (PROF_WAVES - 1));
+#endif
     // ---- UpdateFunction, bucket-parallel
     for (int c = wave; c < C; c += REPL_WAVES) {
         const size_t b = (size_t)c * S.R + r;
@@ -995,6 +1000,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
             if (dry_l[c] != IMAX) atomicMin(&s_lb, dry_l[c]);
         __syncthreads();
         const int LB = s_lb;
+        PROF_STAMP(2);
         // all pending orders older than LB: ordinary own-cluster matches, bucket-parallel
         for (int c = wave; c < C; c += REPL_WAVES) {
             const int nx = next_l[c];
@@ -1030,6 +1036,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
             }
         }
         __syncthreads();
+        PROF_STAMP(3);
         if (LB == IMAX) break;
         // ---- order LB: its own cluster is dry -> FindServerVehicleFunction over the visit sequence
         const int pc = s_lbc;
@@ -1104,6 +1111,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
             }
         }
         if (lane == 0) { s_cand[wave][0] = bc; s_cand[wave][1] = bsi; s_cand[wave][2] = bpos; s_cand[wave][3] = bcl; }
+        PROF_STAMP(4);
         // evaluations of all scanned clusters count (:986-991 runs for every visited cluster)
         if (lane == 0 && ev) atomicAdd((unsigned long long *)&D.cnt[((size_t)pc * S.R + r) * CNT_WORDS + CNT_EVALS], (unsigned long long)ev);
         __syncthreads();
@@ -1143,6 +1151,10 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
             }
         }
         __syncthreads();
+        PROF_STAMP(5);
+#ifdef VDS_PROF
+        if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+#endif
     }
 }
 
