@@ -461,7 +461,8 @@ int vds_step(vds_handle *h) {
         }
         launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
-        launch_tick_work(h->S, h->D, h->t, h->stream);
+        // the fast kernel only defers buckets whose cluster cost block does not fit LDS
+        if (!h->S.fast_ok || h->S.max_nc * h->S.max_nc > h->lds_ints) launch_tick_work(h->S, h->D, h->t, h->stream);
     } else if (h->S.C <= 3072 && !h->cfg.force_generic) {   // 5 ints of LDS per cluster
         hipEvent_t a = nullptr, b = nullptr;
         if (h->profiling) {

@@ -395,9 +395,13 @@ __device__ __forceinline__ void add_counters(long long *cnt, long long k, long l
     if (lane < CNT_WORDS && d != 0) cnt[lane] += d;
 }
 
+__device__ void match_bucket_slow(const Static &S, const State &D, int r, int t, int now, int &m, int qs, int n,
+                                  const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
+                                  long long &evals, int &rejects);
+
 // Whole generic tick of one bucket by one wavefront.  MAXJ = 4: tables up to 256 idle entries are
 // matched here, bigger ones are pushed to the worklist (match only).  MAXJ = 16: everything here.
-template <bool DO_MATCH, bool LDSBLK, int MAXJ>
+template <bool DO_MATCH, bool LDSBLK, int MAXJ, bool ONLY_J4 = false>
 __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t, int q0, int k, const int *blk, int nc) {
     const int lane = lane_id();
     const int p = t & 1;
@@ -421,14 +425,16 @@ __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t
     int rejects = 0;
     bool deferred = false;
     if (DO_MATCH && k > 0) {
-        if (MAXJ < 16 && m > 256) {
+        if (MAXJ < 16 && m > 256 && ONLY_J4) {
+            match_bucket_slow(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);   // any size, in place
+        } else if (MAXJ < 16 && m > 256) {
             deferred = true;
             if (lane == 0) {
                 int slot = atomicAdd(&D.work[p], 1);
                 D.work[2 + (size_t)p * S.C * S.R + slot] = (int)b;
             }
-        } else if (m <= 64) match_bucket<1, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-        else if (m <= 128) match_bucket<2, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        } else if (!ONLY_J4 && m <= 64) match_bucket<1, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        else if (!ONLY_J4 && m <= 128) match_bucket<2, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
         else if (MAXJ < 16 || m <= 256) match_bucket<4, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
         else match_bucket<MAXJ, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
     }
@@ -742,24 +748,28 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
     const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
     const int now = S.now0 + t * S.tick_minutes;
     const bool wg_ok = nc * nc <= lds_ints && k <= 64;
-    // rows the register tables cannot hold (or that own far arrivals) go to the generic kernel, untouched
+    // rows the register tables cannot hold (or that own far arrivals): handled after the fast rows by this
+    // same wavefront with the generic per-bucket code (cost block already in LDS); only when the block does
+    // not fit LDS do they go to the worklist of k_tick_work.  Nothing of theirs is touched by the fast path.
     const int mnew0 = m + A;
     const bool bad = rowvalid && (!wg_ok || far != 0 || A > ROW_KEYS || A > S.ring_cap || mnew0 > ROW_MAXM || mnew0 > S.idle_cap);
-    if (bad && l16 == 0) {
+    const bool blk_in_lds = nc * nc <= lds_ints;
+    if (bad && !blk_in_lds && l16 == 0) {
         int slot = atomicAdd(&D.work[p], 1);
         D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
     }
+    const unsigned long long badrows = blk_in_lds ? ballot(bad && l16 == 0) : 0ull;
     if (bad) { rowvalid = false; m = 0; A = 0; }
     const bool any = ballot(rowvalid) != 0;
     const bool big = ballot(m + A > 64) != 0;
     // 2. stage the cluster's cost block and the bucket's order records in LDS
-    if (wg_ok && k > 0) {
+    if (blk_in_lds && k > 0) {
         // 16-byte loads, three in flight per thread before the first LDS store (blocks are padded to 4 ints)
         const int4 *blk4 = reinterpret_cast<const int4 *>(S.blk + cd.y);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
         const int n4 = (nc * nc + 3) >> 2;
         int4 rec = make_int4(0, 0, 0, 0);
-        if ((int)threadIdx.x < k) rec = S.so_rec[q0 + threadIdx.x];
+        if ((int)threadIdx.x < min(k, 64)) rec = S.so_rec[q0 + threadIdx.x];
         for (int i0 = 0; i0 < n4; i0 += 3 * 256) {
             const int i = i0 + threadIdx.x;
             int4 v0 = make_int4(0, 0, 0, 0), v1 = v0, v2 = v0;
@@ -770,16 +780,22 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
             if (i + 256 < n4) lds4[i + 256] = v1;
             if (i + 512 < n4) lds4[i + 512] = v2;
         }
-        if ((int)threadIdx.x < k) lds_rec[threadIdx.x] = rec;
+        if ((int)threadIdx.x < min(k, 64)) lds_rec[threadIdx.x] = rec;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) D.work[p ^ 1] = 0;   // next tick's worklist
     __syncthreads();
-    if (!any) return;
-    // 3.-5. idle list + arrivals + match, specialised on the table depth
-    unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
-    PROF_STAMP(0);
-    if (big) rows_body<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-    else rows_body<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+    if (any) {
+        // 3.-5. idle list + arrivals + match, specialised on the table depth
+        unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
+        PROF_STAMP(0);
+        if (big) rows_body<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else rows_body<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+    }
+    // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
+    for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
+        const int gg = (__ffsll((long long)rest) - 1) >> 4;
+        bucket_tick<true, true, 4, true>(S, D, c, (chunk * 4 + wave) * 4 + gg, t, q0, k, lds_blk, nc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
