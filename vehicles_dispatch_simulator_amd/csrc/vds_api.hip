@@ -389,7 +389,8 @@ static int reset_device(vds_handle *h) {
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->D.out, 0xFF, (size_t)S.R * std::max(S.Oq, 1) * sizeof(int2), h->stream));
+    // D.out needs no clearing: every processed order's slot is written (match or reject) before
+    // vds_read_orders may look at it (it only reads orders whose tick has been stepped)
     launch_reset(S, h->D, h->d_veh_node, h->stream);
     HIPCHK(h, hipGetLastError());
     h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;

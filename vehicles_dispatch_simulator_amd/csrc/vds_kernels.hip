@@ -145,20 +145,21 @@ __global__ __launch_bounds__(256) void k_reset(Static S, State D, const int *veh
 }
 
 // k_reset_fast: one workgroup per replica - a stable counting sort of the vehicles by cluster through
-// LDS: each wavefront owns a contiguous quarter of the vehicle range (so vehicle order is kept),
+// LDS: each wavefront owns a contiguous 1/16 of the vehicle range (so vehicle order is kept),
 // pass A counts per (wave, cluster), a prefix over the waves gives every wave its base position in
 // each idle list, pass B places the vehicles chunk by chunk (lanes of one cluster are ranked with a
-// ballot).  Needs 4*C ints of LDS; bigger cities use k_reset.
-__global__ __launch_bounds__(256) void k_reset_fast(Static S, State D, const int *veh_node) {
+// ballot).  Needs 16*C ints of LDS; bigger cities use k_reset.
+#define RESET_WAVES 16
+__global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, State D, const int *veh_node) {
     extern __shared__ int lds_dyn[];
     const int r = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int C = S.C;
-    const int seg = (((S.V + 3) / 4) + WAVE - 1) / WAVE * WAVE;
+    const int seg = (((S.V + RESET_WAVES - 1) / RESET_WAVES) + WAVE - 1) / WAVE * WAVE;
     const int v0 = min(S.V, wave * seg), v1 = min(S.V, v0 + seg);
     const int *vn = veh_node + (size_t)r * S.V;
     int *mine = lds_dyn + wave * C;
-    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) lds_dyn[i] = 0;
+    for (int i = threadIdx.x; i < RESET_WAVES * C; i += blockDim.x) lds_dyn[i] = 0;
     __syncthreads();
     for (int base = v0; base < v1; base += WAVE) {
         const int v = base + lane;
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(256) void k_reset_fast(Static S, State D, const int
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int t0 = lds_dyn[c], t1 = lds_dyn[C + c], t2 = lds_dyn[2 * C + c], t3 = lds_dyn[3 * C + c];
-        lds_dyn[c] = 0; lds_dyn[C + c] = t0; lds_dyn[2 * C + c] = t0 + t1; lds_dyn[3 * C + c] = t0 + t1 + t2;
-        int total = t0 + t1 + t2 + t3;
+        int run = 0;
+        for (int w = 0; w < RESET_WAVES; ++w) { const int tw = lds_dyn[w * C + c]; lds_dyn[w * C + c] = run; run += tw; }
+        int total = run;
         if (total > S.idle_cap) { atomicOr(&D.err[0], ERR_IDLE_CAP); total = S.idle_cap; }
         const size_t b = (size_t)c * S.R + r;
         int4 *h4 = reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS);
@@ -1278,8 +1279,8 @@ __global__ void k_total_counters(int R, const long long *per, long long *tot) {
 // ---------------------------------------------------------------------------------------
 // launchers (called from vds_api.hip)
 void launch_reset(const Static &S, const State &D, const int *veh_node, hipStream_t st) {
-    if (S.C <= 8192) {
-        hipLaunchKernelGGL(k_reset_fast, dim3(S.R), dim3(256), (size_t)4 * S.C * sizeof(int), st, S, D, veh_node);
+    if (S.C <= 2048) {
+        hipLaunchKernelGGL(k_reset_fast, dim3(S.R), dim3(RESET_WAVES * WAVE), (size_t)RESET_WAVES * S.C * sizeof(int), st, S, D, veh_node);
     } else {
         dim3 grid(S.C * ((S.R + 3) / 4));
         hipLaunchKernelGGL(k_reset, grid, dim3(256), 0, st, S, D, veh_node);
