@@ -913,7 +913,7 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
 // LB itself then searches the precomputed visit sequence with all wavefronts scanning candidate clusters
 // in parallel (winner = lexicographic min of (cost, visit position, list position) == the reference's first
 // strict minimum in visit order), the victim list shrinks, and the next round begins.
-#define REPL_THREADS 512
+#define REPL_THREADS 256
 #define REPL_WAVES (REPL_THREADS / WAVE)
 
 // own-cluster match of orders [qs, qs+n) for tables of any size (slow path: > 256 idle entries)
