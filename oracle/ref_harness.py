@@ -97,7 +97,7 @@ class _LoggingList(list):
 def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, cluster_mode: str,
                   side_m: float = 800.0, service_m: float = 800.0, neighbor_can_server: bool = False,
                   dispatch_policy: Optional[Callable] = None, capture_lists: bool = False,
-                  keep_dir: Optional[str] = None, quiet: bool = True) -> Dict[str, np.ndarray]:
+                  keep_dir: Optional[str] = None, quiet: bool = True, focus_bound=None) -> Dict[str, np.ndarray]:
     """Run the reference end to end on the given synthetic day; return inputs + outputs.
 
     ``dispatch_policy(sim, tick) -> list[(vehicle_obj, target_node)]`` (optional) is invoked
@@ -120,9 +120,9 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
         random.seed(seed)
         S = refsim.Simulation(
             ClusterMode=cluster_mode, DemandPredictionMode="None", DispatchMode="Simulation",
-            VehiclesNumber=V, TimePeriods=setting.TIMESTEP, LocalRegionBound=tuple(city.bound),
+            VehiclesNumber=V, TimePeriods=setting.TIMESTEP, LocalRegionBound=tuple(focus_bound or city.bound),
             SideLengthMeter=side_m, VehiclesServiceMeter=service_m,
-            NeighborCanServer=neighbor_can_server, FocusOnLocalRegion=False)
+            NeighborCanServer=neighbor_can_server, FocusOnLocalRegion=focus_bound is not None)
         t0 = time.time()
         S.CreateAllInstantiate("1101")
         t_init = time.time() - t0

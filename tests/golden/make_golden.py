@@ -74,6 +74,8 @@ TINY = {
                           run=dict(V=140, seed=18, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
     "tiny_dispatch_dfs2": dict(city=dict(seed=109, N=300, C=12), O=3000, oseed=9, dispatch=True,
                                run=dict(V=70, seed=19, cluster_mode="KmeansClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
+    "tiny_focus_grid": dict(city=dict(seed=111, N=420, C=12), O=3000, oseed=11, focus=(104.035, 104.105, 30.625, 30.695),
+                            run=dict(V=80, seed=21, cluster_mode="Grid", side_m=2000, service_m=5000, neighbor_can_server=True)),
     "tiny_two_orders": dict(city=dict(seed=110, N=120, C=12), O=2, oseed=10,
                             run=dict(V=30, seed=20, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
 }
@@ -104,19 +106,28 @@ def generate(name, spec, real=False):
     start, pick, dele = synth.make_orders(spec["oseed"], city.N, spec["O"])
     run = dict(spec["run"])
     pol = policy_factory(city.N) if spec.get("dispatch") else None
-    out = rh.run_reference(city, start, pick, dele, dispatch_policy=pol, capture_lists=not real, **run)
+    focus = spec.get("focus")
+    out = rh.run_reference(city, start, pick, dele, dispatch_policy=pol, capture_lists=not real, focus_bound=focus, **run)
     # the generator's tables must be exactly what the reference loaded / derived
     assert out["cost_is_integral"]
-    assert (out["cost"] == city.cost).all() and (out["node2cluster"] == city.node2cluster).all()
-    nbr = [out["nbr_idx"][out["nbr_off"][c]:out["nbr_off"][c + 1]].tolist() for c in range(city.C)]
-    assert nbr == [list(x) for x in city.neighbors], "neighbour lists differ from the reference's"
+    assert (out["cost"] == city.cost).all()
     import random
-    assert (synth.init_vehicle_nodes(random.Random(run["seed"]), city.N, run["V"]) == out["veh_node"]).all()
-    assert (out["veh_cluster"] == city.node2cluster[out["veh_node"]]).all()
+    if focus is None:
+        assert (out["node2cluster"] == city.node2cluster).all()
+        nbr = [out["nbr_idx"][out["nbr_off"][c]:out["nbr_off"][c + 1]].tolist() for c in range(city.C)]
+        assert nbr == [list(x) for x in city.neighbors], "neighbour lists differ from the reference's"
+        assert (synth.init_vehicle_nodes(random.Random(run["seed"]), city.N, run["V"]) == out["veh_node"]).all()
+        assert (out["veh_cluster"] == city.node2cluster[out["veh_node"]]).all()
+    else:
+        valid = out["node2cluster"] >= 0
+        assert 0 < valid.sum() < city.N
+        assert (synth.init_vehicle_nodes(random.Random(run["seed"]), city.N, run["V"], valid) == out["veh_node"]).all()
+        assert (out["veh_cluster"] == out["node2cluster"][out["veh_node"]]).all()
     meta = dict(city_seed=np.int64(spec["city"]["seed"]), city_mode=np.str_(spec["city"].get("mode", "cluster")),
                 city_side_m=np.float64(spec["city"].get("side_m", 800.0)),
                 empty=np.array(spec.get("empty", []), dtype=np.int32),
-                order_seed=np.int64(spec["oseed"]), cluster_mode=np.str_(run["cluster_mode"]),
+                order_seed=np.int64(spec["oseed"]), n_orders_raw=np.int64(spec["O"]),
+                focus_bound=np.array(spec.get("focus", ()), dtype=np.float64), cluster_mode=np.str_(run["cluster_mode"]),
                 side_m=np.float64(run["side_m"]), service_m=np.float64(run["service_m"]))
     out.update(meta)
     out["sha_status"], out["sha_vehicle"], out["sha_wait"] = np.str_(sha(out["o_status"])), np.str_(sha(out["o_vehicle"])), np.str_(sha(out["o_wait"].astype(np.int32)))

@@ -123,7 +123,49 @@ def test_fast_forward_equals_hooked_loop_and_batches_replicas():
     sim2 = make_sim(g, Simulation)
     sim2.SimCity(FastForward=False)
     assert (sim2.OrderNum, sim2.RejectNum, sim2.TotallyWaitTime) == (sim.OrderNum, sim.RejectNum, sim.TotallyWaitTime)
-    with pytest.raises(Exception):
-        Simulation(ClusterMode="Grid", DemandPredictionMode="None", DispatchMode="Simulation", VehiclesNumber=10, TimePeriods=TIMESTEP,
-                   LocalRegionBound=(104.035, 104.105, 30.625, 30.695), SideLengthMeter=800, VehiclesServiceMeter=800,
-                   NeighborCanServer=False, FocusOnLocalRegion=True, Quiet=True)
+
+
+def test_drop_in_from_data_directory_with_focus_region_and_reload(tmp_path):
+    """The whole drop-in path: the reference's ./data layout on disk -> Simulation(...).CreateAllInstantiate()
+    -> SimCity(), with FocusOnLocalRegion=True, must equal the day the unmodified reference produced from the same
+    files (golden tiny_focus_grid); Reload() then runs another day from ./data/test/."""
+    import os, shutil, time
+    from oracle.ref_harness import write_reference_data_dir
+    from test_world_loader import rebuild_inputs
+    from vehicles_dispatch_simulator_amd import synth
+    os.environ["TZ"] = "UTC"; time.tzset()
+    g = load_golden("tiny_focus_grid")
+    city, start, pick, dele = rebuild_inputs(g)
+    write_reference_data_dir(str(tmp_path), city, start, pick, dele, n_drivers=int(g["V"]), cluster_mode="Grid")
+    data = os.path.join(str(tmp_path), "data")
+    bound = tuple(g["focus_bound"].tolist())
+    sim = Simulation(ClusterMode="Grid", DemandPredictionMode="None", DispatchMode="Simulation", VehiclesNumber=int(g["V"]),
+                     TimePeriods=TIMESTEP, LocalRegionBound=bound, SideLengthMeter=float(g["side_m"]),
+                     VehiclesServiceMeter=float(g["service_m"]), NeighborCanServer=True, FocusOnLocalRegion=True, DataDir=data, Quiet=True)
+    random.seed(int(g["seed"]))
+    sim.CreateAllInstantiate("1101")
+    np.testing.assert_array_equal(sim._init_nodes[0], g["veh_node"])
+    assert len(sim.Orders) == g["o_pickup"].size and len(sim.Clusters) == int(g["C"])
+    sim.SimCity()
+    # same-minute ties may be ordered differently from the reference's unstable sort: compare what is invariant
+    assert sim.step == int(g["n_ticks"]) and sim.OrderNum == int(g["order_num"])
+    same_order = np.array_equal(sim._world.o_pickup, g["o_pickup"]) and np.array_equal(sim._world.o_delivery, g["o_delivery"])
+    if same_order:
+        assert (sim.RejectNum, sim.TotallyWaitTime, sim.SumOrderValue) == (int(g["reject_num"]), int(g["wait_sum"]), int(g["sum_order_value"]))
+    # Reload: another day from data/test
+    os.makedirs(os.path.join(data, "test"))
+    start2, pick2, dele2 = synth.make_orders(77, city.N, 1500)
+    write_reference_data_dir(os.path.join(str(tmp_path), "day2"), city, start2, pick2, dele2, n_drivers=int(g["V"]), cluster_mode="Grid", date="1102")
+    shutil.copy(os.path.join(str(tmp_path), "day2", "data", "order_20161102.csv"), os.path.join(data, "test", "order_20161102.csv"))
+    sim.Reload("1102")
+    assert sim.OrderNum == 0 and 0 < len(sim.Orders) < 1500
+    sim.SimCity()
+    assert sim.OrderNum == len(sim.Orders) - 1
+    from oracle.oracle import Oracle
+    W = sim._world
+    from vehicles_dispatch_simulator_amd.env import neighbors_to_csr
+    off, idx = neighbors_to_csr(W.neighbors)
+    o = Oracle(W.cost, W.node2cluster, off, idx, W.depth_limit, True, W.o_release_min, W.o_pickup, W.o_delivery, len(sim.Vehicles))
+    o.reset(sim._init_nodes[0]); o.run_day()
+    oc = o.counters()
+    assert (sim.RejectNum, sim.TotallyWaitTime, sim.SumOrderValue) == (oc["reject_num"], oc["wait_sum"], oc["sum_order_value"])

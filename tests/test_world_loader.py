@@ -23,20 +23,23 @@ def rebuild_inputs(g):
         for e in g["empty"]:
             lab[lab == e] = (e + 1) % city.C
         city.node2cluster = lab
-    start, pick, dele = synth.make_orders(int(g["order_seed"]), city.N, g["o_pickup"].size)
+    n_raw = int(g["n_orders_raw"]) if "n_orders_raw" in g else g["o_pickup"].size
+    start, pick, dele = synth.make_orders(int(g["order_seed"]), city.N, n_raw)
     return city, start, pick, dele
 
 
-@pytest.mark.parametrize("name", ["tiny_grid", "tiny_kmeans_dfs2", "tiny_empty_clusters_dfs2", "tiny_grid_nbr_scarce"])
+@pytest.mark.parametrize("name", ["tiny_grid", "tiny_kmeans_dfs2", "tiny_empty_clusters_dfs2", "tiny_grid_nbr_scarce", "tiny_focus_grid"])
 def test_loader_matches_reference_tables(name, tmp_path):
     g = load_golden(name)
     city, start, pick, dele = rebuild_inputs(g)
+    focus = len(g["focus_bound"]) == 4 if "focus_bound" in g else False
+    bound = tuple(g["focus_bound"].tolist()) if focus else synth.DEFAULT_BOUND
     os.environ["TZ"] = "UTC"
     import time
     time.tzset()
     write_reference_data_dir(str(tmp_path), city, start, pick, dele, n_drivers=int(g["V"]), cluster_mode=str(g["cluster_mode"]))
-    W = world.load_world(os.path.join(str(tmp_path), "data"), cluster_mode=str(g["cluster_mode"]), local_region_bound=synth.DEFAULT_BOUND,
-                         side_length_meter=float(g["side_m"]), vehicles_service_meter=float(g["service_m"]))
+    W = world.load_world(os.path.join(str(tmp_path), "data"), cluster_mode=str(g["cluster_mode"]), local_region_bound=bound,
+                         side_length_meter=float(g["side_m"]), vehicles_service_meter=float(g["service_m"]), focus_on_local_region=focus)
     np.testing.assert_array_equal(W.cost, g["cost"])
     np.testing.assert_array_equal(W.node2cluster, g["node2cluster"])
     assert W.n_clusters == int(g["C"]) and W.depth_limit == int(g["depth_limit"])

@@ -13,7 +13,6 @@ reference exposes (``Clusters`` / ``Vehicles`` / ``Orders``) is served as lazy v
 Differences a maintainer should know (also in INTEGRATION.md):
   * idle vehicles are moved with ``DispatchVehicle(vehicle, target_node)`` inside
     ``DispatchFunction`` instead of editing ``Cluster.IdleVehicles`` in place;
-  * ``FocusOnLocalRegion=True`` is not supported yet (raises);
   * extra optional keywords: ``Replicas``, ``Replica``, ``Device``, ``VehicleSeed``, ``DataDir``.
 """
 from __future__ import annotations
@@ -48,8 +47,6 @@ class Simulation(object):
     def __init__(self, ClusterMode, DemandPredictionMode, DispatchMode, VehiclesNumber, TimePeriods, LocalRegionBound,
                  SideLengthMeter, VehiclesServiceMeter, NeighborCanServer, FocusOnLocalRegion,
                  Replicas=1, Replica=0, Device=0, VehicleSeed=None, DataDir=None, Quiet=False, **device_kwargs):
-        if FocusOnLocalRegion:
-            raise Exception("FocusOnLocalRegion=True is not supported by the device engine yet")
         # components (simulator.py:44-45)
         self.DispatchModule = None
         self.DemandPredictorModule = None
@@ -124,7 +121,8 @@ class Simulation(object):
         W = World if World is not None else world.load_world(
             self.DataDir or os.path.join(os.getcwd(), "data"), cluster_mode=self.ClusterMode,
             local_region_bound=self.LocalRegionBound, side_length_meter=self.SideLengthMeter,
-            vehicles_service_meter=self.VehiclesServiceMeter, order_file_date=OrderFileDate)
+            vehicles_service_meter=self.VehiclesServiceMeter, order_file_date=OrderFileDate,
+            focus_on_local_region=self.FocusOnLocalRegion)
         self._world = W
         N = W.node_id.size
         self.Node = pd.DataFrame({"NodeID": np.arange(N), "Longitude": W.lon, "Latitude": W.lat})
@@ -141,6 +139,11 @@ class Simulation(object):
             if W.node2cluster[n] >= 0:
                 self.NodeID2Cluseter[n] = self.Clusters[int(W.node2cluster[n])]
                 self.NodeID2NodesLocation[n] = (float(W.lon[n]), float(W.lat[n]))
+        self._build_orders_and_env()
+        self.InitVehiclesIntoCluster()
+
+    def _build_orders_and_env(self):
+        W = self._world
         self._say("Create Orders set")
         self._t0 = pd.Timestamp(W.o_release[0])
         rel = W.o_release_min.astype(np.int64)
@@ -154,13 +157,38 @@ class Simulation(object):
         self._o_tick = tk
         self._say("Create Vehicles set")
         V = min(int(self.VehiclesNumber), W.driver_ids.size)
-        self.Vehicles = [Vehicle(self, i, W.driver_ids[i]) for i in range(V)]
+        if self.Vehicles is None:
+            self.Vehicles = [Vehicle(self, i, W.driver_ids[i]) for i in range(V)]
         off, idx = neighbors_to_csr(W.neighbors)
+        if self.env is not None:
+            self.env.close()
         self.env = BatchedDispatchEnv(W.cost, W.node2cluster, off, idx, replicas=self.Replicas, vehicles=V,
                                       depth_limit=self.NeighborServerDeepLimit, neighbor_can_server=self.NeighborCanServer,
                                       tick_minutes=self._tick_minutes, reject_threshold=PICKUP_REJECT_THRESHOLD,
                                       device=self.Device, **self._device_kwargs)
         self.env.load_orders(rel, W.o_pickup, W.o_delivery)
+
+    def Reload(self, OrderFileDate="1101"):
+        """``simulator.py:130-212``: read another day (``./data/test/order_2016<date>.csv``), reset the
+        statistics, clusters and vehicles (new random start nodes, continuing the RNG stream)."""
+        self._say("Load order " + OrderFileDate + "and reset the experimental environment")
+        data_dir = self.DataDir or os.path.join(os.getcwd(), "data")
+        W = self._world
+        index = {int(v): i for i, v in enumerate(W.node_id)}
+        minute, pick, dele = world.read_orders(os.path.join(data_dir, "test", "order_2016" + str(OrderFileDate) + ".csv"), index)
+        if self.FocusOnLocalRegion:
+            minute, pick, dele = world.filter_orders_to_region(minute, pick, dele, W.node2cluster)
+        W.o_release, W.o_pickup, W.o_delivery = minute, pick, dele
+        W.o_release_min = ((minute - minute[0]) / np.timedelta64(1, "m")).astype(np.int32)
+        self.OrderNum = self.RejectNum = self.DispatchNum = 0
+        self.TotallyDispatchCost = self.TotallyWaitTime = 0
+        for k in ("Update", "NextState", "Learning", "Dispatch", "Match", "DemandPredict"):
+            setattr(self, "Totally" + k + "Time", dt.timedelta())
+        self.TransitionTempPool.clear()
+        self.RealExpTime = None
+        self.NowOrder = None
+        self.step = None
+        self._build_orders_and_env()
         self.InitVehiclesIntoCluster()
 
     def InitVehiclesIntoCluster(self):

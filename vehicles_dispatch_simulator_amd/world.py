@@ -49,6 +49,13 @@ def read_node_id_list(path: str) -> np.ndarray:
         return np.array([int(line.split()[0]) for line in f if line.strip()], dtype=np.int64)
 
 
+def filter_orders_to_region(minute, pick, dele, node2cluster):
+    """``FocusOnLocalRegion``: orders with an endpoint outside the region are dropped and the rest is
+    renumbered (``simulator.py:329-336``, ``IsOrderInLimitRegion`` :356-362)."""
+    keep = (node2cluster[pick] >= 0) & (node2cluster[dele] >= 0)
+    return minute[keep], pick[keep], dele[keep]
+
+
 def read_orders(path: str, node_index: dict) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """``ReadOrder`` (readfiles.py:70-81): keep ID/Start_time/NodeS/NodeE, truncate the unix
     start time to the minute in the process-local time zone, sort by time, renumber.  The
@@ -99,8 +106,12 @@ def _parse_neighbor_csv(path: str, C: int, threshold: float = 15.0, first: int =
 
 def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_length_meter: float,
                vehicles_service_meter: float, order_file_date: str = "1101",
-               cache_neighbors: bool = True) -> World:
-    """Read ``data_dir`` (the reference's ``./data``) and derive every static table."""
+               focus_on_local_region: bool = False, order_path: Optional[str] = None) -> World:
+    """Read ``data_dir`` (the reference's ``./data``) and derive every static table.
+
+    ``focus_on_local_region``: nodes outside ``local_region_bound`` belong to no cluster
+    (``IsNodeInLimitRegion``, ``simulator.py:364-370``: inclusive bounds) and orders touching them are
+    dropped.  ``order_path`` overrides the order file (``Reload`` reads ``./data/test/...``, :159)."""
     import pandas as pd
 
     node = pd.read_csv(os.path.join(data_dir, "Node.csv"))
@@ -120,6 +131,9 @@ def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_len
     C = gw * gh
     depth = int((vehicles_service_meter - (0.5 * side_length_meter)) // side_length_meter)   # simulator.py:290
     node2cluster = np.full(N, -1, dtype=np.int32)
+    if focus_on_local_region:
+        inside = ~((lonlat[:, 0] < bound[0]) | (lonlat[:, 0] > bound[1]) | (lonlat[:, 1] < bound[2]) | (lonlat[:, 1] > bound[3]))
+        row_internal, lonlat = row_internal[inside], lonlat[inside]
     if cluster_mode == "Grid":
         node2cluster[row_internal] = _grid_assignment(lonlat[:, 0], lonlat[:, 1], bound, gw, gh)
         neighbors = synth.grid_neighbors(gw, gh)
@@ -136,7 +150,9 @@ def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_len
             neighbors = synth.cluster_neighbors_from_cost(cost, node2cluster, C)
     cluster_nodes = [np.flatnonzero(node2cluster == c).tolist() for c in range(C)]
 
-    minute, pick, dele = read_orders(os.path.join(data_dir, "order_2016" + str(order_file_date) + ".csv"), index)
+    minute, pick, dele = read_orders(order_path or os.path.join(data_dir, "order_2016" + str(order_file_date) + ".csv"), index)
+    if focus_on_local_region:
+        minute, pick, dele = filter_orders_to_region(minute, pick, dele, node2cluster)
     rel = ((minute - minute[0]) / np.timedelta64(1, "m")).astype(np.int32)
     drivers = pd.read_csv(os.path.join(data_dir, "Drivers1101.csv"))
     return World(node_id=node_id, lon=lon, lat=lat, cost=cost, node2cluster=node2cluster, neighbors=neighbors,
