@@ -54,8 +54,8 @@ def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 2048):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--replicas", type=int, default=1024, help="replicas PER GPU")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

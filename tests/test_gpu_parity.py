@@ -214,3 +214,19 @@ def test_all_vehicles_in_one_cluster_oversize_bucket(mode):
         np.testing.assert_array_equal(od[k][1], oo[k])
     assert node >= 0
     env.close()
+
+
+def test_zero_copy_torch_observations_match_host_read():
+    import torch
+    g = load_golden("tiny_kmeans")
+    env = make_env(g, 4, stream=torch.cuda.current_stream().cuda_stream)
+    env.reset(np.tile(g["veh_node"], (4, 1)))
+    for _ in range(30):
+        env.step(); env.advance()
+    host = env.obs()
+    dev = env.obs_torch()
+    torch.cuda.synchronize()
+    assert dev.shape == (5, 4, int(g["C"])) and dev.dtype == torch.int32 and dev.is_cuda
+    for i, k in enumerate(("idle_pre", "idle_now", "supply", "cl_orders", "inflight")):
+        np.testing.assert_array_equal(dev[i].cpu().numpy(), host[k])
+    env.close()

@@ -143,6 +143,20 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_obs_device(self._h, C.byref(p)))
         return p.value
 
+    def obs_torch(self):
+        """The packed observation block as a zero-copy ``torch`` int32 tensor ``[5, R, C]`` on the GPU
+        (``idle_pre, idle_now, supply, cl_orders, inflight``): what a batched RL agent consumes without a
+        host round trip.  The tensor aliases library memory and is overwritten by the next call."""
+        import torch
+
+        class _Block:
+            pass
+
+        blk = _Block()
+        blk.__cuda_array_interface__ = {"shape": (5, self.R, self.C), "typestr": "<i4", "data": (self.obs_device_ptr(), False),
+                                        "version": 2, "strides": None}
+        return torch.as_tensor(blk, device="cuda")
+
     def counters(self) -> np.ndarray:
         out = np.zeros((self.R, _lib.NUM_COUNTERS), dtype=np.int64)
         self._chk(self._lib.vds_read_counters(self._h, _p(out)))
