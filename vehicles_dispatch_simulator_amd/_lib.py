@@ -75,8 +75,11 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libvds.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                               "or `make -C vehicles_dispatch_simulator_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+            try:                      # same image on the GPU box: hipcc is there, build in-tree on first use
+                build(force=True)
+            except Exception as e:
+                raise RuntimeError("libvds.so is not built (%s) and building it failed (%s): run "
+                                   "`make -C vehicles_dispatch_simulator_amd/csrc`; there is no CPU fallback" % (LIB_PATH, e))
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in {**SYMBOLS, **TEST_SYMBOLS}.items():
             fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
