@@ -706,13 +706,16 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
     rows_match<J>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
 }
 
-__global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+#ifndef ROWS_WAVES
+#define ROWS_WAVES 4   // wavefronts per workgroup: ROWS_WAVES * 4 replicas share one staged cost block
+#endif
+__global__ __launch_bounds__(ROWS_WAVES * WAVE) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     extern __shared__ int lds_dyn[];
     // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
     // the ranked arrivals) | cost block
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
     unsigned long long *scr_all = reinterpret_cast<unsigned long long *>(lds_rec + 64);
-    int *lds_blk = reinterpret_cast<int *>(scr_all + 16 * ROW_KEYS);
+    int *lds_blk = reinterpret_cast<int *>(scr_all + ROWS_WAVES * 4 * ROW_KEYS);
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
     const int c = S.corder[blockIdx.x / nchunks];
@@ -728,8 +731,8 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
     const bool prof = false;
     unsigned long long tprev = 0ull;
 #endif
-    const int pwave = (int)((blockIdx.x * 4 + wave) & (PROF_WAVES - 1));
-    const int r = (chunk * 4 + wave) * 4 + g;
+    const int pwave = (int)((blockIdx.x * ROWS_WAVES + wave) & (PROF_WAVES - 1));
+    const int r = (chunk * ROWS_WAVES + wave) * 4 + g;
     bool rowvalid = r < S.R;
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
@@ -771,15 +774,15 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
         const int n4 = (nc * nc + 3) >> 2;
         int4 rec = make_int4(0, 0, 0, 0);
         if ((int)threadIdx.x < min(k, 64)) rec = S.so_rec[q0 + threadIdx.x];
-        for (int i0 = 0; i0 < n4; i0 += 3 * 256) {
+        for (int i0 = 0; i0 < n4; i0 += 3 * ROWS_WAVES * WAVE) {
             const int i = i0 + threadIdx.x;
             int4 v0 = make_int4(0, 0, 0, 0), v1 = v0, v2 = v0;
             if (i < n4) v0 = blk4[i];
-            if (i + 256 < n4) v1 = blk4[i + 256];
-            if (i + 512 < n4) v2 = blk4[i + 512];
+            if (i + ROWS_WAVES * WAVE < n4) v1 = blk4[i + ROWS_WAVES * WAVE];
+            if (i + 2 * ROWS_WAVES * WAVE < n4) v2 = blk4[i + 2 * ROWS_WAVES * WAVE];
             if (i < n4) lds4[i] = v0;
-            if (i + 256 < n4) lds4[i + 256] = v1;
-            if (i + 512 < n4) lds4[i + 512] = v2;
+            if (i + ROWS_WAVES * WAVE < n4) lds4[i + ROWS_WAVES * WAVE] = v1;
+            if (i + 2 * ROWS_WAVES * WAVE < n4) lds4[i + 2 * ROWS_WAVES * WAVE] = v2;
         }
         if ((int)threadIdx.x < min(k, 64)) lds_rec[threadIdx.x] = rec;
     }
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(256) void k_tick_rows(Static S, State D, int t, int
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int gg = (__ffsll((long long)rest) - 1) >> 4;
-        bucket_tick<true, true, 4, true>(S, D, c, (chunk * 4 + wave) * 4 + gg, t, q0, k, lds_blk, nc);
+        bucket_tick<true, true, 4, true>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, lds_blk, nc);
     }
 }
 
@@ -1287,12 +1290,13 @@ void launch_reset(const Static &S, const State &D, const int *veh_node, hipStrea
     }
 }
 
-static int rows_lds_bytes(int lds_ints) { return 64 * 16 + 16 * ROW_KEYS * 8 + lds_ints * 4; }
+static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_KEYS * 8 + lds_ints * 4; }
 
 // main kernel of a non-DFS tick (the one bench.py brackets with events)
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int chunks = (S.R + 15) / 16;
-    if (S.fast_ok) hipLaunchKernelGGL(k_tick_rows, dim3(S.C * chunks), dim3(256), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+    const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+    if (S.fast_ok) hipLaunchKernelGGL(k_tick_rows, dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
     else hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * 4, st, S, D, t, lds_ints);
 }
 
