@@ -194,6 +194,7 @@ def main():
         print(json.dumps(out))
     env.close()
     if dist is not None:
+        dist.barrier()            # rank 0 still ran the roofline pass: leave together
         dist.destroy_process_group()
 
 
