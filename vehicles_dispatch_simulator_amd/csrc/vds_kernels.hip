@@ -659,7 +659,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
     uint2 *idle = D.idle + b * S.idle_cap;
     unsigned veh[J];
     int loc[J];
-    rows_load_idle<J>(idle, l16, m, veh, loc);
+    if (k > 0) rows_load_idle<J>(idle, l16, m, veh, loc);      // k is workgroup-uniform
     uint2 *arr_row = reinterpret_cast<uint2 *>(key_row);
     PROF_STAMP(1);
     // 4. arrivals of this tick (UpdateFunction :1014-1024): rank by dict insertion key
@@ -703,6 +703,20 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         wave_fence();
     }
     PROF_STAMP(2);
+    if (k == 0) {
+        // no order in this (tick, cluster) bucket: the idle list is not even read - the ranked arrivals are
+        // appended behind it in HBM and the header is updated
+        if (rowvalid) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int idx = a * 16 + l16;
+                if (idx < A) idle[m + idx] = arr_row[idx];
+            }
+            if (l16 < 3) D.hdr[b * HDR_WORDS + l16] = l16 == HDR_ORDERS ? 0 : m + A;
+            if (l16 == CNT_ARRIVALS && A > 0) D.cnt[b * CNT_WORDS + l16] = cntv + A;
+        }
+        return;
+    }
     rows_match<J>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
 }
 
