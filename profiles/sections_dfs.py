@@ -3,7 +3,7 @@ import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
 from vehicles_dispatch_simulator_amd import workloads
-R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
@@ -15,7 +15,7 @@ env.profile(True); env.run(T); ms = env.profile_read(T + 8); env.profile(False)
 env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
 env._lib.vds_debug_ablate(env._h, 0)
 names = ["0 update (drain + hdr)", "1 node mirror build", "2 LB reduction", "3 bucket-parallel own-cluster match", "4 DFS candidate scan", "5 DFS winner + removal + post"]
-nw = R * 8
+nw = R * 4
 tot = float(buf[:6].sum())
 print("instrumented: %.2f ms/launch; DFS rounds per replica-tick: %.1f" % (ms.mean(), buf[6] / nw / T))
 for i, n in enumerate(names):

@@ -236,7 +236,18 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
     h->cost_host.assign(cost, cost + (size_t)N * N);
     int *d;
     long long *dl;
-    if ((rc = upload(h, &d, h->cost_host))) return rc; S.cost = d;
+    {
+        // device copy with CLUSTER-CONTIGUOUS columns: column cl_off[c] + l holds node cl_nodes[cl_off[c] + l], so a
+        // vehicle's cost-row index is (cluster offset + loc_local) with no node-table lookup on the device
+        std::vector<int> costp((size_t)N * N, 0);
+        const int ncol = h->cl_off[C];
+        for (int i = 0; i < N; ++i) {
+            const int *src = cost + (size_t)i * N;
+            int *dst = costp.data() + (size_t)i * N;
+            for (int j = 0; j < ncol; ++j) dst[j] = src[h->cl_nodes[j]];
+        }
+        if ((rc = upload(h, &d, costp))) return rc; S.cost = d;
+    }
     if ((rc = upload(h, &d, h->node2cluster))) return rc; S.node2cluster = d;
     if ((rc = upload(h, &d, h->node_local))) return rc; S.node_local = d;
     if ((rc = upload(h, &d, h->cl_off))) return rc; S.cl_off = d;
@@ -346,7 +357,7 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
     std::vector<int> bkt_off(cnt);
     std::vector<int4> so_rec(n_proc);
     h->so_id.assign(n_proc, 0);
-    std::vector<int> ord_q(n_proc), tick_off(T + 1, 0);
+    std::vector<int> ord_q(n_proc), tick_off(T + 1, 0), so_pnode(n_proc);
     h->value_upto.assign(T + 1, 0);
     {
         std::vector<int> fill(bkt_off.begin(), bkt_off.end() - 1);
@@ -358,6 +369,7 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
             int q = fill[(size_t)ti * C + pc]++;
             so_rec[q] = make_int4(i, h->node_local[pickup[i]] | (h->node_local[delivery[i]] << 16), dc | (pc << 16), value[i]);
             h->so_id[q] = i;
+            so_pnode[q] = pickup[i];
             ord_q[k++] = q;
             tick_off[ti + 1]++;
             h->value_upto[ti + 1] += value[i];
@@ -371,6 +383,9 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
     if ((rc = upload(h, &d4, so_rec))) return rc; S.so_rec = d4;
     if ((rc = upload(h, &d, bkt_off))) return rc; S.bkt_off = d;
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;
+    if ((rc = upload(h, &d, so_pnode))) return rc; S.so_pnode = d;
+    S.max_tick_orders = 0;
+    for (int t = 0; t < T; ++t) S.max_tick_orders = std::max(S.max_tick_orders, tick_off[t + 1] - tick_off[t]);
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
     if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(n_proc, 1)))) return rc;
     if ((rc = alloc_state(h, O))) return rc;

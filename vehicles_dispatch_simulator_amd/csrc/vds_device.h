@@ -62,7 +62,7 @@ struct Static {
     int H, ring_cap;                 // arrival ring: H ticks (power of two) x ring_cap entries
     int fast_ok;                     // costs fit the packed (cost << 7 | pos) fast kernel and never exceed the reject threshold
     int max_nc;
-    const int *cost;                 // [N*N]
+    const int *cost;                 // [N*N] rows = node, COLUMNS cluster-contiguous: column cl_off[c] + loc_local
     const int *node2cluster;         // [N]
     const int *node_local;           // [N]
     const int *cl_off;               // [C+1]
@@ -77,6 +77,8 @@ struct Static {
     const int *bkt_off;              // [T*C + 1]
     const int *tick_off;             // [T+1] into ord_q
     const int *ord_q;                // [Oq] processed orders in id order -> q
+    const int *so_pnode;             // [Oq] pickup NODE of each sorted order (row of the cost matrix the DFS scans)
+    int max_tick_orders;             // most orders processed in one tick
 };
 
 struct State {

@@ -312,7 +312,7 @@ __device__ int drain_ring(const Static &S, const State &D, size_t b, int t, int 
 template <int J, bool LDSBLK>
 __device__ void match_bucket(const Static &S, const State &D, int r, int t, int now, int &m, int q0, int k,
                              const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
-                             long long &evals, int &rejects) {
+                             long long &evals, int &rejects, unsigned short *mir = nullptr) {
     const int lane = lane_id();
     unsigned veh[J], loc[J];
     bool av[J];
@@ -377,6 +377,7 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
 #pragma unroll
         for (int s = 0; s < J; ++s) {
             if (av[s]) idle[before] = make_uint2(veh[s], loc[s]);
+            if (av[s] && mir) mir[before] = (unsigned short)loc[s];     // LDS mirror of the list (k_tick_replica)
             before += av[s] ? 1 : 0;
         }
         m = navail;
@@ -398,7 +399,7 @@ __device__ __forceinline__ void add_counters(long long *cnt, long long k, long l
 
 __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t, int now, int &m, int qs, int n,
                                   const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
-                                  long long &evals, int &rejects);
+                                  long long &evals, int &rejects, unsigned short *mir = nullptr);
 
 // Whole generic tick of one bucket by one wavefront.  MAXJ = 4: tables up to 256 idle entries are
 // matched here, bigger ones are pushed to the worklist (match only).  MAXJ = 16: everything here.
@@ -874,12 +875,12 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
                 const int m2 = D.hdr[b2 * HDR_WORDS + HDR_IDLE];
                 if (m2 == 0) continue;
                 const uint2 *idle2 = D.idle + b2 * S.idle_cap;
-                const int *nodes2 = S.cl_nodes + S.cl_off[c2];
+                const int off2 = S.cl_off[c2];
                 int lc = IMAX, lp = -1;
                 for (int base = 0; base < m2; base += WAVE) {
                     int i = base + lane;
                     if (i < m2) {
-                        int cst = crow[nodes2[idle2[i].y]];
+                        int cst = crow[off2 + idle2[i].y];
                         if (lp < 0 || cst < lc) { lc = cst; lp = i; }
                     }
                 }
@@ -936,7 +937,7 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
 // own-cluster match of orders [qs, qs+n) for tables of any size (slow path: > 256 idle entries)
 __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t, int now, int &m, int qs, int n,
                                   const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
-                                  long long &evals, int &rejects) {
+                                  long long &evals, int &rejects, unsigned short *mir) {
     const int lane = lane_id();
     for (int j = 0; j < n; ++j) {
         const int4 rec = S.so_rec[qs + j];
@@ -965,6 +966,7 @@ __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t,
                     if (i < m - 1) e = idle[i + 1];
                     wave_fence();
                     if (i < m - 1) idle[i] = e;
+                    if (i < m - 1 && mir) mir[i] = (unsigned short)e.y;
                     wave_fence();
                 }
                 m--;
@@ -981,28 +983,49 @@ __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t,
     }
 }
 
-// id of the order at sorted position q, or IMAX past the bucket's end
-__device__ __forceinline__ int order_id_or_inf(const Static &S, int q, int qend) { return q < qend ? S.so_rec[q].x : IMAX; }
+// Per-bucket counters of one tick kept in LDS (flushed to D.cnt once at the end of the tick)
+#define LCNT 6   // orders, rejects, wait, value, evals, arrivals
+__device__ __forceinline__ void add_counters_lds(int *cl, int k, int rejects, long long wait_sum, long long value_sum, long long evals, int A) {
+    const int lane = lane_id();
+    int d = 0;
+    if (lane == CNT_ORDERS) d = k;
+    if (lane == CNT_REJECTS) d = rejects;
+    if (lane == CNT_WAIT) d = (int)wait_sum;
+    if (lane == CNT_VALUE) d = (int)value_sum;
+    if (lane == CNT_EVALS) d = (int)evals;
+    if (lane == CNT_ARRIVALS) d = A;
+    if (lane < LCNT && d != 0) cl[lane] += d;
+}
 
-__global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D, int t) {
+__global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D, int t, int use_mirror) {
     extern __shared__ int lds_dyn[];
     const int C = S.C;
     int *m_l = lds_dyn;               // [C] idle count
     int *qcur_l = lds_dyn + C;        // [C] sorted position of the bucket's next pending order
     int *qend_l = lds_dyn + 2 * C;    // [C] end of the bucket
-    int *next_l = lds_dyn + 3 * C;    // [C] id of the next pending order (IMAX: none)
-    int *dry_l = lds_dyn + 4 * C;     // [C] id of the first order that can find the cluster dry (IMAX: none / not DFS-capable)
+    int *dry_l = lds_dyn + 3 * C;     // [C] id of the first order that can find the cluster dry (IMAX: none / not DFS-capable)
+    int *moff_l = lds_dyn + 4 * C;    // [C] start of the cluster's segment in the node mirror
+    int *cnt_l = lds_dyn + 5 * C;     // [C][LCNT] this tick's counter deltas
+    int *ids_l = lds_dyn + (5 + LCNT) * C;                  // [max_tick_orders] Order.ID by sorted position, this tick
+    unsigned short *mirror = reinterpret_cast<unsigned short *>(ids_l + S.max_tick_orders);   // [V] LocationNode of every idle
+                                      // vehicle (cluster segments in list order): the neighbour search reads its
+                                      // candidates from LDS instead of two dependent HBM loads
     __shared__ int s_lb, s_lbc;
     __shared__ int s_cand[REPL_WAVES][4];
     const int r = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int p = t & 1;
     const int now = S.now0 + t * S.tick_minutes;
+    const int tq0 = S.bkt_off[(size_t)t * C], tq1 = S.bkt_off[(size_t)(t + 1) * C];
 #ifdef VDS_PROF
     const bool prof = (g_ablate & 128) != 0;
     unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     const int pwave = (int)((blockIdx.x * REPL_WAVES + wave) & (PROF_WAVES - 1));
 #endif
+    for (int i = threadIdx.x; i < tq1 - tq0; i += REPL_THREADS) ids_l[i] = S.so_rec[tq0 + i].x;
+    for (int i = threadIdx.x; i < LCNT * C; i += REPL_THREADS) cnt_l[i] = 0;
+    __syncthreads();
+#define ORDER_ID(q, qend) ((q) < (qend) ? ids_l[(q) - tq0] : IMAX)
     // ---- UpdateFunction, bucket-parallel
     for (int c = wave; c < C; c += REPL_WAVES) {
         const size_t b = (size_t)c * S.R + r;
@@ -1018,14 +1041,36 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
         const int A = drain_ring(S, D, b, t, m, D.idle + b * S.idle_cap);
         const int q0 = S.bkt_off[(size_t)t * C + c], q1 = S.bkt_off[(size_t)t * C + c + 1];
         if (lane == 0) {
-            hdr[HDR_IDLE] = m; hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
+            hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
             m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
-            next_l[c] = order_id_or_inf(S, q0, q1);
-            dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? order_id_or_inf(S, q0 + m, q1) : IMAX;
         }
-        if (A > 0) add_counters(D.cnt + b * CNT_WORDS, 0, 0, 0, 0, 0, A);
+        if (A > 0 && lane == 0) cnt_l[c * LCNT + CNT_ARRIVALS] = A;
     }
     __syncthreads();
+    PROF_STAMP(0);
+    for (int c = threadIdx.x; c < C; c += REPL_THREADS)
+        dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID(qcur_l[c] + m_l[c], qend_l[c]) : IMAX;
+    if (use_mirror) {
+        if (wave == 0) {            // exclusive prefix of the idle counts (lists only shrink during Match)
+            int run = 0;
+            for (int base = 0; base < C; base += WAVE) {
+                const int c = base + lane;
+                const int v = c < C ? m_l[c] : 0;
+                int inc = v;
+                for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+                if (c < C) moff_l[c] = run + inc - v;
+                run += rdlane(inc, WAVE - 1);
+            }
+        }
+        __syncthreads();
+        for (int c = wave; c < C; c += REPL_WAVES) {
+            const uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
+            const int m = m_l[c], mo = moff_l[c];
+            for (int i = lane; i < m; i += WAVE) mirror[mo + i] = (unsigned short)idle[i].y;
+        }
+    }
+    __syncthreads();
+    PROF_STAMP(1);
     // ---- MatchFunction in lower-bound rounds
     for (;;) {
         if (threadIdx.x == 0) { s_lb = IMAX; s_lbc = -1; }
@@ -1037,14 +1082,14 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
         PROF_STAMP(2);
         // all pending orders older than LB: ordinary own-cluster matches, bucket-parallel
         for (int c = wave; c < C; c += REPL_WAVES) {
-            const int nx = next_l[c];
+            const int qc = qcur_l[c], qe = qend_l[c];
+            const int nx = ORDER_ID(qc, qe);
             if (nx == LB && LB != IMAX && lane == 0) s_lbc = c;
             if (nx >= LB) continue;
-            const int qc = qcur_l[c], qe = qend_l[c];
             int n = 0;
             for (int base = qc; base < qe; base += WAVE) {
                 const int j = base + lane;
-                const unsigned long long bm = ballot(j < qe && S.so_rec[j].x < LB);
+                const unsigned long long bm = ballot(j < qe && ids_l[(j < qe ? j : qc) - tq0] < LB);
                 n += popc64(bm);
                 if (bm != ~0ull) break;
             }
@@ -1055,18 +1100,16 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
             int m = m_l[c];
             long long wait_sum = 0, value_sum = 0, evals = 0;
             int rejects = 0;
-            if (m <= 64) match_bucket<1, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-            else if (m <= 128) match_bucket<2, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-            else if (m <= 256) match_bucket<4, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-            else match_bucket_slow(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-            add_counters(D.cnt + b * CNT_WORDS, n, rejects, wait_sum, value_sum, evals, 0);
+            unsigned short *mir = use_mirror ? mirror + moff_l[c] : nullptr;   // kept in step during the compaction
+            if (m <= 64) match_bucket<1, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects, mir);
+            else if (m <= 128) match_bucket<2, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects, mir);
+            else if (m <= 256) match_bucket<4, false>(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects, mir);
+            else match_bucket_slow(S, D, r, t, now, m, qc, n, blk, nc, idle, wait_sum, value_sum, evals, rejects, mir);
+            add_counters_lds(cnt_l + c * LCNT, n, rejects, wait_sum, value_sum, evals, 0);
             if (lane == 0) {
-                D.hdr[b * HDR_WORDS + HDR_IDLE] = m;
                 m_l[c] = m; qcur_l[c] = qc + n;
-                const int nn = order_id_or_inf(S, qc + n, qe);
-                next_l[c] = nn;
-                dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? order_id_or_inf(S, qc + n + m, qe) : IMAX;
-                if (nn == LB && LB != IMAX) s_lbc = c;
+                dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID(qc + n + m, qe) : IMAX;
+                if (ORDER_ID(qc + n, qe) == LB && LB != IMAX) s_lbc = c;
             }
         }
         __syncthreads();
@@ -1084,70 +1127,65 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
                 long long wait_sum = 0, value_sum = 0, evals = 0;
                 int rejects = 0;
                 match_bucket_slow(S, D, r, t, now, m, q, 1, S.blk + S.blk_off[pc], S.cl_off[pc + 1] - S.cl_off[pc], D.idle + b * S.idle_cap,
-                                  wait_sum, value_sum, evals, rejects);
-                add_counters(D.cnt + b * CNT_WORDS, 1, rejects, wait_sum, value_sum, evals, 0);
+                                  wait_sum, value_sum, evals, rejects, use_mirror ? mirror + moff_l[pc] : nullptr);
+                add_counters_lds(cnt_l + pc * LCNT, 1, rejects, wait_sum, value_sum, evals, 0);
                 if (lane == 0) {
-                    D.hdr[b * HDR_WORDS + HDR_IDLE] = m; m_l[pc] = m; qcur_l[pc] = q + 1;
-                    next_l[pc] = order_id_or_inf(S, q + 1, qend_l[pc]);
-                    dry_l[pc] = order_id_or_inf(S, q + 1 + m, qend_l[pc]);
+                    m_l[pc] = m; qcur_l[pc] = q + 1;
+                    dry_l[pc] = ORDER_ID(q + 1 + m, qend_l[pc]);
                 }
             }
             __syncthreads();
             continue;
         }
-        const int4 rec = S.so_rec[q];
-        const int pnode = S.cl_nodes[S.cl_off[pc] + (rec.y & 0xFFFF)];
-        const int *crow = S.cost + (size_t)pnode * S.N;
+        const int *crow = S.cost + (size_t)S.so_pnode[q] * S.N;
         int bc = IMAX, bsi = IMAX, bpos = -1, bcl = -1;
-        long long ev = 0;
-        // candidate clusters of this wavefront, two at a time so that their dependent load chains
-        // (idle entry -> node -> cost) overlap
+        int ev = 0;
+        // candidate clusters of this wavefront, four at a time so that their load chains overlap; a candidate's
+        // cost is crow[cl_off[c2] + loc] (cluster-contiguous columns), loc from the LDS mirror or the HBM list
         const int s0 = S.dfs_off[pc], s1 = S.dfs_off[pc + 1];
-        for (int si = s0 + wave; si < s1; si += 2 * REPL_WAVES) {
-            const int siB = si + REPL_WAVES;
-            const int cA = S.dfs_seq[si];
-            const int cB = siB < s1 ? S.dfs_seq[siB] : cA;
-            const int mA = m_l[cA];
-            const int mB = siB < s1 ? m_l[cB] : 0;
-            if (mA == 0 && mB == 0) continue;
-            ev += mA + mB;
-            const uint2 *idA = D.idle + ((size_t)cA * S.R + r) * S.idle_cap, *idB = D.idle + ((size_t)cB * S.R + r) * S.idle_cap;
-            const int *ndA = S.cl_nodes + S.cl_off[cA], *ndB = S.cl_nodes + S.cl_off[cB];
-            int lcA = IMAX, lpA = -1, lcB = IMAX, lpB = -1;
-            const int mm = max(mA, mB);
-            for (int base = 0; base < mm; base += WAVE) {
+        for (int si = s0 + wave; si < s1; si += 4 * REPL_WAVES) {
+            int cc[4], mm4[4], lc[4], lp[4];
+            int mmax = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sx = si + u * REPL_WAVES;
+                cc[u] = sx < s1 ? S.dfs_seq[sx] : 0;
+                mm4[u] = sx < s1 ? m_l[cc[u]] : 0;
+                lc[u] = IMAX; lp[u] = -1;
+                mmax = max(mmax, mm4[u]);
+                ev += mm4[u];
+            }
+            if (mmax == 0) continue;
+            for (int base = 0; base < mmax; base += WAVE) {
                 const int i = base + lane;
-                unsigned la = 0, lb = 0;
-                if (i < mA) la = idA[i].y;
-                if (i < mB) lb = idB[i].y;
-                int na = 0, nb = 0;
-                if (i < mA) na = ndA[la];
-                if (i < mB) nb = ndB[lb];
-                int ca = IMAX, cb = IMAX;
-                if (i < mA) ca = crow[na];
-                if (i < mB) cb = crow[nb];
-                if (i < mA && (lpA < 0 || ca < lcA)) { lcA = ca; lpA = i; }
-                if (i < mB && (lpB < 0 || cb < lcB)) { lcB = cb; lpB = i; }
-            }
-            if (mA > 0) {
-                const int minc = wave_min_i32(lpA >= 0 ? lcA : IMAX);
-                if (bcl < 0 || minc < bc) {      // this wave's clusters come in increasing visit position
-                    const int minp = wave_min_i32((lpA >= 0 && lcA == minc) ? lpA : IMAX);
-                    bc = minc; bsi = si; bpos = minp; bcl = cA;
+                int col[4], cst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    col[u] = 0;
+                    if (i < mm4[u]) col[u] = S.cl_off[cc[u]] + (use_mirror ? (int)mirror[moff_l[cc[u]] + i]
+                                                                        : (int)D.idle[((size_t)cc[u] * S.R + r) * S.idle_cap + i].y);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { cst[u] = IMAX; if (i < mm4[u]) cst[u] = crow[col[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i < mm4[u] && (lp[u] < 0 || cst[u] < lc[u])) { lc[u] = cst[u]; lp[u] = i; }
             }
-            if (mB > 0) {
-                const int minc = wave_min_i32(lpB >= 0 ? lcB : IMAX);
-                if (bcl < 0 || minc < bc) {
-                    const int minp = wave_min_i32((lpB >= 0 && lcB == minc) ? lpB : IMAX);
-                    bc = minc; bsi = siB; bpos = minp; bcl = cB;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {          // this wave's clusters come in increasing visit position
+                if (mm4[u] > 0) {
+                    const int minc = wave_min_i32(lp[u] >= 0 ? lc[u] : IMAX);
+                    if (bcl < 0 || minc < bc) {
+                        const int minp = wave_min_i32((lp[u] >= 0 && lc[u] == minc) ? lp[u] : IMAX);
+                        bc = minc; bsi = si + u * REPL_WAVES; bpos = minp; bcl = cc[u];
+                    }
                 }
             }
         }
         if (lane == 0) { s_cand[wave][0] = bc; s_cand[wave][1] = bsi; s_cand[wave][2] = bpos; s_cand[wave][3] = bcl; }
         PROF_STAMP(4);
         // evaluations of all scanned clusters count (:986-991 runs for every visited cluster)
-        if (lane == 0 && ev) atomicAdd((unsigned long long *)&D.cnt[((size_t)pc * S.R + r) * CNT_WORDS + CNT_EVALS], (unsigned long long)ev);
+        if (lane == 0 && ev) atomicAdd(&cnt_l[pc * LCNT + CNT_EVALS], ev);
         __syncthreads();
         if (wave == 0) {
             int wc = IMAX, wsi = IMAX, wpos = -1, wcl = -1;
@@ -1155,10 +1193,9 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
                 const int c0 = s_cand[w][0], sx = s_cand[w][1];
                 if (s_cand[w][3] >= 0 && (wcl < 0 || c0 < wc || (c0 == wc && sx < wsi))) { wc = c0; wsi = sx; wpos = s_cand[w][2]; wcl = s_cand[w][3]; }
             }
-            const size_t bp = (size_t)pc * S.R + r;
-            long long *cnt = D.cnt + bp * CNT_WORDS;
             int res_veh = -1, res_wait = -1;
             const bool matched = wcl >= 0 && (long long)wc <= S.reject_threshold;
+            const int4 rec = S.so_rec[q];
             if (matched) {
                 const size_t bw = (size_t)wcl * S.R + r;
                 uint2 *widle = D.idle + bw * S.idle_cap;
@@ -1167,21 +1204,31 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
                 res_wait = wc;
                 wave_fence();
                 list_remove(widle, mw, wpos);
+                if (use_mirror) {
+                    unsigned short *seg = mirror + moff_l[wcl];
+                    for (int base = wpos; base < mw - 1; base += WAVE) {
+                        const int i = base + lane;
+                        unsigned short v = 0;
+                        if (i < mw - 1) v = seg[i + 1];
+                        wave_fence();
+                        if (i < mw - 1) seg[i] = v;
+                        wave_fence();
+                    }
+                }
                 if (lane == 0) {
-                    D.hdr[bw * HDR_WORDS + HDR_IDLE] = mw - 1;
                     m_l[wcl] = mw - 1;
-                    if (S.dfs_off[wcl + 1] > S.dfs_off[wcl]) dry_l[wcl] = order_id_or_inf(S, qcur_l[wcl] + mw - 1, qend_l[wcl]);
+                    if (S.dfs_off[wcl + 1] > S.dfs_off[wcl]) dry_l[wcl] = ORDER_ID(qcur_l[wcl] + mw - 1, qend_l[wcl]);
                     post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
                 }
             }
             if (lane == 0) {
                 D.out[(size_t)r * S.Oq + q] = make_int2(res_veh, res_wait);
-                cnt[CNT_ORDERS] += 1;
-                if (!matched) cnt[CNT_REJECTS] += 1;
-                else { cnt[CNT_WAIT] += res_wait; cnt[CNT_VALUE] += rec.w; }
+                int *cl = cnt_l + pc * LCNT;
+                cl[CNT_ORDERS] += 1;
+                if (!matched) cl[CNT_REJECTS] += 1;
+                else { cl[CNT_WAIT] += res_wait; cl[CNT_VALUE] += rec.w; }
                 qcur_l[pc] = q + 1;
-                next_l[pc] = order_id_or_inf(S, q + 1, qend_l[pc]);
-                dry_l[pc] = order_id_or_inf(S, q + 1, qend_l[pc]);     // m == 0: the very next order is dry again
+                dry_l[pc] = ORDER_ID(q + 1, qend_l[pc]);     // m == 0: the very next order is dry again
             }
         }
         __syncthreads();
@@ -1190,6 +1237,15 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
         if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
 #endif
     }
+    // ---- flush: idle counts and this tick's counter deltas
+    for (int c = threadIdx.x; c < C; c += REPL_THREADS) {
+        const size_t b = (size_t)c * S.R + r;
+        D.hdr[b * HDR_WORDS + HDR_IDLE] = m_l[c];
+        long long *cnt = D.cnt + b * CNT_WORDS;
+#pragma unroll
+        for (int w = 0; w < LCNT; ++w) { const int d = cnt_l[c * LCNT + w]; if (d) cnt[w] += d; }
+    }
+#undef ORDER_ID
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1209,7 +1265,6 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
     int *hdr = D.hdr + b * HDR_WORDS;
     uint2 *idle = D.idle + b * S.idle_cap;
     const int m = hdr[HDR_IDLE];
-    const int *nodes = S.cl_nodes + S.cl_off[c];
     long long cost_sum = 0;
     int ndone = 0;
     for (int base = a0; base < a1; base += WAVE) {
@@ -1221,7 +1276,7 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
             if (pos >= 0 && pos < m) {
                 uint2 e = idle[pos];
                 int tc = S.node2cluster[tgt];
-                cst = S.cost[(size_t)tgt * S.N + nodes[e.y]];     // RoadCost(LocationNode, target)
+                cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
                 post_arrival(S, D, tc, r, t, now, (int)e.x, a_seq[a], now + cst, 1, S.node_local[tgt]);
                 ok = true;
             } else {
@@ -1324,7 +1379,10 @@ void launch_update_only(const Static &S, const State &D, int t, hipStream_t st) 
 }
 
 void launch_tick_replica(const Static &S, const State &D, int t, hipStream_t st) {
-    hipLaunchKernelGGL(k_tick_replica, dim3(S.R), dim3(REPL_THREADS), (size_t)5 * S.C * sizeof(int), st, S, D, t);
+    // u16 node mirror in LDS when node ids fit 16 bits and one replica's vehicles fit ~40 KB
+    const int use_mirror = (S.N <= 65535 && S.V <= 20480) ? 1 : 0;
+    const size_t lds = ((size_t)(5 + LCNT) * S.C + S.max_tick_orders) * sizeof(int) + (use_mirror ? ((size_t)S.V + 2) / 2 * 4 : 0);
+    hipLaunchKernelGGL(k_tick_replica, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t, use_mirror);
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
