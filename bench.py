@@ -63,6 +63,7 @@ def main():
     a = ap.parse_args()
 
     import torch
+    from vehicles_dispatch_simulator_amd import dist as vdist
     from vehicles_dispatch_simulator_amd import workloads
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +92,9 @@ def main():
     else:
         w = workloads.stress()
         wname = "configs[4] (stress): %d replicas/GPU x 2048 clusters, 16384 nodes, 100k vehicles, 2M synthetic orders/day" % R
-    init = w.vehicle_nodes(R, first_replica=rank * R)
+    first, count = vdist.shard(R * world, world, rank)     # weak scaling: R replicas on every GPU, global replica ids
+    assert count == R
+    init = w.vehicle_nodes(R, first_replica=first)
 
     stream = torch.cuda.current_stream()
     env = w.make_env(R, device=local_rank, stream=stream.cuda_stream)
@@ -104,7 +107,7 @@ def main():
         env.run(T)
         env.reduce_counters_into(totals.data_ptr())
         if dist is not None:
-            dist.all_reduce(totals)   # RCCL: aggregate reward/metrics only (64 B)
+            vdist.allreduce_counters(totals)   # RCCL over xGMI: aggregate reward/metrics only (64 B)
 
     def fence():
         torch.cuda.synchronize()
@@ -122,9 +125,7 @@ def main():
     elapsed = time.perf_counter() - t0
     env.sync()                # surfaces capacity errors, if any
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = vdist.max_over_ranks(elapsed, device="cuda")
     agg = totals.cpu().numpy()
 
     # ---- roofline pass (rank 0): per-launch duration of the dominant kernel, HIP events on its stream
