@@ -1,0 +1,113 @@
+"""Randomised differential test: many small random cities / configurations, HIP path (through the C ABI) vs the
+CPU oracle, bit-exact on per-order results, counters and the final container state.  Seeds are fixed."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, neighbors_to_csr, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(20, 220))
+    C = int(rng.integers(1, min(24, N)))
+    city = synth.make_city(seed * 7 + 1, N=N, C=C, with_neighbors=False)
+    cost = city.cost.copy()
+    style = int(rng.integers(0, 4))
+    if style == 1:                                   # many ties
+        cost = (cost // 7).astype(np.int32)
+    elif style == 2:                                 # long trips (far tables)
+        cost = (cost * int(rng.integers(3, 9))).astype(np.int32)
+    elif style == 3:                                 # negative entries -> generic kernels
+        cost = (cost - int(rng.integers(1, 6))).astype(np.int32)
+    n2c = city.node2cluster.copy()
+    if rng.random() < 0.3:                           # some nodes outside every cluster
+        out = rng.random(N) < 0.15
+        if (~out).sum() >= 4:
+            n2c[out] = -1
+    nbr = []
+    for c in range(C):
+        k = int(rng.integers(0, min(C, 6)))
+        nbr.append(rng.choice(C, size=k, replace=False).tolist() if k else [])
+    V = int(rng.integers(0, 140))
+    O = int(rng.integers(2, 1400))
+    valid_nodes = np.flatnonzero(n2c >= 0)
+    span = int(rng.integers(30, 1440))
+    rel = np.sort(rng.integers(0, span, size=O)).astype(np.int32)
+    if rng.random() < 0.25:                          # a few out-of-order releases
+        idx = rng.choice(O, size=max(1, O // 20), replace=False)
+        rel[idx] = rng.integers(0, span, size=idx.size)
+        rel[0] = min(int(rel[0]), int(rel.min()))
+    pick = rng.choice(valid_nodes, size=O).astype(np.int32)
+    dele = rng.choice(valid_nodes, size=O).astype(np.int32)
+    cfg = dict(neighbor=bool(rng.random() < 0.5), depth=int(rng.integers(-1, 4)),
+               threshold=int(rng.choice([600_000_000_000, 600_000_000_000, 40, 8, 0])),
+               ring_ticks=int(rng.choice([32, 32, 8, 2])), force_generic=bool(rng.random() < 0.3),
+               tick=int(rng.choice([10, 10, 5, 15])), R=int(rng.integers(1, 9)), dispatch=bool(rng.random() < 0.4))
+    return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "60")))))
+def test_random_city_matches_oracle(seed):
+    cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg = random_case(seed)
+    off, idx = neighbors_to_csr(nbr)
+    R, N = cfg["R"], cost.shape[0]
+    rng = np.random.default_rng(1000 + seed)
+    init = rng.choice(valid_nodes, size=(R, V)).astype(np.int32) if V else np.zeros((R, 0), np.int32)
+    env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
+                             tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
+                             force_generic=cfg["force_generic"], idle_cap=max(64, V), ring_cap=max(16, V), far_cap=max(64, V))
+    env.load_orders(rel, pick, dele)
+    env.reset(init)
+    oracles = []
+    for r in range(R):
+        o = Oracle(cost, n2c, off, idx, cfg["depth"], cfg["neighbor"], rel, pick, dele, V, tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"])
+        o.reset(init[r])
+        oracles.append(o)
+    assert env.T == oracles[0].num_ticks
+    for t in range(env.T):
+        env.step()
+        for o in oracles:
+            o.begin_tick()
+        if cfg["dispatch"] and t % 4 == 1:
+            reps, cls, poss, tgts = [], [], [], []
+            for r, o in enumerate(oracles):
+                L = o.lists()
+                nidle = int(L["idle_off"][-1])
+                if nidle == 0:
+                    continue
+                pickn = rng.choice(nidle, size=min(nidle, int(rng.integers(1, 5))), replace=False)
+                vehs = L["idle_veh"][pickn]
+                tg = rng.choice(valid_nodes, size=vehs.size).astype(np.int32)
+                for v, flat, tnode in zip(vehs, pickn, tg):
+                    c = int(np.searchsorted(L["idle_off"], flat, side="right") - 1)
+                    reps.append(r); cls.append(c); poss.append(int(flat - L["idle_off"][c])); tgts.append(int(tnode))
+                o.dispatch(vehs, tg)
+            if reps:
+                env.apply_dispatch(reps, cls, poss, tgts)
+        if t % 9 == 0:
+            ob = env.obs()
+            for r, o in enumerate(oracles):
+                oo = o.obs()
+                np.testing.assert_array_equal(ob["supply"][r], oo["supply"])
+                np.testing.assert_array_equal(ob["idle_now"][r], oo["idle_now"])
+                np.testing.assert_array_equal(ob["inflight"][r], oo["inflight"])
+        env.advance()
+        for o in oracles:
+            o.end_tick()
+    got, cn = env.orders(), env.counters()
+    for r, o in enumerate(oracles):
+        exp, oc = o.orders(), o.counters()
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][r], exp[k], err_msg="seed %d replica %d %s cfg %s" % (seed, r, k, cfg))
+        for i, k in enumerate(("order_num", "reject_num", "matched", "wait_sum", "dispatch_num", "dispatch_cost", "sum_order_value", "evals")):
+            assert cn[r, i] == oc[k], (seed, r, k, cfg)
+        L, G = o.lists(), env.lists(r)
+        for k in ("idle_off", "idle_veh", "arr_off", "arr_veh", "arr_min"):
+            np.testing.assert_array_equal(G[k], L[k], err_msg="seed %d replica %d %s" % (seed, r, k))
+    env.close()
