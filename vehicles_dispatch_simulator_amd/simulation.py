@@ -381,6 +381,7 @@ class Simulation(object):
             t0 = dt.datetime.now()
             T = self.env.T
             self.env.run(T)
+            self.env.sync()
             self._touch()
             self._pull_counters()
             self._stepped_current = False
