@@ -162,9 +162,10 @@ def main():
         from oracle.oracle import Oracle
         env.reset_again()
         env.run(T)
-        got = env.orders(0, 2)
+        ncheck = min(2, R)
+        got = env.orders(0, ncheck)
         ok = True
-        for r in range(2):
+        for r in range(ncheck):
             o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server,
                        w.release_min, w.pickup, w.delivery, w.vehicles)
             o.reset(init[r]); o.run_day()
