@@ -190,6 +190,12 @@ int vds_read_work(vds_handle *h, int64_t *out);
 int vds_profile_enable(vds_handle *h, int32_t on);
 int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n);
 
+/* Host-only helper for InitVehiclesIntoCluster (:249-258): the node sequence that CPython's
+ * `rng = random.Random(seed); rng.choice(range(N))` produces (MT19937 seeded by init_by_array with the 32-bit words
+ * of `seed`, `_randbelow` by rejection on getrandbits(N.bit_length())), one draw per attempt, retried until
+ * valid[node] != 0 (valid == NULL: every node is valid).  Writes `count` nodes; needs no GPU and no handle. */
+int vds_py_random_nodes(uint64_t seed, int32_t N, int32_t count, const uint8_t *valid, int32_t *out);
+
 /* Library/ABI version: (major << 16) | minor. */
 int32_t vds_version(void);
 

@@ -104,6 +104,67 @@ extern "C" {
 
 int32_t vds_version(void) { return (1 << 16) | 0; }
 
+// MT19937 exactly as CPython's _random module drives it
+namespace {
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void init_by_array(const uint32_t *key, int len) {
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = std::max(624, len); k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (++j >= len) j = 0;
+        }
+        for (int k = 623; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+};
+}  // namespace
+
+int vds_py_random_nodes(uint64_t seed, int32_t N, int32_t count, const uint8_t *valid, int32_t *out) {
+    if (N < 1 || count < 0 || (count > 0 && !out)) return VDS_EINVAL;
+    if (valid) {
+        bool any = false;
+        for (int i = 0; i < N && !any; ++i) any = valid[i] != 0;
+        if (!any) return VDS_ESTATE;
+    }
+    Mt19937 g;
+    uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+    g.init_by_array(key, key[1] ? 2 : 1);
+    int k = 0;
+    for (uint32_t n = (uint32_t)N; n; n >>= 1) ++k;          // N.bit_length()
+    for (int v = 0; v < count; ++v) {
+        for (;;) {
+            uint32_t r;
+            do { r = g.next() >> (32 - k); } while (r >= (uint32_t)N);   // Random._randbelow_with_getrandbits
+            if (!valid || valid[r]) { out[v] = (int32_t)r; break; }
+        }
+    }
+    return VDS_OK;
+}
+
 void vds_config_init(vds_config *cfg) {
     memset(cfg, 0, sizeof(*cfg));
     cfg->struct_size = (int32_t)sizeof(vds_config);

@@ -28,8 +28,8 @@ class Workload:
     def vehicle_nodes(self, replicas: int, first_replica: int = 0) -> np.ndarray:
         """[replicas, V]; replica r (global index) draws from random.Random(veh_seed + r)."""
         valid = self.city.node2cluster >= 0
-        return synth.make_vehicle_nodes(self.veh_seed + first_replica, self.city.N, self.vehicles, replicas,
-                                        None if valid.all() else valid)
+        return native_vehicle_nodes(self.veh_seed + first_replica, self.city.N, self.vehicles, replicas,
+                                    None if valid.all() else valid)
 
     def make_env(self, replicas: int, device: int = 0, stream: Optional[int] = None, **kw):
         from .env import BatchedDispatchEnv
@@ -38,6 +38,22 @@ class Workload:
                                  neighbor_can_server=self.neighbor_can_server, device=device, stream=stream, **kw)
         env.load_orders(self.release_min, self.pickup, self.delivery)
         return env
+
+
+def native_vehicle_nodes(seed: int, N: int, V: int, R: int, valid=None) -> np.ndarray:
+    """``synth.make_vehicle_nodes`` through the native MT19937 of libvds (``vds_py_random_nodes``): the same
+    ``random.Random(seed + r).choice(range(N))`` streams, ~100x faster (tests/test_py_random.py pins the equality)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    out = np.empty((R, V), dtype=np.int32)
+    vmask = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+    for r in range(R):
+        rc = lib.vds_py_random_nodes(C.c_uint64(seed + r), N, V, None if vmask is None else vmask.ctypes.data_as(C.c_void_p),
+                                     out[r].ctypes.data_as(C.c_void_p))
+        if rc:
+            raise Exception("vds_py_random_nodes failed (%d)" % rc)
+    return out
 
 
 def depth_limit_for(side_m: float, service_m: float) -> int:
