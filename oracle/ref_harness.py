@@ -97,7 +97,8 @@ class _LoggingList(list):
 def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, cluster_mode: str,
                   side_m: float = 800.0, service_m: float = 800.0, neighbor_can_server: bool = False,
                   dispatch_policy: Optional[Callable] = None, capture_lists: bool = False,
-                  keep_dir: Optional[str] = None, quiet: bool = True, focus_bound=None) -> Dict[str, np.ndarray]:
+                  keep_dir: Optional[str] = None, quiet: bool = True, focus_bound=None,
+                  tick_minutes: int = 10, pickup_window_raw: Optional[int] = None) -> Dict[str, np.ndarray]:
     """Run the reference end to end on the given synthetic day; return inputs + outputs.
 
     ``dispatch_policy(sim, tick) -> list[(vehicle_obj, target_node)]`` (optional) is invoked
@@ -108,6 +109,12 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
     processes dispatched vehicles.
     """
     setting, refsim = _import_reference()
+    # settings, not code: TimePeriods is a constructor argument; PICKUPTIMEWINDOW is the module global the reference's
+    # `from config.setting import *` bound into simulator.simulator (read at simulator.py:943)
+    saved_window = refsim.PICKUPTIMEWINDOW
+    if pickup_window_raw is not None:
+        refsim.PICKUPTIMEWINDOW = np.timedelta64(int(pickup_window_raw))
+    time_periods = np.timedelta64(int(tick_minutes) * setting.MINUTES)
     root = keep_dir or tempfile.mkdtemp(prefix="vds_ref_")
     cwd = os.getcwd()
     devnull = open(os.devnull, "w")
@@ -120,7 +127,7 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
         random.seed(seed)
         S = refsim.Simulation(
             ClusterMode=cluster_mode, DemandPredictionMode="None", DispatchMode="Simulation",
-            VehiclesNumber=V, TimePeriods=setting.TIMESTEP, LocalRegionBound=tuple(focus_bound or city.bound),
+            VehiclesNumber=V, TimePeriods=time_periods, LocalRegionBound=tuple(focus_bound or city.bound),
             SideLengthMeter=side_m, VehiclesServiceMeter=service_m,
             NeighborCanServer=neighbor_can_server, FocusOnLocalRegion=focus_bound is not None)
         t0 = time.time()
@@ -146,6 +153,8 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
         # probe facts re-asserted
         assert S.RoadCost(1, 2) == int(cost[2, 1])
         assert not (5 > setting.PICKUPTIMEWINDOW) and (10 ** 13 > setting.PICKUPTIMEWINDOW)
+        if pickup_window_raw is not None:
+            assert (pickup_window_raw + 1 > refsim.PICKUPTIMEWINDOW) and not (pickup_window_raw > refsim.PICKUPTIMEWINDOW)
         ep0 = S.Orders[0].ReleasTime
         rel_min = np.array([int((o.ReleasTime - ep0).total_seconds()) // 60 for o in S.Orders], dtype=np.int32)
         o_pick = np.array([o.PickupPoint for o in S.Orders], dtype=np.int32)
@@ -242,6 +251,7 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
             cost=cost_int.astype(np.int32), cost_is_integral=np.bool_((cost == cost_int).all()),
             node2cluster=node2cluster, nbr_off=nbr_off, nbr_idx=nbr_idx,
             depth_limit=np.int64(S.NeighborServerDeepLimit), neighbor_can_server=np.bool_(neighbor_can_server),
+            tick_minutes=np.int64(tick_minutes), reject_threshold=np.int64(600_000_000_000 if pickup_window_raw is None else pickup_window_raw),
             veh_node=veh_node, veh_cluster=veh_cluster,
             o_release_min=rel_min, o_pickup=o_pick, o_delivery=o_del, o_value=o_val,
             # outputs
@@ -267,6 +277,7 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
             out["l_arr_min"] = np.array([x + [-1] * (V - len(x)) for x in lists["arr_min"]], dtype=np.int32).reshape(T, V)
         return out
     finally:
+        refsim.PICKUPTIMEWINDOW = saved_window
         sys.stdout = old_stdout
         devnull.close()
         os.chdir(cwd)

@@ -76,6 +76,12 @@ TINY = {
                                run=dict(V=70, seed=19, cluster_mode="KmeansClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
     "tiny_focus_grid": dict(city=dict(seed=111, N=420, C=12), O=3000, oseed=11, focus=(104.035, 104.105, 30.625, 30.695),
                             run=dict(V=80, seed=21, cluster_mode="Grid", side_m=2000, service_m=5000, neighbor_can_server=True)),
+    "tiny_tick5": dict(city=dict(seed=112, N=300, C=12), O=2500, oseed=12,
+                       run=dict(V=100, seed=22, cluster_mode="KmeansClustering", side_m=3200, service_m=8000, neighbor_can_server=True, tick_minutes=5)),
+    "tiny_window6": dict(city=dict(seed=113, N=300, C=12), O=2500, oseed=13,
+                         run=dict(V=140, seed=23, cluster_mode="KmeansClustering", side_m=3200, service_m=3200, pickup_window_raw=6)),
+    "tiny_window4_dfs2": dict(city=dict(seed=114, N=300, C=12), O=3000, oseed=14,
+                              run=dict(V=70, seed=24, cluster_mode="SpectralClustering", side_m=3200, service_m=8000, neighbor_can_server=True, pickup_window_raw=4)),
     "tiny_two_orders": dict(city=dict(seed=110, N=120, C=12), O=2, oseed=10,
                             run=dict(V=30, seed=20, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
 }

@@ -36,9 +36,15 @@ def load_golden(name):
 
 def make_oracle(g) -> Oracle:
     o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], int(g["depth_limit"]),
-               bool(g["neighbor_can_server"]), g["o_release_min"], g["o_pickup"], g["o_delivery"], int(g["V"]))
+               bool(g["neighbor_can_server"]), g["o_release_min"], g["o_pickup"], g["o_delivery"], int(g["V"]), **engine_settings(g))
     o.reset(g["veh_node"])
     return o
+
+
+def engine_settings(g):
+    """tick length / raw pickup window of a fixture (older fixtures: the reference's defaults)."""
+    return dict(tick_minutes=int(g["tick_minutes"]) if "tick_minutes" in g else 10,
+                reject_threshold=int(g["reject_threshold"]) if "reject_threshold" in g else 600_000_000_000)
 
 
 def dispatch_by_tick(g):

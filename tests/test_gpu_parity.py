@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from helpers import dispatch_by_tick, golden_names, load_golden, make_oracle
+from helpers import dispatch_by_tick, engine_settings, golden_names, load_golden, make_oracle
 from oracle.oracle import Oracle
 from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth
 
@@ -18,7 +18,8 @@ TINY = golden_names("tiny_")
 
 def make_env(g, R, **kw):
     env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=int(g["V"]),
-                             depth_limit=int(g["depth_limit"]), neighbor_can_server=bool(g["neighbor_can_server"]), **kw)
+                             depth_limit=int(g["depth_limit"]), neighbor_can_server=bool(g["neighbor_can_server"]),
+                             **{**engine_settings(g), **kw})
     env.load_orders(g["o_release_min"], g["o_pickup"], g["o_delivery"])
     return env
 
