@@ -196,6 +196,15 @@ int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n);
  * valid[node] != 0 (valid == NULL: every node is valid).  Writes `count` nodes; needs no GPU and no handle. */
 int vds_py_random_nodes(uint64_t seed, int32_t N, int32_t count, const uint8_t *valid, int32_t *out);
 
+/* Host-only: the visit order of FindServerVehicleFunction (:978-996) from every start cluster - the order in which
+ * the recursion marks clusters visited (`Visitlist[Cluster.ID] = True` :984), start cluster first - for neighbour
+ * lists nbr_idx[nbr_off[c] .. nbr_off[c+1]) (Cluster.Neighbor order) and NeighborServerDeepLimit = depth_limit
+ * (:290).  This is the table vds_load_static derives for the neighbour search.  Always writes seq_off[C+1]
+ * (seq_off[C] = total length); writes the first `cap` sequence entries to `seq`; returns VDS_ECAPACITY when the
+ * total exceeds cap (call with cap = 0, seq = NULL to size the buffer).  Needs no GPU and no handle. */
+int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
+                      int32_t *seq_off, int32_t *seq, int64_t cap);
+
 /* Library/ABI version: (major << 16) | minor. */
 int32_t vds_version(void);
 

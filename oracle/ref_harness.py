@@ -46,7 +46,7 @@ def _import_reference():
 
 
 def write_reference_data_dir(root: str, city, start_unix, pickup, delivery, n_drivers: int,
-                             cluster_mode: str, date: str = "1101") -> None:
+                             cluster_mode: str, date: str = "1101", neighbor_csv: Optional[str] = None) -> None:
     """Lay out ``<root>/data`` the way ``ReadAllFiles`` (``readfiles.py:102-114``) and
     ``CreateCluster`` (``simulator.py:572``) expect it."""
     import pandas as pd
@@ -78,6 +78,9 @@ def write_reference_data_dir(root: str, city, start_unix, pickup, delivery, n_dr
     if cluster_mode != "Grid":
         path = os.path.join(d, str(tuple(city.bound)) + str(city.C) + cluster_mode + "Clusters.csv")
         pd.DataFrame({"0": city.node2cluster.astype(np.int64)}).to_csv(path, index=False)
+        if neighbor_csv is not None:
+            # a cached "...Neighbor.csv" (simulator.py:592-594): CreateCluster then parses it instead of recomputing
+            shutil.copyfile(neighbor_csv, os.path.join(d, str(tuple(city.bound)) + str(city.C) + cluster_mode + "Neighbor.csv"))
 
 
 class _LoggingList(list):
@@ -98,7 +101,8 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
                   side_m: float = 800.0, service_m: float = 800.0, neighbor_can_server: bool = False,
                   dispatch_policy: Optional[Callable] = None, capture_lists: bool = False,
                   keep_dir: Optional[str] = None, quiet: bool = True, focus_bound=None,
-                  tick_minutes: int = 10, pickup_window_raw: Optional[int] = None) -> Dict[str, np.ndarray]:
+                  tick_minutes: int = 10, pickup_window_raw: Optional[int] = None,
+                  neighbor_csv: Optional[str] = None, capture_dfs=()) -> Dict[str, np.ndarray]:
     """Run the reference end to end on the given synthetic day; return inputs + outputs.
 
     ``dispatch_policy(sim, tick) -> list[(vehicle_obj, target_node)]`` (optional) is invoked
@@ -107,6 +111,10 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
     (``DispatchNum``/``TotallyDispatchCost`` ``simulator.py:50-51``; idle list / arrival dict
     ``objects.py:10-11``) so that the *reference's own* Update/Match/SupplyExpect code then
     processes dispatched vehicles.
+
+    ``neighbor_csv``: a cached neighbour-distance file placed where ``CreateCluster`` looks for it.
+    ``capture_dfs``: depth limits for which the visit order of ``FindServerVehicleFunction``
+    (``simulator.py:978-996``) is recorded for every start cluster (``dfs_off_d<k>`` / ``dfs_seq_d<k>``).
     """
     setting, refsim = _import_reference()
     # settings, not code: TimePeriods is a constructor argument; PICKUPTIMEWINDOW is the module global the reference's
@@ -120,7 +128,8 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
     devnull = open(os.devnull, "w")
     old_stdout = sys.stdout
     try:
-        write_reference_data_dir(root, city, start_unix, pickup, delivery, n_drivers=V, cluster_mode=cluster_mode)
+        write_reference_data_dir(root, city, start_unix, pickup, delivery, n_drivers=V, cluster_mode=cluster_mode,
+                                 neighbor_csv=neighbor_csv)
         os.chdir(root)
         if quiet:
             sys.stdout = devnull
@@ -162,6 +171,30 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
         o_val = np.array([o.OrderValue for o in S.Orders], dtype=np.int64)
         assert all(o.ID == i for i, o in enumerate(S.Orders))
         O = len(S.Orders)
+
+        # ---------------- DFS visit order of the reference's own recursion ----------------
+        dfs = {}
+        if capture_dfs:
+            # `Visitlist` is a plain dict keyed by Cluster.ID (:984): its insertion order IS the visit order.
+            # Idle lists are emptied meanwhile so the walk does no cost lookups; NeighborCanServer is a setting.
+            saved_idle = [c.IdleVehicles for c in S.Clusters]
+            saved_ncs = S.NeighborCanServer
+            for c in S.Clusters:
+                c.IdleVehicles = []
+            S.NeighborCanServer = True
+            S.NowOrder = S.Orders[0]
+            for d in capture_dfs:
+                off, seq = [0], []
+                for c in S.Clusters:
+                    visit = {}
+                    assert S.FindServerVehicleFunction(int(d), visit, c, None, 0) is None
+                    seq.extend(visit.keys())
+                    off.append(len(seq))
+                dfs["dfs_off_d%d" % d] = np.array(off, dtype=np.int32)
+                dfs["dfs_seq_d%d" % d] = np.array(seq, dtype=np.int16)
+            S.NeighborCanServer = saved_ncs
+            for c, l in zip(S.Clusters, saved_idle):
+                c.IdleVehicles = l
 
         # ---------------- instrumentation ----------------
         match_log = []
@@ -268,6 +301,7 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
             dispatch_log=np.array(dispatch_log, dtype=np.int64).reshape(-1, 6),
             ref_init_s=np.float64(t_init), ref_sim_s=np.float64(t_sim),
         )
+        out.update(dfs)
         if capture_lists:
             T = len(lists["idle_off"])
             out["l_idle_off"] = np.array(lists["idle_off"], dtype=np.int32).reshape(T, C + 1)

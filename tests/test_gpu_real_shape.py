@@ -17,7 +17,9 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("name,R", [("real_kmeans192", 6), ("real_spectral192_dfs2", 3)])
+@pytest.mark.parametrize("name,R", [("real_kmeans192", 6), ("real_spectral192_dfs2", 3),
+                                    # the reference's shipped road graph + shipped clusterings / neighbour tables
+                                    ("real_shipped_kmeans", 3), ("real_shipped_spectral_dfs2", 2), ("real_shipped_transport_dfs2", 2)])
 def test_real_shape_day(name, R):
     g = load_golden(name)
     V, N = int(g["V"]), int(g["N"])

@@ -213,12 +213,50 @@ int vds_set_stream(vds_handle *h, void *hip_stream) {
     return VDS_OK;
 }
 
-// FindServerVehicleFunction (:978-996) visit order for start cluster c, positions >= 1
-static void dfs_visit(int k, int deep, int limit, const int32_t *off, const int32_t *idx, std::vector<char> &seen, std::vector<int> &seq) {
-    if (deep > limit || seen[k]) return;
-    seen[k] = 1;
-    seq.push_back(k);
-    for (int j = off[k]; j < off[k + 1]; ++j) dfs_visit(idx[j], deep + 1, limit, off, idx, seen, seq);
+// FindServerVehicleFunction (:978-996): clusters in the order the recursion marks them visited, start cluster
+// first.  Depth-limited and global-visited (quirk Q4: a cluster first reached on a deep branch is not revisited
+// from a shallower one).  Explicit stack: the walk can be C levels deep.
+static void dfs_visit(int start, int limit, const int32_t *off, const int32_t *idx, std::vector<char> &seen, std::vector<int> &seq) {
+    struct Frame { int k, next, deep; };
+    std::vector<Frame> stack;
+    if (limit < 0) return;                         // `deep > NeighborServerDeepLimit` already at deep 0
+    seen[start] = 1;
+    seq.push_back(start);
+    stack.push_back({start, off[start], 0});
+    while (!stack.empty()) {
+        Frame &f = stack.back();
+        if (f.next >= off[f.k + 1]) { stack.pop_back(); continue; }
+        const int j = idx[f.next++];
+        const int deep = f.deep + 1;
+        if (deep > limit || seen[j]) continue;
+        seen[j] = 1;
+        seq.push_back(j);
+        stack.push_back({j, off[j], deep});        // (invalidates f; not used again this iteration)
+    }
+}
+
+int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
+                      int32_t *seq_off, int32_t *seq, int64_t cap) {
+    if (!nbr_off || !seq_off || C < 1 || (cap > 0 && !seq)) return VDS_EINVAL;
+    if (!nbr_idx && nbr_off[C] > 0) return VDS_EINVAL;
+    for (int k = 0; k < nbr_off[C]; ++k)
+        if (nbr_idx[k] < 0 || nbr_idx[k] >= C) return VDS_EINVAL;
+    std::vector<char> seen(C);
+    std::vector<int> one;
+    int64_t total = 0;
+    seq_off[0] = 0;
+    for (int c = 0; c < C; ++c) {
+        one.clear();
+        std::fill(seen.begin(), seen.end(), 0);
+        dfs_visit(c, depth_limit, nbr_off, nbr_idx, seen, one);
+        for (int v : one) {
+            if (total < cap) seq[total] = v;
+            ++total;
+        }
+        if (total > 0x7fffffff) return VDS_ECAPACITY;
+        seq_off[c + 1] = (int32_t)total;
+    }
+    return total <= cap ? VDS_OK : VDS_ECAPACITY;
 }
 
 int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t *node2cluster, int32_t C,
@@ -284,7 +322,7 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
             seq.clear();
             if (nbr_off[c + 1] > nbr_off[c]) {          // `elif self.NeighborCanServer and len(NowCluster.Neighbor)` :936
                 std::fill(seen.begin(), seen.end(), 0);
-                dfs_visit(c, 0, depth_limit, nbr_off, nbr_idx, seen, seq);
+                dfs_visit(c, depth_limit, nbr_off, nbr_idx, seen, seq);
             }
             for (size_t i = 1; i < seq.size(); ++i) dfs_seq.push_back(seq[i]);   // position 0 is c itself
             dfs_off[c + 1] = (int)dfs_seq.size();

@@ -231,6 +231,22 @@ def cluster_neighbors_from_cost(cost: np.ndarray, node2cluster: np.ndarray, C: i
     return out
 
 
+def lattice_cost(seed: int, ix: np.ndarray, iy: np.ndarray, minutes_per_m_inv: int = 280) -> np.ndarray:
+    """Asymmetric integer travel minutes between lattice points (micro-degree coordinates):
+    Manhattan metres, stretched by a per-ordered-pair factor in [1.0, 1.3), floor-divided by
+    ``minutes_per_m_inv`` metres per minute (floor(shortest-path-metres / 280))."""
+    ix = np.asarray(ix, dtype=np.int64)
+    iy = np.asarray(iy, dtype=np.int64)
+    N = ix.size
+    idx = np.arange(N, dtype=np.int64)
+    dm = (np.abs(ix[:, None] - ix[None, :]) * 957 + np.abs(iy[:, None] - iy[None, :]) * 1110) // 10000
+    pair = (idx[:, None] * np.int64(N) + idx[None, :]).astype(_U64)
+    noise = (hash_u64(seed, 41, pair.ravel()) % _U64(300)).astype(np.int64).reshape(N, N)
+    cost = ((dm * (1000 + noise)) // (minutes_per_m_inv * 1000)).astype(np.int32)
+    np.fill_diagonal(cost, 0)
+    return cost
+
+
 def make_city(seed: int, N: int = 4139, C: int = 192, mode: str = "cluster",
               bound=DEFAULT_BOUND, side_m: float = 800.0, minutes_per_m_inv: int = 280,
               with_neighbors: bool = True) -> City:
@@ -245,12 +261,7 @@ def make_city(seed: int, N: int = 4139, C: int = 192, mode: str = "cluster",
     ix, iy = _node_lattice(seed, N, span_x, span_y)
     node_id = (np.int64(1_000_000_007) + np.argsort(np.argsort(hash_u64(seed, 31, np.arange(N)), kind="stable"), kind="stable") * 7919).astype(np.int64)
 
-    idx = np.arange(N, dtype=np.int64)
-    dm = (np.abs(ix[:, None] - ix[None, :]) * 957 + np.abs(iy[:, None] - iy[None, :]) * 1110) // 10000
-    pair = (idx[:, None] * np.int64(N) + idx[None, :]).astype(_U64)
-    noise = (hash_u64(seed, 41, pair.ravel()) % _U64(300)).astype(np.int64).reshape(N, N)
-    cost = ((dm * (1000 + noise)) // (minutes_per_m_inv * 1000)).astype(np.int32)
-    np.fill_diagonal(cost, 0)
+    cost = lattice_cost(seed, ix, iy, minutes_per_m_inv)
 
     gw = gh = 0
     if mode == "grid":

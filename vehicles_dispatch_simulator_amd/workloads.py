@@ -56,6 +56,27 @@ def native_vehicle_nodes(seed: int, N: int, V: int, R: int, valid=None) -> np.nd
     return out
 
 
+def native_dfs_sequences(nbr_off, nbr_idx, depth_limit: int):
+    """Visit order of ``FindServerVehicleFunction`` (``simulator.py:978-996``) from every start cluster, as the
+    library derives it (``vds_dfs_sequences``; host code, no GPU): ``(seq_off[C+1], seq)``, start cluster first."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    off = np.ascontiguousarray(nbr_off, dtype=np.int32)
+    idx = np.ascontiguousarray(nbr_idx, dtype=np.int32)
+    n = off.size - 1
+    seq_off = np.zeros(n + 1, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+    rc = lib.vds_dfs_sequences(p(off), p(idx), n, int(depth_limit), p(seq_off), None, 0)
+    if rc not in (0, -3):
+        raise Exception("vds_dfs_sequences failed (%d)" % rc)
+    seq = np.zeros(int(seq_off[n]), dtype=np.int32)
+    rc = lib.vds_dfs_sequences(p(off), p(idx), n, int(depth_limit), p(seq_off), p(seq), seq.size)
+    if rc:
+        raise Exception("vds_dfs_sequences failed (%d)" % rc)
+    return seq_off, seq
+
+
 def depth_limit_for(side_m: float, service_m: float) -> int:
     """NeighborServerDeepLimit, ``simulator.py:290``."""
     return int((service_m - (0.5 * side_m)) // side_m)
