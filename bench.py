@@ -14,7 +14,8 @@ The one JSON line printed by rank 0 also carries
   roofline      dominant kernel k_tick: algorithmic bytes per launch (SURVEY.md 8(d) byte model)
                 / average launch duration (HIP events on the kernel's stream) vs 8 TB/s HBM;
   cpu_baseline  the CPU oracle (a C port of the reference algorithm, 1 thread) timed on this
-                host on a bounded sample of the same workload.
+                host on a bounded sample of the same workload;
+  cpu_baseline_all_cores  the same oracle as one independent single-replica process per host core.
 """
 from __future__ import annotations
 
@@ -49,6 +50,54 @@ def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 2048):
     return {"value": ticks / dt, "unit": "env-steps*replicas/s", "cores": 1, "kind": "port",
             "sample": "%d single-replica days (%d ticks, %.3g match evaluations) of the same workload in %.1f s" % (days, ticks, evals, dt),
             "match_evals_per_s": evals / dt}
+
+
+def cpu_baseline_all_cores(w, init_rows, budget_s: float = 8.0, max_procs: int = 256):
+    """the same oracle as independent single-replica processes on every host core (the reference is
+    single-threaded; multi-core = independent replica processes).  Fresh interpreters, no GPU state shared."""
+    import shutil
+    import subprocess
+    import tempfile
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    procs_n = max(1, min(cores, max_procs))
+    tmp = tempfile.mkdtemp(prefix="vds_cpu_")
+    try:
+        arrays = dict(cost=w.city.cost, node2cluster=w.city.node2cluster, nbr_off=w.nbr_off, nbr_idx=w.nbr_idx,
+                      release_min=w.release_min, pickup=w.pickup, delivery=w.delivery, init=np.ascontiguousarray(init_rows),
+                      scalars=np.array([w.depth_limit, int(w.neighbor_can_server), w.vehicles], dtype=np.int64))
+        for k, v in arrays.items():
+            np.save(os.path.join(tmp, k + ".npy"), np.ascontiguousarray(v))
+        worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, worker, tmp, str(budget_s), str(i)], stdout=subprocess.PIPE, env=env)
+                 for i in range(procs_n)]
+        rate = evals_rate = 0.0
+        days = ticks = 0
+        for p in procs:
+            out, _ = p.communicate(timeout=budget_s * 6 + 120)
+            if p.returncode != 0:
+                raise RuntimeError("cpu worker failed")
+            d, t, e, dt = out.decode().split()
+            days += int(d); ticks += int(t)
+            rate += int(t) / float(dt); evals_rate += int(e) / float(dt)
+        wall = time.perf_counter() - t0
+        quota = ""
+        try:                                     # a container CPU quota below the visible core count explains sub-linear scaling
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = "; cgroup cpu.max=%s" % ("unlimited" if q[0] == "max" else "%.1f cores" % (int(q[0]) / int(q[1])))
+        except Exception:
+            pass
+        return {"value": rate, "unit": "env-steps*replicas/s", "cores": procs_n, "kind": "port",
+                "sample": "%d processes x ~%.0f s, %d single-replica days (%d ticks) of the same workload; %.1f s wall incl. start-up%s" % (procs_n, budget_s, days, ticks, wall, quota),
+                "match_evals_per_s": evals_rate}
+    except Exception as e:       # a reported extra, never a reason to lose the bench line
+        return {"value": None, "error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -173,9 +222,10 @@ def main():
             ok = ok and all(np.array_equal(got[k][r], exp[k]) for k in ("status", "vehicle", "wait"))
         check = bool(ok)
 
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(w, init[: min(R, 16)])
+        cpu_all = cpu_baseline_all_cores(w, init[: min(R, 64)])
 
     if rank == 0:
         env_steps = T * R * world * a.steps
@@ -191,6 +241,8 @@ def main():
             "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if cpu_all is not None:
+            out["cpu_baseline_all_cores"] = cpu_all
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))
