@@ -116,3 +116,40 @@ def test_api_misuse_is_reported_not_fatal():
     with pytest.raises(Exception, match="replica range"):
         env.orders(1, 5)
     env.close()
+
+
+def test_handles_on_their_own_streams_advance_independently():
+    """INTEGRATION.md "different days in parallel": several handles on one GPU, each on its own HIP stream
+    (torch side streams adopted through vds_set_stream), ticks issued interleaved without host syncs."""
+    import torch
+    names = ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid", "tiny_tick5"]
+    envs, inits, gs, streams = [], [], [], []
+    for i, name in enumerate(names):
+        g = load_golden(name)
+        R, V, N = 5 + i, int(g["V"]), int(g["N"])
+        st = torch.cuda.Stream()
+        init = np.stack([g["veh_node"]] + [synth.init_vehicle_nodes(random.Random(40 + 10 * i + r), N, V, g["node2cluster"] >= 0) for r in range(1, R)])
+        env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=V,
+                                 depth_limit=int(g["depth_limit"]), neighbor_can_server=bool(g["neighbor_can_server"]),
+                                 tick_minutes=int(g["tick_minutes"]) if "tick_minutes" in g else 10, stream=st.cuda_stream)
+        env.load_orders(g["o_release_min"], g["o_pickup"], g["o_delivery"])
+        env.reset(init)
+        envs.append(env); inits.append(init); gs.append(g); streams.append(st)
+    for t in range(max(e.T for e in envs)):
+        for e in envs:
+            if t < e.T:
+                e.step()
+                e.advance()
+    for e, g, init in zip(envs, gs, inits):
+        got = e.orders()
+        np.testing.assert_array_equal(got["vehicle"][0], g["o_vehicle"])      # replica 0 = the reference's own day
+        np.testing.assert_array_equal(got["wait"][0], g["o_wait"])
+        for r in range(1, e.R):
+            o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], int(g["depth_limit"]), bool(g["neighbor_can_server"]),
+                       g["o_release_min"], g["o_pickup"], g["o_delivery"], int(g["V"]),
+                       tick_minutes=int(g["tick_minutes"]) if "tick_minutes" in g else 10)
+            o.reset(init[r]); o.run_day()
+            exp = o.orders()
+            for k in ("status", "vehicle", "wait"):
+                np.testing.assert_array_equal(got[k][r], exp[k], err_msg="%d %s" % (r, k))
+        e.close()
