@@ -303,6 +303,18 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
         )
         out.update(dfs)
         if capture_lists:
+            # context features of every order (simulator.py:842-866) and the normalised weather tables (:79-95)
+            out["o_time_weather"] = np.array([S.GetTimeAndWeather(o) for o in S.Orders], dtype=np.float64)
+            import pandas as pd
+
+            class _Stamp:          # GetTimeAndWeather only reads Order.ReleasTime
+                def __init__(self, ts):
+                    self.ReleasTime = ts
+            grid = [pd.Timestamp(2016, 11, d, h, (7 * d + h) % 60) for d in range(1, 31) for h in (0, 11, 12, 23)]
+            out["tw_grid_minutes"] = np.array([int((g - pd.Timestamp(2016, 11, 1)).total_seconds()) // 60 for g in grid], dtype=np.int64)
+            out["tw_grid"] = np.array([S.GetTimeAndWeather(_Stamp(g)) for g in grid], dtype=np.float64)
+            out["weather_tables"] = np.concatenate([S.WeatherType, S.MinimumTemperature, S.MaximumTemperature,
+                                                    S.WindDirection, S.WindPower]).astype(np.float64)
             T = len(lists["idle_off"])
             out["l_idle_off"] = np.array(lists["idle_off"], dtype=np.int32).reshape(T, C + 1)
             out["l_idle_veh"] = np.array([x + [-1] * (V - len(x)) for x in lists["idle_veh"]], dtype=np.int32).reshape(T, V)

@@ -69,6 +69,13 @@ class Simulation(object):
         self.NodeID2NodesLocation = {}
         self.TransitionTempPool = []
         self.MapWestBound, self.MapEastBound, self.MapSouthBound, self.MapNorthBound = LocalRegionBound
+        # weather data, normalised (simulator.py:79-95)
+        from .config import weather
+        self.WeatherType = self.Normaliztion_1D(weather.WEATHER_TYPE_HALF_DAYS)
+        self.MinimumTemperature = self.Normaliztion_1D(weather.MINIMUM_TEMPERATURE)
+        self.MaximumTemperature = self.Normaliztion_1D(weather.MAXIMUM_TEMPERATURE)
+        self.WindDirection = self.Normaliztion_1D(weather.WIND_DIRECTION)
+        self.WindPower = self.Normaliztion_1D(weather.WIND_POWER)
         # input parameters (simulator.py:98-113)
         self.ClusterMode = ClusterMode
         self.DispatchMode = DispatchMode
@@ -95,6 +102,45 @@ class Simulation(object):
         self._cache = {}
         self._pending = []
         self.CalculateTheScaleOfDivision()
+
+    # ---------------------------------------------------------------- context features (simulator.py:697-706, 833-866)
+    def Normaliztion_1D(self, arr):
+        arr = np.asarray(arr)
+        lo = arr.min()
+        span = arr.max() - lo
+        return np.array([float(x - lo) / span for x in arr])
+
+    def WorkdayOrWeekend(self, day):
+        if type(day) != type(0) or day < 0 or day > 6:
+            raise Exception('input format error')
+        return "Weekend" if day in (5, 6) else "Workday"
+
+    def GetTimeAndWeather(self, Order):
+        """[Day, Week, Weekend, Hour, Minute, WeatherType, MinTemp, MaxTemp, WindDirection, WindPower] of the order's
+        release time (November only, like the reference)."""
+        return self._time_weather_one(Order.ReleasTime)
+
+    def _time_weather_one(self, ts):
+        if ts.month != 11:
+            raise Exception('Month format error')
+        day, week = ts.day, ts.weekday()
+        half = 2 * (day - 1) + (0 if ts.hour < 12 else 1)
+        return [day, week, 1 if week in (5, 6) else 0, ts.hour, ts.minute, self.WeatherType[half],
+                self.MinimumTemperature[day - 1], self.MaximumTemperature[day - 1], self.WindDirection[day - 1], self.WindPower[day - 1]]
+
+    def TimeAndWeatherFeatures(self, times=None):
+        """``GetTimeAndWeather`` for many timestamps at once: float64 ``[n, 10]`` (default: every order's release
+        time), the batched form an agent consumes."""
+        ts = pd.DatetimeIndex([o.ReleasTime for o in self.Orders] if times is None else times)
+        if (ts.month != 11).any():
+            raise Exception('Month format error')
+        day, week, hour = ts.day.values, ts.weekday.values, ts.hour.values
+        out = np.empty((len(ts), 10), dtype=np.float64)
+        out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4] = day, week, (week >= 5), hour, ts.minute.values
+        out[:, 5] = self.WeatherType[2 * (day - 1) + (hour >= 12)]
+        for k, tab in enumerate((self.MinimumTemperature, self.MaximumTemperature, self.WindDirection, self.WindPower)):
+            out[:, 6 + k] = tab[day - 1]
+        return out
 
     # ---------------------------------------------------------------- construction
     def _say(self, *a):
