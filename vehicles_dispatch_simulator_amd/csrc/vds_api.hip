@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -98,6 +100,21 @@ static int upload(vds_handle *h, T **p, const std::vector<T> &v) {
     return VDS_OK;
 }
 
+// No C++ exception may cross the C ABI (vds.h: "never abort"): host allocation failures and the like become a
+// status code + vds_last_error.
+template <typename F>
+static int guarded(vds_handle *h, const char *name, F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(h, VDS_ENOMEM, "%s: out of host memory", name);
+    } catch (const std::exception &e) {
+        return fail(h, VDS_EINVAL, "%s: %s", name, e.what());
+    } catch (...) {
+        return fail(h, VDS_EINVAL, "%s: unknown C++ exception", name);
+    }
+}
+
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" {
@@ -176,7 +193,7 @@ void vds_config_init(vds_config *cfg) {
 
 const char *vds_last_error(const vds_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int vds_create(const vds_config *cfg, vds_handle **out) {
+static int create_impl(const vds_config *cfg, vds_handle **out) {
     if (!cfg || !out) return fail(nullptr, VDS_EINVAL, "vds_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(vds_config)) return fail(nullptr, VDS_EINVAL, "vds_create: vds_config size mismatch (%d vs %zu)", cfg->struct_size, sizeof(vds_config));
     if (cfg->replicas < 1 || cfg->vehicles < 0 || cfg->tick_minutes < 1) return fail(nullptr, VDS_EINVAL, "vds_create: bad replicas/vehicles/tick_minutes");
@@ -235,7 +252,7 @@ static void dfs_visit(int start, int limit, const int32_t *off, const int32_t *i
     }
 }
 
-int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
+static int dfs_sequences_impl(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
                       int32_t *seq_off, int32_t *seq, int64_t cap) {
     if (!nbr_off || !seq_off || C < 1 || (cap > 0 && !seq)) return VDS_EINVAL;
     if (!nbr_idx && nbr_off[C] > 0) return VDS_EINVAL;
@@ -259,7 +276,7 @@ int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C,
     return total <= cap ? VDS_OK : VDS_ECAPACITY;
 }
 
-int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t *node2cluster, int32_t C,
+static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const int32_t *node2cluster, int32_t C,
                     const int32_t *nbr_off, const int32_t *nbr_idx, int32_t depth_limit) {
     if (!h || !cost || !node2cluster || !nbr_off || N < 1 || C < 1) return fail(h, VDS_EINVAL, "vds_load_static: bad argument");
     if (h->have_static) return fail(h, VDS_EINVAL, "vds_load_static: static tables already loaded (create a new handle)");
@@ -412,7 +429,7 @@ static int alloc_state(vds_handle *h, int O) {
     return VDS_OK;
 }
 
-int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
+static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
     if (!h || !h->have_static) return fail(h, VDS_EINVAL, "vds_load_orders: call vds_load_static first");
     if (h->have_orders) return fail(h, VDS_EINVAL, "vds_load_orders: orders already loaded (create a new handle)");
     if (O < 1 || !release_min || !pickup || !delivery) return fail(h, VDS_EINVAL, "vds_load_orders: bad argument");
@@ -512,7 +529,7 @@ static int reset_device(vds_handle *h) {
     return VDS_OK;
 }
 
-int vds_reset(vds_handle *h, const int32_t *veh_init_node) {
+static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
     if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_reset: load static tables and orders first");
     if (!veh_init_node && h->S.V > 0) return fail(h, VDS_EINVAL, "vds_reset: null veh_init_node");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -535,7 +552,7 @@ int vds_reset_again(vds_handle *h) {
     return reset_device(h);   // asynchronous
 }
 
-int vds_profile_enable(vds_handle *h, int32_t on) {
+static int profile_enable_impl(vds_handle *h, int32_t on) {
     if (!h) return VDS_EINVAL;
     h->profiling = on != 0;
     h->ev_used = 0;
@@ -551,7 +568,7 @@ static hipEvent_t next_event(vds_handle *h) {
     return h->ev_pool[h->ev_used++];
 }
 
-int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
+static int profile_read_impl(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
     if (!h || !ms || !n) return VDS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -562,7 +579,7 @@ int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
     return VDS_OK;
 }
 
-int vds_step(vds_handle *h) {
+static int step_impl(vds_handle *h) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_step: call vds_reset first");
     if (h->last_stepped == h->t) return fail(h, VDS_EINVAL, "vds_step: tick %d already stepped; call vds_advance", h->t);
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -635,7 +652,7 @@ int vds_clock(const vds_handle *h, int32_t *step, int32_t *now_min) {
     return VDS_OK;
 }
 
-int vds_apply_dispatch(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
+static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
                        const int32_t *idle_pos, const int32_t *target_node) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_apply_dispatch: call vds_reset first");
     if (h->last_stepped != h->t) return fail(h, VDS_EINVAL, "vds_apply_dispatch: must follow vds_step of the current tick (the hook runs after Match, :1083)");
@@ -692,7 +709,7 @@ int vds_obs_device(vds_handle *h, void **dev_ptr) {
     return VDS_OK;
 }
 
-int vds_read_obs(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {
+static int read_obs_impl(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {
     int rc = vds_obs_device(h, nullptr);
     if (rc) return rc;
     const size_t RC = (size_t)h->S.R * h->S.C;
@@ -717,7 +734,7 @@ static void finish_counters(const vds_handle *h, const long long *raw, int64_t *
     out[VDS_CNT_EVALS] = raw[CNT_EVALS];
 }
 
-int vds_read_counters(vds_handle *h, int64_t *out) {
+static int read_counters_impl(vds_handle *h, int64_t *out) {
     if (!h || !h->have_reset || !out) return fail(h, VDS_EINVAL, "vds_read_counters: bad argument / call order");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     launch_reduce_counters(h->S, h->D, h->d_cnt_per, h->d_cnt_tot, h->stream);
@@ -730,7 +747,7 @@ int vds_read_counters(vds_handle *h, int64_t *out) {
     return VDS_OK;
 }
 
-int vds_reduce_counters(vds_handle *h, int64_t *out, void **dev_ptr) {
+static int reduce_counters_impl(vds_handle *h, int64_t *out, void **dev_ptr) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_reduce_counters: call vds_reset first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     launch_reduce_counters(h->S, h->D, h->d_cnt_per, h->d_cnt_tot, h->stream);
@@ -761,7 +778,7 @@ int vds_reduce_counters_into(vds_handle *h, void *dev_out) {
     return VDS_OK;
 }
 
-int vds_read_work(vds_handle *h, int64_t *out) {
+static int read_work_impl(vds_handle *h, int64_t *out) {
     if (!h || !h->have_reset || !out) return fail(h, VDS_EINVAL, "vds_read_work: bad argument / call order");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     launch_reduce_counters(h->S, h->D, h->d_cnt_per, h->d_cnt_tot, h->stream);
@@ -775,7 +792,7 @@ int vds_read_work(vds_handle *h, int64_t *out) {
     return VDS_OK;
 }
 
-int vds_read_orders(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int32_t *vehicle, int32_t *wait) {
+static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int32_t *vehicle, int32_t *wait) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_read_orders: call vds_reset first");
     const Static &S = h->S;
     if (r0 < 0 || nr < 0 || r0 + nr > S.R) return fail(h, VDS_EINVAL, "vds_read_orders: replica range out of bounds");
@@ -807,7 +824,7 @@ int vds_read_orders(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int3
     return VDS_OK;
 }
 
-int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *idle_veh, int32_t *idle_node,
+static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *idle_veh, int32_t *idle_node,
                    int32_t *arr_off, int32_t *arr_veh, int32_t *arr_min, int32_t *arr_order, int32_t *arr_node) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_read_lists: call vds_reset first");
     const Static &S = h->S;
@@ -914,6 +931,71 @@ int vds_selftest_dpp(vds_handle *h, const int32_t *in, int32_t *out_wave, int32_
     HIPCHK(h, hipMemcpy(out_rowscan, d3, n * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(din); (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(d3);
     return VDS_OK;
+}
+
+// ---- exception-safe entry points
+int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
+                      int32_t *seq_off, int32_t *seq, int64_t cap) {
+    return guarded(nullptr, "vds_dfs_sequences", [&] { return dfs_sequences_impl(nbr_off, nbr_idx, C, depth_limit, seq_off, seq, cap); });
+}
+
+int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t *node2cluster, int32_t C,
+                    const int32_t *nbr_off, const int32_t *nbr_idx, int32_t depth_limit) {
+    return guarded(h, "vds_load_static", [&] { return load_static_impl(h, cost, N, node2cluster, C, nbr_off, nbr_idx, depth_limit); });
+}
+
+int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
+    return guarded(h, "vds_load_orders", [&] { return load_orders_impl(h, release_min, pickup, delivery, O); });
+}
+
+int vds_reset(vds_handle *h, const int32_t *veh_init_node) {
+    return guarded(h, "vds_reset", [&] { return reset_impl(h, veh_init_node); });
+}
+
+int vds_step(vds_handle *h) {
+    return guarded(h, "vds_step", [&] { return step_impl(h); });
+}
+
+int vds_apply_dispatch(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
+                       const int32_t *idle_pos, const int32_t *target_node) {
+    return guarded(h, "vds_apply_dispatch", [&] { return apply_dispatch_impl(h, n, replica, from_cluster, idle_pos, target_node); });
+}
+
+int vds_read_obs(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {
+    return guarded(h, "vds_read_obs", [&] { return read_obs_impl(h, idle_pre, idle_now, supply, cl_orders, inflight); });
+}
+
+int vds_read_counters(vds_handle *h, int64_t *out) {
+    return guarded(h, "vds_read_counters", [&] { return read_counters_impl(h, out); });
+}
+
+int vds_reduce_counters(vds_handle *h, int64_t *out, void **dev_ptr) {
+    return guarded(h, "vds_reduce_counters", [&] { return reduce_counters_impl(h, out, dev_ptr); });
+}
+
+int vds_read_work(vds_handle *h, int64_t *out) {
+    return guarded(h, "vds_read_work", [&] { return read_work_impl(h, out); });
+}
+
+int vds_read_orders(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int32_t *vehicle, int32_t *wait) {
+    return guarded(h, "vds_read_orders", [&] { return read_orders_impl(h, r0, nr, status, vehicle, wait); });
+}
+
+int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *idle_veh, int32_t *idle_node,
+                   int32_t *arr_off, int32_t *arr_veh, int32_t *arr_min, int32_t *arr_order, int32_t *arr_node) {
+    return guarded(h, "vds_read_lists", [&] { return read_lists_impl(h, replica, idle_off, idle_veh, idle_node, arr_off, arr_veh, arr_min, arr_order, arr_node); });
+}
+
+int vds_profile_enable(vds_handle *h, int32_t on) {
+    return guarded(h, "vds_profile_enable", [&] { return profile_enable_impl(h, on); });
+}
+
+int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
+    return guarded(h, "vds_profile_read", [&] { return profile_read_impl(h, ms, cap, n); });
+}
+
+int vds_create(const vds_config *cfg, vds_handle **out) {
+    return guarded(nullptr, "vds_create", [&] { return create_impl(cfg, out); });
 }
 
 }  // extern "C"
