@@ -68,7 +68,8 @@ typedef struct vds_config {
     int32_t ring_ticks;               /* arrival-ring horizon in ticks (power of two); trips that end later go
                                          through the slower "far" tables; 0 = 32 */
     int32_t far_cap;                  /* slots per (replica, cluster) far table; 0 = auto */
-    int32_t force_generic;            /* 1: never use the row-mapped fast kernel (testing) */
+    int32_t force_generic;            /* testing: 1 = generic one-wavefront-per-bucket / serial neighbour-search kernels,
+                                         2 = first-generation neighbour-search kernel (k_tick_replica); 0 = fastest */
 } vds_config;
 
 /* Fill cfg with defaults (tick 10 min, threshold 6e11, caps auto). */

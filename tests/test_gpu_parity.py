@@ -120,6 +120,7 @@ MODES = {
     "generic": {"force_generic": True},      # one wavefront per bucket
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
+    "dfs_v1": {"force_generic": 2},          # neighbour search by the first-generation kernel (lists edited in place)
 }
 
 

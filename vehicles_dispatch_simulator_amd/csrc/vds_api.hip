@@ -19,6 +19,7 @@ void launch_tick_work(const Static &, const State &, int, hipStream_t);
 void launch_update_only(const Static &, const State &, int, hipStream_t);
 void launch_match_dfs(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica(const Static &, const State &, int, hipStream_t);
+void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, hipStream_t);
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
@@ -40,6 +41,8 @@ struct vds_handle {
     std::string err;
     bool have_static = false, have_orders = false, have_reset = false;
     bool dfs_mode = false;
+    bool dfs2_ok = false;   // k_tick_replica2 preconditions hold (see vds_kernels.hip)
+    int cost_min = 0, cost_max = 0;
     int depth_limit = 0;
     int t = 0;              // self.step
     int last_stepped = -1;  // tick of the last vds_step
@@ -384,7 +387,8 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         int cmin = 0x7FFFFFFF, cmax = -0x7FFFFFFF - 1;
         for (size_t i = 0; i < (size_t)N * N; ++i) { cmin = std::min(cmin, cost[i]); cmax = std::max(cmax, cost[i]); }
         S.fast_ok = (cmin >= 0 && cmax < (1 << 23) && (long long)cmax <= S.reject_threshold) ? 1 : 0;
-        if (h->cfg.force_generic) S.fast_ok = 0;
+        if (h->cfg.force_generic == 1) S.fast_ok = 0;
+        h->cost_min = cmin; h->cost_max = cmax;
     }
     // LDS budget for the cluster cost block
     const int lds_budget_ints = (64 * 1024) / 4;
@@ -505,6 +509,13 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
     if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(n_proc, 1)))) return rc;
     if ((rc = alloc_state(h, O))) return rc;
+    {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
+        const Static &Z = h->S;
+        const size_t lds2 = ((size_t)11 * Z.C + 1 + Z.max_tick_orders + (Z.V >> 5) + 2) * sizeof(int) + ((size_t)Z.V + 2) / 2 * 4;
+        h->dfs2_ok = h->dfs_mode && O <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 16) &&
+                     Z.V <= 20480 && Z.N <= 65535 && Z.C <= 3072 && Z.idle_cap <= 65535 && Z.max_tick_orders < 32768 &&
+                     lds2 <= 64 * 1024;
+    }
     h->have_orders = true;
     return VDS_OK;
 }
@@ -595,14 +606,16 @@ static int step_impl(vds_handle *h) {
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
         // the fast kernel only defers buckets whose cluster cost block does not fit LDS
         if (!h->S.fast_ok || h->S.max_nc * h->S.max_nc > h->lds_ints) launch_tick_work(h->S, h->D, h->t, h->stream);
-    } else if (h->S.C <= 3072 && !h->cfg.force_generic) {   // 5 ints of LDS per cluster
+    } else if (h->S.C <= 3072 && h->cfg.force_generic != 1) {   // 11 ints of LDS per cluster
         hipEvent_t a = nullptr, b = nullptr;
         if (h->profiling) {
             a = next_event(h); b = next_event(h);
             if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
             HIPCHK(h, hipEventRecord(a, h->stream));
         }
-        launch_tick_replica(h->S, h->D, h->t, h->stream);      // neighbour search: lower-bound rounds, one workgroup per replica
+        // neighbour search: lower-bound rounds, one workgroup per replica
+        if (h->dfs2_ok && h->cfg.force_generic == 0) launch_tick_replica2(h->S, h->D, h->t, h->stream);
+        else launch_tick_replica(h->S, h->D, h->t, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
     } else {
         launch_update_only(h->S, h->D, h->t, h->stream);       // serial reference form

@@ -1250,6 +1250,307 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
 }
 
 // ---------------------------------------------------------------------------------------
+// k_tick_replica2: neighbour-search mode, second generation (same lower-bound rounds as k_tick_replica, same
+// results).  What changed is how a round is executed:
+//   * idle lists are NOT edited during the tick.  A replica's lists stay in HBM at their positions after Update
+//     ("original positions"); LDS holds a u16 node mirror of them and one ALIVE BIT per entry.  Taking a vehicle
+//     clears its bit; list order == original order, so "first strict minimum" is still the lowest position.
+//   * own-cluster matching is THREAD-per-bucket: in every round thread c walks bucket c's pending orders older
+//     than LB by itself (candidates 8 at a time: LDS mirror -> 8 cost gathers in flight -> compare), so all
+//     buckets with work advance concurrently instead of one bucket per wavefront at a time, and a visit costs
+//     one L2 round trip per 8 candidates instead of three dependent HBM round trips.
+//   * results are written in a preliminary form {victim cluster << 16 | original position, wait}; after the
+//     last round one thread per order resolves the vehicle id from the untouched HBM list, posts the arrival
+//     (:954-960) and accumulates the counters, and one wavefront per bucket compacts the HBM list once (:963).
+// Preconditions (Static.dfs2_ok): order ids < 2^20, clusters <= 2047 nodes, 0 <= cost < 2^16, V <= 20480,
+// N <= 65535, idle_cap <= 65535, < 32768 orders per tick.
+#define ID_BITS 20
+#define ID_MASK ((1 << ID_BITS) - 1)
+
+__device__ __forceinline__ unsigned alive8(const unsigned *alive, int g) {   // alive bits g .. g+7
+    const int w = g >> 5, sh = g & 31;
+    const unsigned long long two = ((unsigned long long)alive[w + 1] << 32) | alive[w];
+    return (unsigned)(two >> sh) & 0xFFu;
+}
+
+__global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State D, int t) {
+    extern __shared__ int lds_dyn[];
+    const int C = S.C;
+    int *m_l = lds_dyn;                 // [C] idle vehicles still alive
+    int *qcur_l = lds_dyn + C;          // [C] sorted position of the bucket's next pending order
+    int *qend_l = lds_dyn + 2 * C;      // [C]
+    int *dry_l = lds_dyn + 3 * C;       // [C] id of the first order that can find the cluster dry
+    int *moff_l = lds_dyn + 4 * C;      // [C+1] start of the cluster's segment in mirror / alive bits
+    int *cnt_l = lds_dyn + 5 * C + 1;   // [C][LCNT]
+    int *ids_l = cnt_l + LCNT * C;      // [max_tick_orders] id | pickup_local << ID_BITS, by sorted position
+    unsigned *alive = reinterpret_cast<unsigned *>(ids_l + S.max_tick_orders);        // [V/32 + 2]
+    unsigned short *mirror = reinterpret_cast<unsigned short *>(alive + (S.V >> 5) + 2);   // [V]
+    __shared__ int s_lb, s_lbc;
+    __shared__ unsigned long long s_cand[REPL_WAVES];
+    const int r = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int p = t & 1;
+    const int now = S.now0 + t * S.tick_minutes;
+    const int tq0 = S.bkt_off[(size_t)t * C], tq1 = S.bkt_off[(size_t)(t + 1) * C];
+#ifdef VDS_PROF
+    const bool prof = (g_ablate & 128) != 0;
+    unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int pwave = (int)((blockIdx.x * REPL_WAVES + wave) & (PROF_WAVES - 1));
+#endif
+    for (int i = threadIdx.x; i < tq1 - tq0; i += REPL_THREADS) {
+        const int4 rec = S.so_rec[tq0 + i];
+        ids_l[i] = rec.x | ((rec.y & 0xFFFF) << ID_BITS);
+    }
+    for (int i = threadIdx.x; i < LCNT * C; i += REPL_THREADS) cnt_l[i] = 0;
+    for (int i = threadIdx.x; i < (S.V >> 5) + 2; i += REPL_THREADS) alive[i] = 0xFFFFFFFFu;
+    __syncthreads();
+#define ORDER_ID2(q, qend) ((q) < (qend) ? (ids_l[(q) - tq0] & ID_MASK) : IMAX)
+    // ---- UpdateFunction, bucket-parallel (one wavefront per bucket)
+    for (int c = wave; c < C; c += REPL_WAVES) {
+        const size_t b = (size_t)c * S.R + r;
+        int *hdr = D.hdr + b * HDR_WORDS;
+        int hv = lane < HDR_WORDS ? hdr[lane] : 0;
+        int m = rdlane(hv, HDR_IDLE);
+        const int f = rdlane(hv, HDR_FL), qin = rdlane(hv, HDR_INBOX0 + p);
+        int newf = f;
+        if (f + qin > 0) {
+            update_far(S, D, c, r, t, now, f, qin, D.fl + b * S.fl_cap, D.inbox + ((size_t)p * S.C * S.R + b) * S.in_cap, newf);
+            wave_fence();
+        }
+        const int A = drain_ring(S, D, b, t, m, D.idle + b * S.idle_cap);
+        const int q0 = S.bkt_off[(size_t)t * C + c], q1 = S.bkt_off[(size_t)t * C + c + 1];
+        if (lane == 0) {
+            hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
+            m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
+        }
+        if (A > 0 && lane == 0) cnt_l[c * LCNT + CNT_ARRIVALS] = A;
+    }
+    __syncthreads();
+    PROF_STAMP(0);
+    for (int c = threadIdx.x; c < C; c += REPL_THREADS)
+        dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qcur_l[c] + m_l[c], qend_l[c]) : IMAX;
+    if (wave == 0) {            // exclusive prefix of the list lengths
+        int run = 0;
+        for (int base = 0; base < C; base += WAVE) {
+            const int c = base + lane;
+            const int v = c < C ? m_l[c] : 0;
+            int inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            if (c < C) moff_l[c] = run + inc - v;
+            run += rdlane(inc, WAVE - 1);
+        }
+        if (lane == 0) moff_l[C] = run;
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += REPL_WAVES) {
+        const uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
+        const int m = m_l[c], mo = moff_l[c];
+        for (int i = lane; i < m; i += WAVE) mirror[mo + i] = (unsigned short)idle[i].y;
+    }
+    __syncthreads();
+    PROF_STAMP(1);
+    int2 *out_r = D.out + (size_t)r * S.Oq;
+
+    // own-cluster matches of bucket c by ONE thread: pending orders with id < limit (:924-965)
+    auto own_match = [&](int c, int limit) {
+        int qc = qcur_l[c];
+        const int qe = qend_l[c];
+        if (qc >= qe) return;
+        int idw = ids_l[qc - tq0];
+        if ((idw & ID_MASK) >= limit) return;
+        const int4 cd = S.cdesc[c];
+        const int nc = cd.x;
+        const int *blk = S.blk + cd.y;
+        const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
+        int m = m_l[c];
+        int evals = 0;
+        do {
+            evals += m;
+            int best = IMAX, bpos = -1;
+            if (m > 0) {
+                const int *row = blk + (size_t)(idw >> ID_BITS) * nc;
+                for (int i0 = 0; i0 < m0; i0 += 8) {
+                    unsigned bits = alive8(alive, mo + i0);
+                    if (m0 - i0 < 8) bits &= (1u << (m0 - i0)) - 1u;
+                    if (bits == 0) continue;
+                    int cst[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int lc = (int)mirror[mo + min(i0 + u, m0 - 1)];
+                        cst[u] = row[lc];                     // entries already taken are fetched too, then ignored
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (((bits >> u) & 1u) && cst[u] < best) { best = cst[u]; bpos = i0 + u; }
+                }
+            }
+            int2 res = make_int2(-1, -1);
+            if (bpos >= 0 && (long long)best <= S.reject_threshold) {      // :943 (quirk Q3)
+                atomicAnd(&alive[(mo + bpos) >> 5], ~(1u << ((mo + bpos) & 31)));
+                m--;
+                res = make_int2((int)(((unsigned)c << 16) | (unsigned)bpos), best);
+            }
+            out_r[qc] = res;
+            qc++;
+            idw = qc < qe ? ids_l[qc - tq0] : IMAX;
+        } while (qc < qe && (idw & ID_MASK) < limit);
+        m_l[c] = m; qcur_l[c] = qc;
+        dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qc + m, qe) : IMAX;
+        if (evals) cnt_l[c * LCNT + CNT_EVALS] += evals;
+    };
+
+    // ---- MatchFunction in lower-bound rounds
+    for (;;) {
+        if (threadIdx.x == 0) { s_lb = IMAX; s_lbc = -1; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += REPL_THREADS)
+            if (dry_l[c] != IMAX) atomicMin(&s_lb, dry_l[c]);
+        __syncthreads();
+        const int LB = s_lb;
+        PROF_STAMP(2);
+        for (int c = threadIdx.x; c < C; c += REPL_THREADS) {
+            if (LB != IMAX && dry_l[c] == LB) s_lbc = c;       // order ids are unique: exactly one bucket
+            own_match(c, LB);
+        }
+        __syncthreads();
+        PROF_STAMP(3);
+        if (LB == IMAX) break;
+        const int pc = s_lbc;
+        if (m_l[pc] > 0) {
+            // not dry after all (an older order of this bucket was rejected by the pickup window, :943, without
+            // taking a vehicle): order LB is an ordinary own-cluster match
+            if (threadIdx.x == 0) own_match(pc, LB + 1);
+            __syncthreads();
+            continue;
+        }
+        const int q = qcur_l[pc];
+        const int *crow = S.cost + (size_t)S.so_pnode[q] * S.N;
+        // candidate clusters of this wavefront, four at a time; one 64-bit key per lane
+        //   (cost, visit position, list position) -> lexicographic minimum == first strict minimum in visit order
+        unsigned long long best = ~0ull;
+        int ev = 0;
+        const int s0 = S.dfs_off[pc], s1 = S.dfs_off[pc + 1];
+        for (int si = s0 + wave; si < s1; si += 4 * REPL_WAVES) {
+            int cc[4], mo4[4], m04[4];
+            int mmax = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sx = si + u * REPL_WAVES;
+                cc[u] = sx < s1 ? S.dfs_seq[sx] : 0;
+                const int live = sx < s1 ? m_l[cc[u]] : 0;
+                mo4[u] = moff_l[cc[u]];
+                m04[u] = live > 0 ? moff_l[cc[u] + 1] - mo4[u] : 0;
+                mmax = max(mmax, m04[u]);
+                ev += live;
+            }
+            if (mmax == 0) continue;
+            for (int base = 0; base < mmax; base += WAVE) {
+                const int i = base + lane;
+                int cst[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = mo4[u] + i;
+                    ok[u] = i < m04[u] && ((alive[g >> 5] >> (g & 31)) & 1u);
+                    cst[u] = 0;
+                    if (ok[u]) cst[u] = crow[S.cl_off[cc[u]] + (int)mirror[g]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long key = ((unsigned long long)(unsigned)cst[u] << 32) |
+                                                   ((unsigned)(si + u * REPL_WAVES - s0) << 16) | (unsigned)i;
+                    if (ok[u] && key < best) best = key;
+                }
+            }
+        }
+        {   // wave minimum of the 64-bit keys
+            unsigned hi = (unsigned)(best >> 32), lo = (unsigned)best;
+            for (int o = 32; o; o >>= 1) {
+                const unsigned h2 = (unsigned)__shfl_xor((int)hi, o, WAVE), l2 = (unsigned)__shfl_xor((int)lo, o, WAVE);
+                if (h2 < hi || (h2 == hi && l2 < lo)) { hi = h2; lo = l2; }
+            }
+            if (lane == 0) s_cand[wave] = ((unsigned long long)hi << 32) | lo;
+        }
+        PROF_STAMP(4);
+        if (lane == 0 && ev) atomicAdd(&cnt_l[pc * LCNT + CNT_EVALS], ev);    // :986-991 runs for every visited cluster
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long wk = s_cand[0];
+            for (int w = 1; w < REPL_WAVES; ++w) wk = s_cand[w] < wk ? s_cand[w] : wk;
+            int2 res = make_int2(-1, -1);
+            const int wc = (int)(wk >> 32);
+            if (wk != ~0ull && (long long)wc <= S.reject_threshold) {
+                const int wcl = S.dfs_seq[s0 + (int)((wk >> 16) & 0xFFFF)], wpos = (int)(wk & 0xFFFF);
+                const int g = moff_l[wcl] + wpos;
+                alive[g >> 5] &= ~(1u << (g & 31));
+                const int mw = m_l[wcl] - 1;
+                m_l[wcl] = mw;
+                if (S.dfs_off[wcl + 1] > S.dfs_off[wcl]) dry_l[wcl] = ORDER_ID2(qcur_l[wcl] + mw, qend_l[wcl]);
+                res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
+            }
+            out_r[q] = res;
+            qcur_l[pc] = q + 1;
+            dry_l[pc] = ORDER_ID2(q + 1, qend_l[pc]);     // m == 0: the very next order is dry again
+        }
+        __syncthreads();
+        PROF_STAMP(5);
+#ifdef VDS_PROF
+        if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+#endif
+    }
+    // ---- resolve the preliminary results: vehicle ids, arrivals (:954-960), counters
+    __threadfence_block();
+    for (int q = tq0 + (int)threadIdx.x; q < tq1; q += REPL_THREADS) {
+        const int4 rec = S.so_rec[q];
+        const int2 pr = out_r[q];
+        int *cl = cnt_l + (int)((unsigned)rec.z >> 16) * LCNT;
+        atomicAdd(&cl[CNT_ORDERS], 1);
+        if (pr.x == -1) {
+            atomicAdd(&cl[CNT_REJECTS], 1);
+        } else {
+            const int vc = (int)((unsigned)pr.x >> 16), vpos = pr.x & 0xFFFF;
+            const int veh = (int)D.idle[((size_t)vc * S.R + r) * S.idle_cap + vpos].x;
+            out_r[q] = make_int2(veh, pr.y);
+            post_arrival(S, D, rec.z & 0xFFFF, r, t, now, veh, rec.x, now + pr.y + rec.w, 0, (int)((unsigned)rec.y >> 16));
+            atomicAdd(&cl[CNT_WAIT], pr.y);
+            atomicAdd(&cl[CNT_VALUE], rec.w);
+        }
+    }
+    __syncthreads();
+    // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction by the alive bits
+    for (int c = wave; c < C; c += REPL_WAVES) {
+        const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
+        if (m_l[c] == m0) continue;
+        uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
+        int kept = 0;
+        for (int base = 0; base < m0; base += WAVE) {
+            const int i = base + lane;
+            uint2 e = make_uint2(0u, 0u);
+            bool keep = false;
+            if (i < m0) {
+                const int g = mo + i;
+                keep = (alive[g >> 5] >> (g & 31)) & 1u;
+                if (keep) e = idle[i];
+            }
+            const unsigned long long kb = ballot(keep);
+            wave_fence();        // this chunk's sources are read before any of its (lower or equal) targets is written
+            if (keep) idle[kept + popc64(kb & lanemask_lt())] = e;
+            kept += popc64(kb);
+        }
+    }
+    PROF_STAMP(7);
+    // ---- flush: idle counts and this tick's counter deltas
+    for (int c = threadIdx.x; c < C; c += REPL_THREADS) {
+        const size_t b = (size_t)c * S.R + r;
+        D.hdr[b * HDR_WORDS + HDR_IDLE] = m_l[c];
+        long long *cnt = D.cnt + b * CNT_WORDS;
+#pragma unroll
+        for (int w = 0; w < LCNT; ++w) { const int d = cnt_l[c * LCNT + w]; if (d) cnt[w] += d; }
+    }
+#undef ORDER_ID2
+}
+
+// ---------------------------------------------------------------------------------------
 // k_dispatch: one wavefront per (replica, from_cluster) group of actions (host-sorted).
 // grp_off[g]..grp_off[g+1] index the group's actions; positions refer to the idle list as it
 // stands at call time.
@@ -1384,6 +1685,11 @@ void launch_tick_replica(const Static &S, const State &D, int t, hipStream_t st)
     const int use_mirror = (S.N <= 65535 && S.V <= 20480) ? 1 : 0;
     const size_t lds = ((size_t)(5 + LCNT) * S.C + S.max_tick_orders) * sizeof(int) + (use_mirror ? ((size_t)S.V + 2) / 2 * 4 : 0);
     hipLaunchKernelGGL(k_tick_replica, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t, use_mirror);
+}
+
+void launch_tick_replica2(const Static &S, const State &D, int t, hipStream_t st) {
+    const size_t lds = ((size_t)(5 + LCNT) * S.C + 1 + S.max_tick_orders + (S.V >> 5) + 2) * sizeof(int) + ((size_t)S.V + 2) / 2 * 4;
+    hipLaunchKernelGGL(k_tick_replica2, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {

@@ -50,7 +50,7 @@ class BatchedDispatchEnv:
         cfg.tick_minutes, cfg.neighbor_can_server = int(tick_minutes), int(bool(neighbor_can_server))
         cfg.pickup_reject_threshold = int(reject_threshold)
         cfg.idle_cap, cfg.ring_cap, cfg.ring_ticks, cfg.far_cap = int(idle_cap), int(ring_cap), int(ring_ticks), int(far_cap)
-        cfg.force_generic = int(bool(force_generic))
+        cfg.force_generic = int(force_generic)      # 0 fastest kernels, 1 generic / serial forms, 2 first-generation neighbour-search kernel
         rc = self._lib.vds_create(C.byref(cfg), C.byref(self._h))
         if rc:
             msg = self._lib.vds_last_error(None).decode()
