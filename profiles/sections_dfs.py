@@ -14,9 +14,12 @@ env._lib.vds_debug_ablate(env._h, 128)
 env.profile(True); env.run(T); ms = env.profile_read(T + 8); env.profile(False)
 env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
 env._lib.vds_debug_ablate(env._h, 0)
-names = ["0 update (drain + hdr)", "1 node mirror build", "2 LB reduction", "3 bucket-parallel own-cluster match", "4 DFS candidate scan", "5 DFS winner + removal + post"]
+names = ["0 update (drain + hdr)", "1 node mirror build", "2 LB reduction", "3 bucket-parallel own-cluster match", "4 DFS candidate scan", "5 DFS winner (+ removal + post in v1)",
+         None, "7 resolve results + compaction + flush (v2)"]
 nw = R * 4
-tot = float(buf[:6].sum())
+tot = float(buf[:6].sum() + buf[7])
 print("instrumented: %.2f ms/launch; DFS rounds per replica-tick: %.1f" % (ms.mean(), buf[6] / nw / T))
 for i, n in enumerate(names):
+    if n is None:
+        continue
     print("%-40s %9.0f cycles/wave/tick  %5.1f%%" % (n, buf[i] / nw / T, 100.0 * buf[i] / tot))

@@ -511,9 +511,10 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
     if ((rc = alloc_state(h, O))) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
         const Static &Z = h->S;
-        const size_t lds2 = ((size_t)11 * Z.C + 1 + Z.max_tick_orders + (Z.V >> 5) + 2) * sizeof(int) + ((size_t)Z.V + 2) / 2 * 4;
-        h->dfs2_ok = h->dfs_mode && O <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 16) &&
-                     Z.V <= 20480 && Z.N <= 65535 && Z.C <= 3072 && Z.idle_cap <= 65535 && Z.max_tick_orders < 32768 &&
+        const int ids2 = std::max(Z.max_tick_orders, 4 * Z.C);
+        const size_t lds2 = ((size_t)9 * Z.C + 1 + ids2 + ((size_t)Z.V + 2) / 2) * sizeof(int) + 2048;   // + static shared
+        h->dfs2_ok = h->dfs_mode && O <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 15) &&
+                     Z.V <= 20480 && Z.N <= 65534 && Z.C <= 3072 && Z.idle_cap <= 32767 && Z.max_tick_orders < 32768 &&
                      lds2 <= 64 * 1024;
     }
     h->have_orders = true;

@@ -44,7 +44,7 @@ void read_prof(unsigned long long *out, hipStream_t st) {
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(host));
     for (int i = 0; i < 16; ++i) out[i] = 0;
     for (size_t w = 0; w < PROF_WAVES; ++w) {
-        for (int i = 0; i < 7; ++i) out[i] += host[w * 8 + i];
+        for (int i = 0; i < 8; ++i) out[i] += host[w * 8 + i];
         if (host[w * 8 + 6]) out[15]++;
     }
     memset(host, 0, sizeof(host));
@@ -1253,26 +1253,40 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
 // k_tick_replica2: neighbour-search mode, second generation (same lower-bound rounds as k_tick_replica, same
 // results).  What changed is how a round is executed:
 //   * idle lists are NOT edited during the tick.  A replica's lists stay in HBM at their positions after Update
-//     ("original positions"); LDS holds a u16 node mirror of them and one ALIVE BIT per entry.  Taking a vehicle
-//     clears its bit; list order == original order, so "first strict minimum" is still the lowest position.
-//   * own-cluster matching is THREAD-per-bucket: in every round thread c walks bucket c's pending orders older
-//     than LB by itself (candidates 8 at a time: LDS mirror -> 8 cost gathers in flight -> compare), so all
-//     buckets with work advance concurrently instead of one bucket per wavefront at a time, and a visit costs
-//     one L2 round trip per 8 candidates instead of three dependent HBM round trips.
+//     ("original positions"); LDS holds a u16 mirror of them: the cost-matrix column of every entry's node, or
+//     DEAD once the vehicle has been taken.  List order == original order, so "first strict minimum" is still
+//     the lowest position.
+//   * own-cluster matching runs on 8-LANE GROUPS, one bucket per group: all candidates of an order are gathered
+//     in one round trip (<= 8 per lane in flight), three DPP steps give the group minimum of (cost << 16 | pos).
+//     The 32 groups of a workgroup advance 32 buckets concurrently instead of one bucket per wavefront at a time.
+//   * the neighbour search reads its cluster list once per wavefront (lane j = j-th candidate cluster), prefetched
+//     together with the dry order's pickup node BEFORE the own-cluster pass; candidates carry one 64-bit key
+//     (cost, visit position | list position, cluster), reduced with two DPP wave minima.
 //   * results are written in a preliminary form {victim cluster << 16 | original position, wait}; after the
 //     last round one thread per order resolves the vehicle id from the untouched HBM list, posts the arrival
 //     (:954-960) and accumulates the counters, and one wavefront per bucket compacts the HBM list once (:963).
-// Preconditions (Static.dfs2_ok): order ids < 2^20, clusters <= 2047 nodes, 0 <= cost < 2^16, V <= 20480,
-// N <= 65535, idle_cap <= 65535, < 32768 orders per tick.
+// Preconditions (Static / vds_api dfs2_ok): order ids < 2^20, clusters <= 2047 nodes, 0 <= cost < 2^15,
+// V <= 20480, N <= 65535, C <= 3072, idle_cap <= 32767, < 32768 orders per tick.
 #define ID_BITS 20
 #define ID_MASK ((1 << ID_BITS) - 1)
+#define GRP 8                               // lanes per own-cluster group
+#define GRPS_WAVE (WAVE / GRP)
+#define OB 4                                // orders of one bucket whose cost gathers are in flight together
+#define RCNT 4                              // counters accumulated by the resolve pass: orders, rejects, wait, value
 
-__device__ __forceinline__ unsigned alive8(const unsigned *alive, int g) {   // alive bits g .. g+7
-    const int w = g >> 5, sh = g & 31;
-    const unsigned long long two = ((unsigned long long)alive[w + 1] << 32) | alive[w];
-    return (unsigned)(two >> sh) & 0xFFu;
+__device__ __forceinline__ int grp_min_i32(int v) {     // minimum over each aligned group of 8 lanes
+    v = min(v, dpp_mov<0xB1, 0xF>(v, v));   // quad_perm [1,0,3,2]
+    v = min(v, dpp_mov<0x4E, 0xF>(v, v));   // quad_perm [2,3,0,1]
+    v = min(v, dpp_mov<0x141, 0xF>(v, v));  // row_half_mirror
+    return v;
 }
 
+__host__ __device__ inline size_t replica2_lds_ints(int C, int V, int max_tick_orders) {
+    const int ids = max_tick_orders > RCNT * C ? max_tick_orders : RCNT * C;
+    return (size_t)9 * C + 1 + ids + ((size_t)V + 2) / 2;
+}
+
+#define DEAD 0xFFFF
 __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const int C = S.C;
@@ -1280,13 +1294,18 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
     int *qcur_l = lds_dyn + C;          // [C] sorted position of the bucket's next pending order
     int *qend_l = lds_dyn + 2 * C;      // [C]
     int *dry_l = lds_dyn + 3 * C;       // [C] id of the first order that can find the cluster dry
-    int *moff_l = lds_dyn + 4 * C;      // [C+1] start of the cluster's segment in mirror / alive bits
-    int *cnt_l = lds_dyn + 5 * C + 1;   // [C][LCNT]
-    int *ids_l = cnt_l + LCNT * C;      // [max_tick_orders] id | pickup_local << ID_BITS, by sorted position
-    unsigned *alive = reinterpret_cast<unsigned *>(ids_l + S.max_tick_orders);        // [V/32 + 2]
-    unsigned short *mirror = reinterpret_cast<unsigned short *>(alive + (S.V >> 5) + 2);   // [V]
-    __shared__ int s_lb, s_lbc;
-    __shared__ unsigned long long s_cand[REPL_WAVES];
+    int *moff_l = lds_dyn + 4 * C;      // [C+1] start of the cluster's segment in mirror
+    int *ev_l = lds_dyn + 5 * C + 1;    // [C] match evaluations of this tick
+    int *arr_l = ev_l + C;              // [C] arrivals of this tick
+    int *cdA_l = arr_l + C;             // [C] n_c | first cost column << 11
+    int *cdB_l = cdA_l + C;             // [C] start of the cluster's cost block
+    int *ids_l = cdB_l + C;             // [max(max_tick_orders, RCNT*C)] id | pickup_local << ID_BITS by sorted position;
+                                        //     after the last round: [C][RCNT] counters of the resolve pass
+    const int ids_n = S.max_tick_orders > RCNT * C ? S.max_tick_orders : RCNT * C;
+    unsigned short *mirror = reinterpret_cast<unsigned short *>(ids_l + ids_n);       // [V] cost column of the entry's node,
+                                        //     DEAD (0xFFFF) once the vehicle has been taken
+    __shared__ int s_cand[REPL_WAVES][2];
+    __shared__ int s_wl[REPL_WAVES][WAVE];      // per-wavefront worklist of buckets with pending orders older than LB
     const int r = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int p = t & 1;
@@ -1301,8 +1320,12 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         const int4 rec = S.so_rec[tq0 + i];
         ids_l[i] = rec.x | ((rec.y & 0xFFFF) << ID_BITS);
     }
-    for (int i = threadIdx.x; i < LCNT * C; i += REPL_THREADS) cnt_l[i] = 0;
-    for (int i = threadIdx.x; i < (S.V >> 5) + 2; i += REPL_THREADS) alive[i] = 0xFFFFFFFFu;
+    for (int c = threadIdx.x; c < C; c += REPL_THREADS) {
+        const int4 cd = S.cdesc[c];
+        ev_l[c] = 0; arr_l[c] = 0;
+        cdA_l[c] = cd.x | (S.cl_off[c] << 11);
+        cdB_l[c] = cd.y;
+    }
     __syncthreads();
 #define ORDER_ID2(q, qend) ((q) < (qend) ? (ids_l[(q) - tq0] & ID_MASK) : IMAX)
     // ---- UpdateFunction, bucket-parallel (one wavefront per bucket)
@@ -1322,8 +1345,8 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         if (lane == 0) {
             hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
             m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
+            if (A > 0) arr_l[c] = A;
         }
-        if (A > 0 && lane == 0) cnt_l[c * LCNT + CNT_ARRIVALS] = A;
     }
     __syncthreads();
     PROF_STAMP(0);
@@ -1344,23 +1367,22 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
     __syncthreads();
     for (int c = wave; c < C; c += REPL_WAVES) {
         const uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
-        const int m = m_l[c], mo = moff_l[c];
-        for (int i = lane; i < m; i += WAVE) mirror[mo + i] = (unsigned short)idle[i].y;
+        const int m = m_l[c], mo = moff_l[c], clo = cdA_l[c] >> 11;
+        for (int i = lane; i < m; i += WAVE) mirror[mo + i] = (unsigned short)(clo + (int)idle[i].y);
     }
     __syncthreads();
     PROF_STAMP(1);
     int2 *out_r = D.out + (size_t)r * S.Oq;
 
-    // own-cluster matches of bucket c by ONE thread: pending orders with id < limit (:924-965)
-    auto own_match = [&](int c, int limit) {
+    // own-cluster match of bucket c by ONE thread (rare path: order LB found its cluster not dry after all)
+    auto own_match_thread = [&](int c, int limit) {
         int qc = qcur_l[c];
         const int qe = qend_l[c];
         if (qc >= qe) return;
         int idw = ids_l[qc - tq0];
         if ((idw & ID_MASK) >= limit) return;
-        const int4 cd = S.cdesc[c];
-        const int nc = cd.x;
-        const int *blk = S.blk + cd.y;
+        const int nc = cdA_l[c] & 2047;
+        const int *blk = S.blk + cdB_l[c] - (cdA_l[c] >> 11);
         const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
         int m = m_l[c];
         int evals = 0;
@@ -1369,24 +1391,16 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
             int best = IMAX, bpos = -1;
             if (m > 0) {
                 const int *row = blk + (size_t)(idw >> ID_BITS) * nc;
-                for (int i0 = 0; i0 < m0; i0 += 8) {
-                    unsigned bits = alive8(alive, mo + i0);
-                    if (m0 - i0 < 8) bits &= (1u << (m0 - i0)) - 1u;
-                    if (bits == 0) continue;
-                    int cst[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int lc = (int)mirror[mo + min(i0 + u, m0 - 1)];
-                        cst[u] = row[lc];                     // entries already taken are fetched too, then ignored
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (((bits >> u) & 1u) && cst[u] < best) { best = cst[u]; bpos = i0 + u; }
+                for (int i = 0; i < m0; ++i) {
+                    const int col = mirror[mo + i];
+                    if (col == DEAD) continue;
+                    const int cst = row[col];
+                    if (cst < best) { best = cst; bpos = i; }
                 }
             }
             int2 res = make_int2(-1, -1);
             if (bpos >= 0 && (long long)best <= S.reject_threshold) {      // :943 (quirk Q3)
-                atomicAnd(&alive[(mo + bpos) >> 5], ~(1u << ((mo + bpos) & 31)));
+                mirror[mo + bpos] = DEAD;
                 m--;
                 res = make_int2((int)(((unsigned)c << 16) | (unsigned)bpos), best);
             }
@@ -1396,93 +1410,243 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         } while (qc < qe && (idw & ID_MASK) < limit);
         m_l[c] = m; qcur_l[c] = qc;
         dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qc + m, qe) : IMAX;
-        if (evals) cnt_l[c * LCNT + CNT_EVALS] += evals;
+        if (evals) ev_l[c] += evals;
     };
 
+    const int gl = lane & (GRP - 1);              // lane within its group
+    const int gw = lane / GRP;                    // group within the wavefront
+    const int CW = (C + REPL_WAVES - 1) / REPL_WAVES;     // buckets owned by one wavefront
+    const int cw0 = wave * CW, cw1 = min(C, cw0 + CW);
     // ---- MatchFunction in lower-bound rounds
     for (;;) {
-        if (threadIdx.x == 0) { s_lb = IMAX; s_lbc = -1; }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += REPL_THREADS)
-            if (dry_l[c] != IMAX) atomicMin(&s_lb, dry_l[c]);
-        __syncthreads();
-        const int LB = s_lb;
+        // (A) LB = oldest order that can find its own cluster dry, pc = its cluster (every wavefront computes both)
+        int LB, pc;
+        {
+            int lv = IMAX, lcl = 0;
+            for (int c = lane; c < C; c += WAVE) {
+                const int v = dry_l[c];
+                if (v < lv) { lv = v; lcl = c; }
+            }
+            LB = wave_min_i32(lv);
+            const unsigned long long who = ballot(lv == LB);
+            pc = rdlane(lcl, __ffsll((long long)who) - 1);     // order ids are unique: exactly one bucket
+        }
+        // prefetch for the neighbour search of order LB (position known now: the (m+1)-th pending order of pc)
+        int pnode = 0, cj = 0;
+        int s0 = 0, s1 = 0;
+        if (LB != IMAX) {
+            s0 = S.dfs_off[pc]; s1 = S.dfs_off[pc + 1];
+            pnode = S.so_pnode[qcur_l[pc] + m_l[pc]];
+            const int sx = s0 + wave + lane * REPL_WAVES;      // this wavefront's candidate clusters, lane j = j-th
+            if (sx < s1) cj = S.dfs_seq[sx];
+        }
         PROF_STAMP(2);
-        for (int c = threadIdx.x; c < C; c += REPL_THREADS) {
-            if (LB != IMAX && dry_l[c] == LB) s_lbc = c;       // order ids are unique: exactly one bucket
-            own_match(c, LB);
+        // (B) all pending orders older than LB: ordinary own-cluster matches (:924-965).  Each wavefront lists the
+        //     buckets of its range that have such orders; its eight 8-lane groups take one bucket each.
+        for (int cb = cw0; cb < cw1; cb += WAVE) {
+            const int cmine = cb + lane;
+            bool has = false;
+            if (cmine < cw1) {
+                const int qc = qcur_l[cmine];
+                has = qc < qend_l[cmine] && (ids_l[qc - tq0] & ID_MASK) < LB;
+            }
+            const unsigned long long hm = ballot(has);
+            if (hm == 0) continue;
+            if (has) s_wl[wave][popc64(hm & lanemask_lt())] = cmine;
+            wave_fence();
+            const int nwork = popc64(hm);
+            for (int w0 = 0; w0 < nwork; w0 += GRPS_WAVE) {
+                bool act = w0 + gw < nwork;
+                const int c = act ? s_wl[wave][w0 + gw] : 0;
+                int qc = qcur_l[c];
+                const int qe = qend_l[c];
+                const int cda = cdA_l[c];
+                const int nc = cda & 2047;
+                const int *blk = S.blk + cdB_l[c] - (cda >> 11);    // row[column] with the mirror's matrix columns
+                const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
+                int m = m_l[c], evals = 0;
+                if (m0 <= 8 * GRP) {
+                    // the whole list sits in this group's registers: 8 candidates per lane
+                    int col[8];
+                    unsigned amask = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = u * GRP + gl, g = mo + i;
+                        col[u] = DEAD;
+                        if (act && i < m0) col[u] = mirror[g];
+                        amask |= (col[u] != DEAD ? 1u : 0u) << u;
+                    }
+                    while (ballot(act) != 0) {
+                        // up to OB pending orders of the bucket: all their cost gathers in flight together
+                        int idw[OB], cst[OB][8];
+#pragma unroll
+                        for (int o = 0; o < OB; ++o) {
+                            idw[o] = (act && qc + o < qe) ? ids_l[qc + o - tq0] : IMAX;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) cst[o][u] = 0;
+                        }
+#pragma unroll
+                        for (int o = 0; o < OB; ++o) {
+                            const bool oo = (idw[o] & ID_MASK) < LB && idw[o] != IMAX;
+                            if (ballot(oo) == 0) break;          // usually one pending order: one row of gathers
+                            const int *row = blk + (size_t)(oo ? (idw[o] >> ID_BITS) : 0) * nc;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (oo && ((amask >> u) & 1u)) cst[o][u] = row[col[u]];
+                        }
+#pragma unroll
+                        for (int o = 0; o < OB; ++o) {
+                            const bool oo = act && idw[o] != IMAX && (idw[o] & ID_MASK) < LB;
+                            if (ballot(oo) == 0) break;
+                            int key = IMAX;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (oo && ((amask >> u) & 1u)) key = min(key, (cst[o][u] << 16) | (u * GRP + gl));
+                            key = grp_min_i32(key);
+                            if (oo) {
+                                evals += m;
+                                int2 res = make_int2(-1, -1);
+                                if (key != IMAX && (long long)(key >> 16) <= S.reject_threshold) {     // :943 (quirk Q3)
+                                    const int pos = key & 0xFFFF, g = mo + pos;
+                                    if ((pos & (GRP - 1)) == gl) amask &= ~(1u << (pos / GRP));
+                                    if (gl == 0) mirror[g] = DEAD;
+                                    m--;
+                                    res = make_int2((int)(((unsigned)c << 16) | (unsigned)pos), key >> 16);
+                                }
+                                if (gl == 0) out_r[qc] = res;
+                                qc++;
+                            } else {
+                                act = false;         // orders of a bucket are sorted by id: nothing older than LB is left
+                            }
+                        }
+                        if (act) act = qc < qe && (ids_l[qc - tq0] & ID_MASK) < LB;
+                    }
+                } else {
+                    // long list: one order at a time, 64 candidates per pass
+                    int idw = act ? ids_l[qc - tq0] : IMAX;
+                    while (ballot(act) != 0) {
+                        int key = IMAX;
+                        if (act && m > 0) {
+                            const int *row = blk + (size_t)(idw >> ID_BITS) * nc;
+                            for (int i0 = 0; i0 < m0; i0 += 8 * GRP) {
+                                int cst[8];
+                                bool ok[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int i = i0 + u * GRP + gl;
+                                    const int cl = i < m0 ? (int)mirror[mo + i] : DEAD;
+                                    ok[u] = cl != DEAD;
+                                    cst[u] = 0;
+                                    if (ok[u]) cst[u] = row[cl];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; ++u)
+                                    if (ok[u]) key = min(key, (cst[u] << 16) | (i0 + u * GRP + gl));
+                            }
+                        }
+                        key = grp_min_i32(key);
+                        if (act) {
+                            evals += m;
+                            int2 res = make_int2(-1, -1);
+                            if (key != IMAX && (long long)(key >> 16) <= S.reject_threshold) {     // :943 (quirk Q3)
+                                if (gl == 0) mirror[mo + (key & 0xFFFF)] = DEAD;
+                                m--;
+                                res = make_int2((int)(((unsigned)c << 16) | (unsigned)(key & 0xFFFF)), key >> 16);
+                            }
+                            if (gl == 0) out_r[qc] = res;
+                            qc++;
+                            idw = qc < qe ? ids_l[qc - tq0] : IMAX;
+                            act = qc < qe && (idw & ID_MASK) < LB;
+                        }
+                    }
+                }
+                if (w0 + gw < nwork && gl == 0) {
+                    m_l[c] = m; qcur_l[c] = qc;
+                    dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qc + m, qe) : IMAX;
+                    if (evals) ev_l[c] += evals;
+                }
+            }
+            wave_fence();
         }
         __syncthreads();
         PROF_STAMP(3);
         if (LB == IMAX) break;
-        const int pc = s_lbc;
         if (m_l[pc] > 0) {
             // not dry after all (an older order of this bucket was rejected by the pickup window, :943, without
             // taking a vehicle): order LB is an ordinary own-cluster match
-            if (threadIdx.x == 0) own_match(pc, LB + 1);
+            if (threadIdx.x == 0) own_match_thread(pc, LB + 1);
             __syncthreads();
             continue;
         }
+        // (C) FindServerVehicleFunction for order LB: every wavefront scans its share of the visit sequence.
+        //     key = (cost << 16 | visit position, list position << 16 | cluster): lexicographic minimum == the
+        //     reference's first strict minimum in visit order, then list order
         const int q = qcur_l[pc];
-        const int *crow = S.cost + (size_t)S.so_pnode[q] * S.N;
-        // candidate clusters of this wavefront, four at a time; one 64-bit key per lane
-        //   (cost, visit position, list position) -> lexicographic minimum == first strict minimum in visit order
-        unsigned long long best = ~0ull;
-        int ev = 0;
-        const int s0 = S.dfs_off[pc], s1 = S.dfs_off[pc + 1];
-        for (int si = s0 + wave; si < s1; si += 4 * REPL_WAVES) {
-            int cc[4], mo4[4], m04[4];
-            int mmax = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sx = si + u * REPL_WAVES;
-                cc[u] = sx < s1 ? S.dfs_seq[sx] : 0;
-                const int live = sx < s1 ? m_l[cc[u]] : 0;
-                mo4[u] = moff_l[cc[u]];
-                m04[u] = live > 0 ? moff_l[cc[u] + 1] - mo4[u] : 0;
-                mmax = max(mmax, m04[u]);
-                ev += live;
+        const int *crow = S.cost + (size_t)pnode * S.N;
+        int bhi = IMAX, blo = IMAX;
+        for (int jb = 0; s0 + wave + jb * REPL_WAVES < s1; jb += WAVE) {
+            if (jb > 0) {                               // visit sequences longer than 64 clusters per wavefront
+                const int sx = s0 + wave + (jb + lane) * REPL_WAVES;
+                cj = sx < s1 ? S.dfs_seq[sx] : 0;
             }
-            if (mmax == 0) continue;
-            for (int base = 0; base < mmax; base += WAVE) {
-                const int i = base + lane;
-                int cst[4];
-                bool ok[4];
+            const int nj = min(WAVE, (s1 - s0 - wave - jb * REPL_WAVES + REPL_WAVES - 1) / REPL_WAVES);
+            int mj = 0, moj = 0, m0j = 0;
+            if (lane < nj) {
+                mj = m_l[cj];
+                moj = moff_l[cj];
+                m0j = mj > 0 ? moff_l[cj + 1] - moj : 0;
+                if (mj > 0) atomicAdd(&ev_l[pc], mj);    // :986-991 runs for every visited cluster
+            }
+            for (int j0 = 0; j0 < nj; j0 += 8) {        // eight clusters' gathers in flight per lane
+                int mo8[8], m08[8], c8[8];
+                int mmax = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int g = mo4[u] + i;
-                    ok[u] = i < m04[u] && ((alive[g >> 5] >> (g & 31)) & 1u);
-                    cst[u] = 0;
-                    if (ok[u]) cst[u] = crow[S.cl_off[cc[u]] + (int)mirror[g]];
+                for (int u = 0; u < 8; ++u) {
+                    const int j = min(j0 + u, nj - 1);
+                    c8[u] = rdlane(cj, j);
+                    mo8[u] = rdlane(moj, j);
+                    m08[u] = j0 + u < nj ? rdlane(m0j, j) : 0;
+                    mmax = max(mmax, m08[u]);
                 }
+                if (mmax == 0) continue;
+                for (int base = 0; base < mmax; base += WAVE) {
+                    const int i = base + lane;
+                    int cst[8];
+                    bool ok[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned long long key = ((unsigned long long)(unsigned)cst[u] << 32) |
-                                                   ((unsigned)(si + u * REPL_WAVES - s0) << 16) | (unsigned)i;
-                    if (ok[u] && key < best) best = key;
+                    for (int u = 0; u < 8; ++u) {
+                        const int cl = i < m08[u] ? (int)mirror[mo8[u] + i] : DEAD;
+                        ok[u] = cl != DEAD;
+                        cst[u] = 0;
+                        if (ok[u]) cst[u] = crow[cl];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int hi = (cst[u] << 16) | ((jb + j0 + u) * REPL_WAVES + wave);
+                        const int lo = (i << 16) | c8[u];
+                        if (ok[u] && (hi < bhi || (hi == bhi && lo < blo))) { bhi = hi; blo = lo; }
+                    }
                 }
             }
         }
-        {   // wave minimum of the 64-bit keys
-            unsigned hi = (unsigned)(best >> 32), lo = (unsigned)best;
-            for (int o = 32; o; o >>= 1) {
-                const unsigned h2 = (unsigned)__shfl_xor((int)hi, o, WAVE), l2 = (unsigned)__shfl_xor((int)lo, o, WAVE);
-                if (h2 < hi || (h2 == hi && l2 < lo)) { hi = h2; lo = l2; }
-            }
-            if (lane == 0) s_cand[wave] = ((unsigned long long)hi << 32) | lo;
+        {
+            const int whi = wave_min_i32(bhi);
+            const int wlo = wave_min_i32(bhi == whi ? blo : IMAX);
+            if (lane == 0) { s_cand[wave][0] = whi; s_cand[wave][1] = wlo; }
         }
         PROF_STAMP(4);
-        if (lane == 0 && ev) atomicAdd(&cnt_l[pc * LCNT + CNT_EVALS], ev);    // :986-991 runs for every visited cluster
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long wk = s_cand[0];
-            for (int w = 1; w < REPL_WAVES; ++w) wk = s_cand[w] < wk ? s_cand[w] : wk;
+            int whi = s_cand[0][0], wlo = s_cand[0][1];
+            for (int w = 1; w < REPL_WAVES; ++w) {
+                const int h2 = s_cand[w][0], l2 = s_cand[w][1];
+                if (h2 < whi || (h2 == whi && l2 < wlo)) { whi = h2; wlo = l2; }
+            }
             int2 res = make_int2(-1, -1);
-            const int wc = (int)(wk >> 32);
-            if (wk != ~0ull && (long long)wc <= S.reject_threshold) {
-                const int wcl = S.dfs_seq[s0 + (int)((wk >> 16) & 0xFFFF)], wpos = (int)(wk & 0xFFFF);
-                const int g = moff_l[wcl] + wpos;
-                alive[g >> 5] &= ~(1u << (g & 31));
+            const int wc = whi >> 16;
+            if (whi != IMAX && (long long)wc <= S.reject_threshold) {
+                const int wcl = wlo & 0xFFFF, wpos = wlo >> 16;
+                mirror[moff_l[wcl] + wpos] = DEAD;
                 const int mw = m_l[wcl] - 1;
                 m_l[wcl] = mw;
                 if (S.dfs_off[wcl + 1] > S.dfs_off[wcl]) dry_l[wcl] = ORDER_ID2(qcur_l[wcl] + mw, qend_l[wcl]);
@@ -1498,12 +1662,14 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
 #endif
     }
-    // ---- resolve the preliminary results: vehicle ids, arrivals (:954-960), counters
-    __threadfence_block();
+    // ---- resolve the preliminary results: vehicle ids, arrivals (:954-960), counters (the id table is dead now)
+    int *rc_l = ids_l;
+    for (int i = threadIdx.x; i < RCNT * C; i += REPL_THREADS) rc_l[i] = 0;
+    __syncthreads();
     for (int q = tq0 + (int)threadIdx.x; q < tq1; q += REPL_THREADS) {
         const int4 rec = S.so_rec[q];
         const int2 pr = out_r[q];
-        int *cl = cnt_l + (int)((unsigned)rec.z >> 16) * LCNT;
+        int *cl = rc_l + (int)((unsigned)rec.z >> 16) * RCNT;
         atomicAdd(&cl[CNT_ORDERS], 1);
         if (pr.x == -1) {
             atomicAdd(&cl[CNT_REJECTS], 1);
@@ -1517,7 +1683,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         }
     }
     __syncthreads();
-    // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction by the alive bits
+    // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = mirror entries not DEAD)
     for (int c = wave; c < C; c += REPL_WAVES) {
         const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
         if (m_l[c] == m0) continue;
@@ -1528,8 +1694,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
             uint2 e = make_uint2(0u, 0u);
             bool keep = false;
             if (i < m0) {
-                const int g = mo + i;
-                keep = (alive[g >> 5] >> (g & 31)) & 1u;
+                keep = mirror[mo + i] != DEAD;
                 if (keep) e = idle[i];
             }
             const unsigned long long kb = ballot(keep);
@@ -1545,7 +1710,9 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         D.hdr[b * HDR_WORDS + HDR_IDLE] = m_l[c];
         long long *cnt = D.cnt + b * CNT_WORDS;
 #pragma unroll
-        for (int w = 0; w < LCNT; ++w) { const int d = cnt_l[c * LCNT + w]; if (d) cnt[w] += d; }
+        for (int w = 0; w < RCNT; ++w) { const int d = rc_l[c * RCNT + w]; if (d) cnt[w] += d; }
+        if (ev_l[c]) cnt[CNT_EVALS] += ev_l[c];
+        if (arr_l[c]) cnt[CNT_ARRIVALS] += arr_l[c];
     }
 #undef ORDER_ID2
 }
@@ -1688,7 +1855,7 @@ void launch_tick_replica(const Static &S, const State &D, int t, hipStream_t st)
 }
 
 void launch_tick_replica2(const Static &S, const State &D, int t, hipStream_t st) {
-    const size_t lds = ((size_t)(5 + LCNT) * S.C + 1 + S.max_tick_orders + (S.V >> 5) + 2) * sizeof(int) + ((size_t)S.V + 2) / 2 * 4;
+    const size_t lds = replica2_lds_ints(S.C, S.V, S.max_tick_orders) * sizeof(int);
     hipLaunchKernelGGL(k_tick_replica2, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
 }
 
