@@ -1271,7 +1271,9 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
 #define ID_MASK ((1 << ID_BITS) - 1)
 #define GRP 8                               // lanes per own-cluster group
 #define GRPS_WAVE (WAVE / GRP)
-#define OB 4                                // orders of one bucket whose cost gathers are in flight together
+#ifndef OB
+#define OB 1                                // orders of one bucket whose cost gathers are in flight together
+#endif
 #define RCNT 4                              // counters accumulated by the resolve pass: orders, rejects, wait, value
 
 __device__ __forceinline__ int grp_min_i32(int v) {     // minimum over each aligned group of 8 lanes
@@ -1286,7 +1288,25 @@ __host__ __device__ inline size_t replica2_lds_ints(int C, int V, int max_tick_o
     return (size_t)9 * C + 1 + ids + ((size_t)V + 2) / 2;
 }
 
+// rank of a 64-bit key (hi, lo) among the 16 keys of its row: number of strictly smaller ones (row_ror:1..15)
+template <int N>
+struct RowRank {
+    static __device__ __forceinline__ void run(unsigned hi, unsigned lo, int &rank) {
+        const unsigned h2 = (unsigned)dpp_mov<0x120 + N, 0xF>((int)hi, (int)hi), l2 = (unsigned)dpp_mov<0x120 + N, 0xF>((int)lo, (int)lo);
+        rank += (h2 < hi || (h2 == hi && l2 < lo)) ? 1 : 0;
+        RowRank<N - 1>::run(hi, lo, rank);
+    }
+};
+template <>
+struct RowRank<0> {
+    static __device__ __forceinline__ void run(unsigned, unsigned, int &) {}
+};
+
 #define DEAD 0xFFFF
+#define CAPABLE (1 << 30)
+#ifndef SLOTS
+#define SLOTS 12                            // candidates per lane of an 8-lane group held in registers
+#endif
 __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const int C = S.C;
@@ -1297,7 +1317,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
     int *moff_l = lds_dyn + 4 * C;      // [C+1] start of the cluster's segment in mirror
     int *ev_l = lds_dyn + 5 * C + 1;    // [C] match evaluations of this tick
     int *arr_l = ev_l + C;              // [C] arrivals of this tick
-    int *cdA_l = arr_l + C;             // [C] n_c | first cost column << 11
+    int *cdA_l = arr_l + C;             // [C] n_c | first cost column << 11 | (cluster has neighbours: can search) << 30
     int *cdB_l = cdA_l + C;             // [C] start of the cluster's cost block
     int *ids_l = cdB_l + C;             // [max(max_tick_orders, RCNT*C)] id | pickup_local << ID_BITS by sorted position;
                                         //     after the last round: [C][RCNT] counters of the resolve pass
@@ -1323,13 +1343,15 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
     for (int c = threadIdx.x; c < C; c += REPL_THREADS) {
         const int4 cd = S.cdesc[c];
         ev_l[c] = 0; arr_l[c] = 0;
-        cdA_l[c] = cd.x | (S.cl_off[c] << 11);
+        cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (S.dfs_off[c + 1] > S.dfs_off[c] ? CAPABLE : 0);
         cdB_l[c] = cd.y;
     }
     __syncthreads();
 #define ORDER_ID2(q, qend) ((q) < (qend) ? (ids_l[(q) - tq0] & ID_MASK) : IMAX)
-    // ---- UpdateFunction, bucket-parallel (one wavefront per bucket)
-    for (int c = wave; c < C; c += REPL_WAVES) {
+    // ---- UpdateFunction (:1006-1024).  Four buckets per wavefront, one per 16-lane row: a bucket with no far
+    //      entries and at most 16 arrivals this tick ranks them by dict-insertion key with 15 row rotations and
+    //      appends them to its idle list; the others are handled afterwards by the whole wavefront.
+    auto update_wave = [&](int c) {
         const size_t b = (size_t)c * S.R + r;
         int *hdr = D.hdr + b * HDR_WORDS;
         int hv = lane < HDR_WORDS ? hdr[lane] : 0;
@@ -1347,11 +1369,56 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
             m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
             if (A > 0) arr_l[c] = A;
         }
+    };
+    {
+        const int g16 = lane >> 4, l16 = lane & 15;
+        for (int c0 = 0; c0 < C; c0 += 4 * REPL_WAVES) {
+            const int c = c0 + wave * 4 + g16;
+            const bool valid = c < C;
+            const size_t b = (size_t)(valid ? c : 0) * S.R + r;
+            int *hdr = D.hdr + b * HDR_WORDS;
+            const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
+            int m = 0, far = 0, A = 0, q0 = 0, q1 = 0;
+            if (valid) {
+                m = hdr[HDR_IDLE];
+                far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
+                A = D.ring_cnt[si] & 0xFFFF;
+                q0 = S.bkt_off[(size_t)t * C + c]; q1 = S.bkt_off[(size_t)t * C + c + 1];
+            }
+            const bool slow = valid && (far != 0 || A > 16 || A > S.ring_cap);
+            const bool fast = valid && !slow;
+            if (ballot(fast && A > 0) != 0) {
+                int4 e = make_int4(0, 0, 0, 0);
+                unsigned khi = 0xFFFFFFFFu, klo = 0xFFFFFFFFu;
+                const bool mine = fast && l16 < A;
+                if (mine) {
+                    e = D.ring[si * S.ring_cap + l16];
+                    const unsigned long long key = entry_key(e.y, e.w);
+                    khi = (unsigned)(key >> 32); klo = (unsigned)key;
+                }
+                int rank = 0;
+                RowRank<15>::run(khi, klo, rank);
+                if (mine) {
+                    const int pos = m + rank;
+                    if (pos < S.idle_cap) D.idle[b * S.idle_cap + pos] = make_uint2((unsigned)e.x, (unsigned)meta_dest(e.w));
+                    else atomicOr(&D.err[0], ERR_IDLE_CAP);
+                }
+            }
+            if (fast && l16 == 0) {
+                if (A > 0) D.ring_cnt[si] = 0;
+                const int mn = min(m + A, S.idle_cap);
+                hdr[HDR_IDLE_PRE] = mn; hdr[HDR_ORDERS] = q1 - q0;
+                m_l[c] = mn; qcur_l[c] = q0; qend_l[c] = q1;
+                if (mn > m) arr_l[c] = mn - m;
+            }
+            for (unsigned long long rest = ballot(slow && l16 == 0); rest; rest &= rest - 1)
+                update_wave(c0 + wave * 4 + ((__ffsll((long long)rest) - 1) >> 4));
+        }
     }
     __syncthreads();
     PROF_STAMP(0);
     for (int c = threadIdx.x; c < C; c += REPL_THREADS)
-        dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qcur_l[c] + m_l[c], qend_l[c]) : IMAX;
+        dry_l[c] = (cdA_l[c] & CAPABLE) ? ORDER_ID2(qcur_l[c] + m_l[c], qend_l[c]) : IMAX;
     if (wave == 0) {            // exclusive prefix of the list lengths
         int run = 0;
         for (int base = 0; base < C; base += WAVE) {
@@ -1382,7 +1449,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         int idw = ids_l[qc - tq0];
         if ((idw & ID_MASK) >= limit) return;
         const int nc = cdA_l[c] & 2047;
-        const int *blk = S.blk + cdB_l[c] - (cdA_l[c] >> 11);
+        const int *blk = S.blk + cdB_l[c] - ((cdA_l[c] >> 11) & 0xFFFF);
         const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
         int m = m_l[c];
         int evals = 0;
@@ -1409,7 +1476,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
             idw = qc < qe ? ids_l[qc - tq0] : IMAX;
         } while (qc < qe && (idw & ID_MASK) < limit);
         m_l[c] = m; qcur_l[c] = qc;
-        dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qc + m, qe) : IMAX;
+        dry_l[c] = (cdA_l[c] & CAPABLE) ? ORDER_ID2(qc + m, qe) : IMAX;
         if (evals) ev_l[c] += evals;
     };
 
@@ -1462,37 +1529,44 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                 const int qe = qend_l[c];
                 const int cda = cdA_l[c];
                 const int nc = cda & 2047;
-                const int *blk = S.blk + cdB_l[c] - (cda >> 11);    // row[column] with the mirror's matrix columns
-                const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
+                const int *blk = S.blk + cdB_l[c] - ((cda >> 11) & 0xFFFF);    // row[column] with the mirror's matrix columns
+                const int mo = moff_l[c], m0 = act ? moff_l[c + 1] - mo : 0;
                 int m = m_l[c], evals = 0;
-                if (m0 <= 8 * GRP) {
-                    // the whole list sits in this group's registers: 8 candidates per lane
-                    int col[8];
+                // longest list among this wavefront's buckets of this step: bounds the (uniform) slot loops
+                const bool longlist = m0 > SLOTS * GRP;         // handled after the register-resident lists
+                const bool act_all = act;
+                act = act && !longlist;
+                int mx = longlist ? 0 : m0;
+                mx = max(mx, dpp_mov<0x4E, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x141, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x140, 0xF>(mx, mx));
+                const int mmaxw = max(max(rdlane(mx, 0), rdlane(mx, 16)), max(rdlane(mx, 32), rdlane(mx, 48)));
+                if (ballot(act) != 0) {
+                    // the whole list sits in this group's registers: up to SLOTS candidates per lane
+                    int col[SLOTS];
                     unsigned amask = 0;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = u * GRP + gl, g = mo + i;
+                    for (int u = 0; u < SLOTS; ++u) {
                         col[u] = DEAD;
-                        if (act && i < m0) col[u] = mirror[g];
-                        amask |= (col[u] != DEAD ? 1u : 0u) << u;
+                        if (u * GRP < mmaxw) {
+                            const int i = u * GRP + gl;
+                            if (i < m0) col[u] = mirror[mo + i];
+                            amask |= (col[u] != DEAD ? 1u : 0u) << u;
+                        }
                     }
                     while (ballot(act) != 0) {
-                        // up to OB pending orders of the bucket: all their cost gathers in flight together
-                        int idw[OB], cst[OB][8];
+                        // up to OB pending orders of the bucket: their cost gathers are in flight together
+                        int idw[OB], cst[OB][SLOTS];
 #pragma unroll
-                        for (int o = 0; o < OB; ++o) {
-                            idw[o] = (act && qc + o < qe) ? ids_l[qc + o - tq0] : IMAX;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) cst[o][u] = 0;
-                        }
+                        for (int o = 0; o < OB; ++o) idw[o] = (act && qc + o < qe) ? ids_l[qc + o - tq0] : IMAX;
 #pragma unroll
                         for (int o = 0; o < OB; ++o) {
                             const bool oo = (idw[o] & ID_MASK) < LB && idw[o] != IMAX;
-                            if (ballot(oo) == 0) break;          // usually one pending order: one row of gathers
+                            const bool any = ballot(oo) != 0;       // usually one pending order: one row of gathers
                             const int *row = blk + (size_t)(oo ? (idw[o] >> ID_BITS) : 0) * nc;
 #pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                if (oo && ((amask >> u) & 1u)) cst[o][u] = row[col[u]];
+                            for (int u = 0; u < SLOTS; ++u) {
+                                cst[o][u] = 0;
+                                if (any && u * GRP < mmaxw && oo && ((amask >> u) & 1u)) cst[o][u] = row[col[u]];
+                            }
                         }
 #pragma unroll
                         for (int o = 0; o < OB; ++o) {
@@ -1500,16 +1574,16 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                             if (ballot(oo) == 0) break;
                             int key = IMAX;
 #pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                if (oo && ((amask >> u) & 1u)) key = min(key, (cst[o][u] << 16) | (u * GRP + gl));
+                            for (int u = 0; u < SLOTS; ++u)
+                                if (u * GRP < mmaxw && oo && ((amask >> u) & 1u)) key = min(key, (cst[o][u] << 16) | (u * GRP + gl));
                             key = grp_min_i32(key);
                             if (oo) {
                                 evals += m;
                                 int2 res = make_int2(-1, -1);
                                 if (key != IMAX && (long long)(key >> 16) <= S.reject_threshold) {     // :943 (quirk Q3)
-                                    const int pos = key & 0xFFFF, g = mo + pos;
+                                    const int pos = key & 0xFFFF;
                                     if ((pos & (GRP - 1)) == gl) amask &= ~(1u << (pos / GRP));
-                                    if (gl == 0) mirror[g] = DEAD;
+                                    if (gl == 0) mirror[mo + pos] = DEAD;
                                     m--;
                                     res = make_int2((int)(((unsigned)c << 16) | (unsigned)pos), key >> 16);
                                 }
@@ -1521,8 +1595,10 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                         }
                         if (act) act = qc < qe && (ids_l[qc - tq0] & ID_MASK) < LB;
                     }
-                } else {
-                    // long list: one order at a time, 64 candidates per pass
+                }
+                act = act_all && longlist;
+                if (ballot(act) != 0) {
+                    // long lists: one order at a time, 64 candidates per pass
                     int idw = act ? ids_l[qc - tq0] : IMAX;
                     while (ballot(act) != 0) {
                         int key = IMAX;
@@ -1562,7 +1638,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                 }
                 if (w0 + gw < nwork && gl == 0) {
                     m_l[c] = m; qcur_l[c] = qc;
-                    dry_l[c] = S.dfs_off[c + 1] > S.dfs_off[c] ? ORDER_ID2(qc + m, qe) : IMAX;
+                    dry_l[c] = (cda & CAPABLE) ? ORDER_ID2(qc + m, qe) : IMAX;
                     if (evals) ev_l[c] += evals;
                 }
             }
@@ -1597,43 +1673,44 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                 m0j = mj > 0 ? moff_l[cj + 1] - moj : 0;
                 if (mj > 0) atomicAdd(&ev_l[pc], mj);    // :986-991 runs for every visited cluster
             }
-            for (int j0 = 0; j0 < nj; j0 += 8) {        // eight clusters' gathers in flight per lane
-                int mo8[8], m08[8], c8[8];
-                int mmax = 0;
+            // slots = (cluster j of this wavefront, 64-entry chunk b of its list), walked in (j, b) order, eight cost
+            // gathers in flight per lane.  key = cost << 16 | j << 9 | b: with the lane as the last tie-break this
+            // is (cost, visit position, list position)
+            unsigned long long live = ballot(m0j > 0);
+            int b = 0, best = IMAX;
+            while (live != 0) {
+                int cst[8], seq[8];
+                bool ok[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = min(j0 + u, nj - 1);
-                    c8[u] = rdlane(cj, j);
-                    mo8[u] = rdlane(moj, j);
-                    m08[u] = j0 + u < nj ? rdlane(m0j, j) : 0;
-                    mmax = max(mmax, m08[u]);
-                }
-                if (mmax == 0) continue;
-                for (int base = 0; base < mmax; base += WAVE) {
-                    const int i = base + lane;
-                    int cst[8];
-                    bool ok[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int cl = i < m08[u] ? (int)mirror[mo8[u] + i] : DEAD;
-                        ok[u] = cl != DEAD;
-                        cst[u] = 0;
-                        if (ok[u]) cst[u] = crow[cl];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int hi = (cst[u] << 16) | ((jb + j0 + u) * REPL_WAVES + wave);
-                        const int lo = (i << 16) | c8[u];
-                        if (ok[u] && (hi < bhi || (hi == bhi && lo < blo))) { bhi = hi; blo = lo; }
+                for (int k = 0; k < 8; ++k) {
+                    ok[k] = false; cst[k] = 0; seq[k] = 0;
+                    if (live != 0) {
+                        const int j = __ffsll((long long)live) - 1;
+                        const int m0c = rdlane(m0j, j), moc = rdlane(moj, j);
+                        const int i = b * WAVE + lane;
+                        const int cl = i < m0c ? (int)mirror[moc + i] : DEAD;
+                        ok[k] = cl != DEAD;
+                        if (ok[k]) cst[k] = crow[cl];
+                        seq[k] = (j << 9) | b;
+                        ++b;
+                        if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (ok[k]) best = min(best, (cst[k] << 16) | seq[k]);
+            }
+            // this batch's winner in global terms
+            const int wbest = wave_min_i32(best);
+            if (wbest != IMAX) {
+                const int wl = __ffsll((long long)ballot(best == wbest)) - 1;       // lowest lane = lowest list position
+                const int j = (wbest >> 9) & 63, bb = wbest & 511;
+                const int hi = (wbest & ~0xFFFF) | ((jb + j) * REPL_WAVES + wave);
+                const int lo = ((bb * WAVE + wl) << 16) | rdlane(cj, j);
+                if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; }
             }
         }
-        {
-            const int whi = wave_min_i32(bhi);
-            const int wlo = wave_min_i32(bhi == whi ? blo : IMAX);
-            if (lane == 0) { s_cand[wave][0] = whi; s_cand[wave][1] = wlo; }
-        }
+        if (lane == 0) { s_cand[wave][0] = bhi; s_cand[wave][1] = blo; }
         PROF_STAMP(4);
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1649,7 +1726,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                 mirror[moff_l[wcl] + wpos] = DEAD;
                 const int mw = m_l[wcl] - 1;
                 m_l[wcl] = mw;
-                if (S.dfs_off[wcl + 1] > S.dfs_off[wcl]) dry_l[wcl] = ORDER_ID2(qcur_l[wcl] + mw, qend_l[wcl]);
+                if (cdA_l[wcl] & CAPABLE) dry_l[wcl] = ORDER_ID2(qcur_l[wcl] + mw, qend_l[wcl]);
                 res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
             }
             out_r[q] = res;
