@@ -932,7 +932,9 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
 // LB itself then searches the precomputed visit sequence with all wavefronts scanning candidate clusters
 // in parallel (winner = lexicographic min of (cost, visit position, list position) == the reference's first
 // strict minimum in visit order), the victim list shrinks, and the next round begins.
+#ifndef REPL_THREADS
 #define REPL_THREADS 256
+#endif
 #define REPL_WAVES (REPL_THREADS / WAVE)
 
 // own-cluster match of orders [qs, qs+n) for tables of any size (slow path: > 256 idle entries)
@@ -1432,10 +1434,26 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         if (lane == 0) moff_l[C] = run;
     }
     __syncthreads();
-    for (int c = wave; c < C; c += REPL_WAVES) {
-        const uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
-        const int m = m_l[c], mo = moff_l[c], clo = cdA_l[c] >> 11;
-        for (int i = lane; i < m; i += WAVE) mirror[mo + i] = (unsigned short)(clo + (int)idle[i].y);
+    for (int c = wave; c < C; c += 4 * REPL_WAVES) {       // four buckets' list loads in flight per wavefront
+        int m4[4], mo4[4], clo4[4];
+        unsigned loc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u * REPL_WAVES;
+            m4[u] = cu < C ? m_l[cu] : 0;
+            mo4[u] = cu < C ? moff_l[cu] : 0;
+            clo4[u] = cu < C ? (cdA_l[cu] >> 11) & 0xFFFF : 0;
+            loc4[u] = 0;
+            if (lane < m4[u]) loc4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane].y;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (lane < m4[u]) mirror[mo4[u] + lane] = (unsigned short)(clo4[u] + (int)loc4[u]);
+            if (m4[u] > WAVE) {
+                const uint2 *idle = D.idle + ((size_t)(c + u * REPL_WAVES) * S.R + r) * S.idle_cap;
+                for (int i = WAVE + lane; i < m4[u]; i += WAVE) mirror[mo4[u] + i] = (unsigned short)(clo4[u] + (int)idle[i].y);
+            }
+        }
     }
     __syncthreads();
     PROF_STAMP(1);
@@ -1761,9 +1779,28 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
     }
     __syncthreads();
     // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = mirror entries not DEAD)
+    for (int c = wave; c < C; c += 4 * REPL_WAVES) {
+        // lists of at most 64 entries: four buckets' loads in flight; longer ones chunk by chunk below
+        uint2 e4[4];
+        bool keep4[4], small4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u * REPL_WAVES;
+            const int mo = cu < C ? moff_l[cu] : 0, m0 = cu < C ? moff_l[cu + 1] - mo : 0;
+            small4[u] = cu < C && m0 <= WAVE && m_l[cu] != m0;
+            keep4[u] = small4[u] && lane < m0 && mirror[mo + lane] != DEAD;
+            e4[u] = make_uint2(0u, 0u);
+            if (keep4[u]) e4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long kb = ballot(keep4[u]);
+            if (keep4[u]) D.idle[((size_t)(c + u * REPL_WAVES) * S.R + r) * S.idle_cap + popc64(kb & lanemask_lt())] = e4[u];
+        }
+    }
     for (int c = wave; c < C; c += REPL_WAVES) {
         const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
-        if (m_l[c] == m0) continue;
+        if (m_l[c] == m0 || m0 <= WAVE) continue;
         uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
         int kept = 0;
         for (int base = 0; base < m0; base += WAVE) {
