@@ -200,7 +200,7 @@ def main():
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_tick_rows" if not w.neighbor_can_server else "k_tick_replica",
+            roofline = {"bound": "hbm", "kernel": env.main_kernel(),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes,
                         "avg_launch_ms": float(ms.mean()), "launches": int(ms.size),

@@ -206,6 +206,11 @@ int vds_py_random_nodes(uint64_t seed, int32_t N, int32_t count, const uint8_t *
 int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
                       int32_t *seq_off, int32_t *seq, int64_t cap);
 
+/* Name of the kernel that vds_step launches for the main part of a tick with the handle's current tables (the one
+ * vds_profile_enable brackets with events): "k_tick_rows", "k_tick", "k_tick_replica2", "k_tick_replica" or
+ * "k_match_dfs".  Valid after vds_load_orders; static string. */
+const char *vds_main_kernel(const vds_handle *h);
+
 /* Library/ABI version: (major << 16) | minor. */
 int32_t vds_version(void);
 

@@ -56,6 +56,7 @@ SYMBOLS = {
     "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),
     "vds_read_work": (C.c_int, [_VP, _VP]),
     "vds_py_random_nodes": (C.c_int, [C.c_uint64, _I32, _I32, _VP, _VP]),
+    "vds_main_kernel": (C.c_char_p, [_VP]),
     "vds_dfs_sequences": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, C.c_int64]),
 }
 TEST_SYMBOLS = {"vds_debug_ablate": (C.c_int, [_VP, _I32]), "vds_debug_read_prof": (C.c_int, [_VP, _VP]), "vds_selftest_dpp": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32])}

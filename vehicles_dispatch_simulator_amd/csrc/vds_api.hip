@@ -194,6 +194,13 @@ void vds_config_init(vds_config *cfg) {
     cfg->pickup_reject_threshold = 600000000000LL;      // config/setting.py:7 (raw integer, quirk Q3)
 }
 
+const char *vds_main_kernel(const vds_handle *h) {
+    if (!h || !h->have_orders) return "";
+    if (!h->dfs_mode) return h->S.fast_ok ? "k_tick_rows" : "k_tick";
+    if (h->S.C <= 3072 && h->cfg.force_generic != 1) return (h->dfs2_ok && h->cfg.force_generic == 0) ? "k_tick_replica2" : "k_tick_replica";
+    return "k_match_dfs";
+}
+
 const char *vds_last_error(const vds_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 static int create_impl(const vds_config *cfg, vds_handle **out) {

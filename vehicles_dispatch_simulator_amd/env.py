@@ -175,6 +175,10 @@ class BatchedDispatchEnv:
     def profile(self, on: bool):
         self._chk(self._lib.vds_profile_enable(self._h, int(bool(on))))
 
+    def main_kernel(self) -> str:
+        """Name of the kernel ``step`` launches for the main part of a tick (the one ``profile`` times)."""
+        return (self._lib.vds_main_kernel(self._h) or b"").decode()
+
     def profile_read(self, cap: int = 4096) -> np.ndarray:
         ms = np.zeros(cap, dtype=np.float32)
         n = C.c_int32()
