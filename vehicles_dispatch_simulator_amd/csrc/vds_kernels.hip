@@ -6,8 +6,10 @@
 //                  :924-933) + SupplyExpectFunction :880-891 + idle snapshots :909-910
 //   k_tick<true>   the same, generic per-bucket form (any cost range, any table size)
 //   k_tick_work    buckets deferred by k_tick (> 256 idle entries) or by k_tick_rows (cost block too big for LDS)
-//   k_tick_replica neighbour-search mode: Update + Match + FindServerVehicleFunction :978-996 in exact
-//                  lower-bound rounds, one workgroup per replica
+//   k_tick_replica2 neighbour-search mode: Update + Match + FindServerVehicleFunction :978-996 in exact
+//                  lower-bound rounds, one workgroup per replica, lists untouched during the tick
+//   k_tick_replica  the same, first generation (lists edited in place); used when k_tick_replica2's
+//                  preconditions do not hold
 //   k_tick<false> + k_match_dfs   the same, serial reference form (fallback / second GPU statement for the tests)
 //   k_dispatch     body of a DispatchFunction :893-898
 //
