@@ -58,6 +58,10 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_mov(int old, int v) {
+    // full row mask: every lane has a valid source for the controls used here (quad_perm, row mirrors, row_ror), so
+    // bound_ctrl:0 with an undefined `old` is equivalent - and lets the compiler fold the move into the consuming
+    // VALU op (v_min_i32_dpp / v_add_u32_dpp) instead of copy + v_mov_b32_dpp + op
+    if (ROW_MASK == 0xF) return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
     return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
 }
 template <int CTRL>
