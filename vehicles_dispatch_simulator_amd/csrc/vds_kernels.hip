@@ -740,6 +740,8 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE) void k_tick_rows(Static S, State
     int *lds_blk = reinterpret_cast<int *>(scr_all + ROWS_WAVES * 4 * ROW_KEYS);
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
+    // (keeping all chunks of a cluster on one XCD - blockIdx & 7 - was measured: 99 us vs 93 us, the XCDs lose the
+    // LPT balance; the static tables are small enough to sit in every L2)
     const int c = S.corder[blockIdx.x / nchunks];
     const int chunk = blockIdx.x % nchunks;
     const int wave = threadIdx.x >> 6;
