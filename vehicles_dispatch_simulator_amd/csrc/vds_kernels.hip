@@ -192,21 +192,20 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
         const int node = valid ? vn[v] : 0;
         const int cl = valid ? S.node2cluster[node] : -1;
         const unsigned nl = valid ? (unsigned)S.node_local[node] : 0u;
-        unsigned long long remaining = ballot(valid);
-        while (remaining) {
-            const int leader = __ffsll((long long)remaining) - 1;
-            const int lc = rdlane(cl, leader);
-            const unsigned long long same = ballot(cl == lc);
-            const int bs = mine[lc];
-            if (cl == lc) {
-                const int pos = bs + popc64(same & lanemask_lt());
-                if (pos < S.idle_cap) D.idle[((size_t)lc * S.R + r) * S.idle_cap + pos] = make_uint2((unsigned)v, nl);
-            }
-            wave_fence();
-            if (lane == leader) mine[lc] = bs + popc64(same);
-            wave_fence();
-            remaining &= ~same;
+        // lanes of the same cluster, without a loop over the distinct clusters: one ballot per bit of the cluster id
+        unsigned long long same = ballot(valid);
+        for (int bit = 0; (1 << bit) < C; ++bit) {
+            const unsigned long long bb = ballot((cl >> bit) & 1);
+            same &= ((cl >> bit) & 1) ? bb : ~bb;
         }
+        if (valid) {
+            const int bs = mine[cl];
+            const int pos = bs + popc64(same & lanemask_lt());          // vehicle order is kept inside a cluster
+            if (pos < S.idle_cap) D.idle[((size_t)cl * S.R + r) * S.idle_cap + pos] = make_uint2((unsigned)v, nl);
+            wave_fence();
+            if ((same & lanemask_lt()) == 0) mine[cl] = bs + popc64(same);   // the cluster's first lane advances its cursor
+        }
+        wave_fence();
     }
 }
 
