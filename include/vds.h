@@ -179,6 +179,17 @@ int vds_read_orders(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int3
 int vds_read_lists(vds_handle *h, int32_t replica, int32_t *idle_off, int32_t *idle_veh, int32_t *idle_node,
                    int32_t *arr_off, int32_t *arr_veh, int32_t *arr_min, int32_t *arr_order, int32_t *arr_node);
 
+/* Per-vehicle view of one replica (the fields of `Vehicle`, objects.py:75-82, that the tick path changes), each [V],
+ * NULL to skip:
+ *   state      0 idle (in some Cluster.IdleVehicles), 1 on the way with an order, 2 on the way after a dispatch;
+ *   node       idle: LocationNode; on the way: DeliveryPoint;
+ *   cluster    the cluster whose idle list / arrival dict holds the vehicle (for a vehicle on the way: the
+ *              destination's cluster.  The reference leaves Vehicle.LocationNode / .Cluster at the trip origin
+ *              until ArriveVehicleUpDate, objects.py:84-89; the origin is not kept on the device);
+ *   arrive_min arrival minute on the day clock (-1 when idle);  order  carried Order.ID (-1 when none). */
+int vds_read_vehicles(vds_handle *h, int32_t replica, uint8_t *state, int32_t *node, int32_t *cluster,
+                      int32_t *arrive_min, int32_t *order);
+
 /* Work model of the last vds_step / vds_run call sequence since vds_reset, for roofline
  * accounting (DESIGN.md "algorithmic bytes"): int64 [8] = {ticks, orders processed, matches,
  * evaluations, arrivals, dispatches, 0, 0} summed over replicas. */

@@ -37,6 +37,19 @@ def check_lists(env, r, o, t):
     na = L["arr_off"][-1]
     np.testing.assert_array_equal(G["arr_node"][:na], veh["dest"][L["arr_veh"][:na]])
     np.testing.assert_array_equal(G["arr_order"][:na], veh["order"][L["arr_veh"][:na]])
+    # per-vehicle view (vds_read_vehicles) against the oracle's Vehicle fields
+    W = env.vehicles(r)
+    idle = np.zeros(env.V, dtype=bool); idle[L["idle_veh"][:n]] = True
+    fly = L["arr_veh"][:na]
+    assert ((W["state"] == 0) == idle).all() and set(np.flatnonzero(W["state"] > 0)) == set(fly.tolist())
+    np.testing.assert_array_equal(W["node"][idle], veh["loc"][idle])
+    np.testing.assert_array_equal(W["node"][fly], veh["dest"][fly])
+    np.testing.assert_array_equal(W["order"][fly], veh["order"][fly])
+    np.testing.assert_array_equal(W["state"][fly], np.where(veh["order"][fly] >= 0, 1, 2))
+    np.testing.assert_array_equal(W["arrive_min"][fly], L["arr_min"][:na])
+    assert (W["arrive_min"][idle] == -1).all() and (W["order"][idle] == -1).all()
+    cl_idle = np.empty(env.V, dtype=np.int64); cl_idle[L["idle_veh"][:n]] = np.repeat(np.arange(env.C), np.diff(L["idle_off"]))
+    np.testing.assert_array_equal(W["cluster"][idle], cl_idle[idle])
 
 
 def run_day(g, R, same_init, list_every=1, **kw):

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,6 +55,7 @@ SYMBOLS = {
     "vds_profile_read": (C.c_int, [_VP, _VP, _I32, C.POINTER(_I32)]),
     "vds_read_orders": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
     "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),
+    "vds_read_vehicles": (C.c_int, [_VP, _I32] + [_VP] * 5),
     "vds_read_work": (C.c_int, [_VP, _VP]),
     "vds_py_random_nodes": (C.c_int, [C.c_uint64, _I32, _I32, _VP, _VP]),
     "vds_main_kernel": (C.c_char_p, [_VP]),
@@ -83,6 +85,15 @@ def load():
             except Exception as e:
                 raise RuntimeError("libvds.so is not built (%s) and building it failed (%s): run "
                                    "`make -C vehicles_dispatch_simulator_amd/csrc`; there is no CPU fallback" % (LIB_PATH, e))
+        # One HIP/HSA runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and
+        # a process that initialises the system runtime first (through libvds) and torch's copy second ends with
+        # torch reporting "No HIP GPUs are available".  Importing torch first makes libvds bind to the runtime torch
+        # loaded (same soname), which is the order bench.py and the RCCL path use anyway.
+        if "torch" not in sys.modules and not os.environ.get("VDS_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in {**SYMBOLS, **TEST_SYMBOLS}.items():
             fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol

@@ -954,6 +954,41 @@ int vds_selftest_dpp(vds_handle *h, const int32_t *in, int32_t *out_wave, int32_
     return VDS_OK;
 }
 
+static int read_vehicles_impl(vds_handle *h, int32_t replica, uint8_t *state, int32_t *node, int32_t *cluster,
+                              int32_t *arrive_min, int32_t *order) {
+    if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_read_vehicles: call vds_reset first");
+    const int C = h->S.C, V = h->S.V;
+    std::vector<int32_t> io(C + 1), iv(V), in(V), ao(C + 1), av(V), am(V), aor(V), an(V);
+    int rc = read_lists_impl(h, replica, io.data(), iv.data(), in.data(), ao.data(), av.data(), am.data(), aor.data(), an.data());
+    if (rc) return rc;
+    for (int v = 0; v < V; ++v) {       // a vehicle in neither container cannot happen; mark it if it does
+        if (state) state[v] = 255;
+        if (node) node[v] = -1;
+        if (cluster) cluster[v] = -1;
+        if (arrive_min) arrive_min[v] = -1;
+        if (order) order[v] = -1;
+    }
+    for (int c = 0; c < C; ++c) {
+        for (int k = io[c]; k < io[c + 1]; ++k) {
+            const int v = iv[k];
+            if (v < 0 || v >= V) return fail(h, VDS_ESTATE, "vds_read_vehicles: corrupt idle list");
+            if (state) state[v] = 0;
+            if (node) node[v] = in[k];
+            if (cluster) cluster[v] = c;
+        }
+        for (int k = ao[c]; k < ao[c + 1]; ++k) {
+            const int v = av[k];
+            if (v < 0 || v >= V) return fail(h, VDS_ESTATE, "vds_read_vehicles: corrupt arrival table");
+            if (state) state[v] = aor[k] >= 0 ? 1 : 2;
+            if (node) node[v] = an[k];
+            if (cluster) cluster[v] = c;
+            if (arrive_min) arrive_min[v] = am[k];
+            if (order) order[v] = aor[k];
+        }
+    }
+    return VDS_OK;
+}
+
 // ---- exception-safe entry points
 int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
                       int32_t *seq_off, int32_t *seq, int64_t cap) {
@@ -1017,6 +1052,11 @@ int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
 
 int vds_create(const vds_config *cfg, vds_handle **out) {
     return guarded(nullptr, "vds_create", [&] { return create_impl(cfg, out); });
+}
+
+int vds_read_vehicles(vds_handle *h, int32_t replica, uint8_t *state, int32_t *node, int32_t *cluster,
+                      int32_t *arrive_min, int32_t *order) {
+    return guarded(h, "vds_read_vehicles", [&] { return read_vehicles_impl(h, replica, state, node, cluster, arrive_min, order); });
 }
 
 }  // extern "C"

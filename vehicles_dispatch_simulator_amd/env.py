@@ -185,6 +185,15 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_profile_read(self._h, _p(ms), cap, C.byref(n)))
         return ms[:n.value].copy()
 
+    def vehicles(self, replica: int) -> Dict[str, np.ndarray]:
+        """Per-vehicle view of one replica: ``state`` (0 idle, 1 carrying an order, 2 dispatched), ``node``
+        (LocationNode when idle, DeliveryPoint on the way), ``cluster``, ``arrive_min`` (-1 idle), ``order``."""
+        V = self.V
+        st = np.zeros(V, dtype=np.uint8)
+        arrs = [np.zeros(V, dtype=np.int32) for _ in range(4)]
+        self._chk(self._lib.vds_read_vehicles(self._h, int(replica), _p(st), *[_p(a) for a in arrs]))
+        return dict(state=st, node=arrs[0], cluster=arrs[1], arrive_min=arrs[2], order=arrs[3])
+
     def work(self) -> Dict[str, int]:
         out = np.zeros(8, dtype=np.int64)
         self._chk(self._lib.vds_read_work(self._h, _p(out)))
