@@ -1573,7 +1573,8 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                         col[u] = DEAD;
                         if (u * GRP < mmaxw) {
                             const int i = u * GRP + gl;
-                            if (i < m0) col[u] = mirror[mo + i];
+                            const int v = mirror[mo + min(i, max(m0, 1) - 1)];
+                            col[u] = i < m0 ? v : DEAD;
                             amask |= (col[u] != DEAD ? 1u : 0u) << u;
                         }
                     }
@@ -1590,7 +1591,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
 #pragma unroll
                             for (int u = 0; u < SLOTS; ++u) {
                                 cst[o][u] = 0;
-                                if (any && u * GRP < mmaxw && oo && ((amask >> u) & 1u)) cst[o][u] = row[col[u]];
+                                if (any && u * GRP < mmaxw) cst[o][u] = *((oo && ((amask >> u) & 1u)) ? row + col[u] : S.blk);
                             }
                         }
 #pragma unroll
@@ -1704,26 +1705,32 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
             unsigned long long live = ballot(m0j > 0);
             int b = 0, best = IMAX;
             while (live != 0) {
-                int cst[8], seq[8];
-                bool ok[8];
+                // branch-free in three passes, so that the eight LDS reads and then the eight gathers are issued
+                // back to back instead of one dependent chain per slot
+                int cl[8], cst[8], seq[8];
+                bool in[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    ok[k] = false; cst[k] = 0; seq[k] = 0;
+                    in[k] = false; cl[k] = DEAD; seq[k] = 0;
                     if (live != 0) {
                         const int j = __ffsll((long long)live) - 1;
                         const int m0c = rdlane(m0j, j), moc = rdlane(moj, j);
                         const int i = b * WAVE + lane;
-                        const int cl = i < m0c ? (int)mirror[moc + i] : DEAD;
-                        ok[k] = cl != DEAD;
-                        if (ok[k]) cst[k] = crow[cl];
+                        in[k] = i < m0c;
+                        cl[k] = mirror[moc + min(i, m0c - 1)];
                         seq[k] = (j << 9) | b;
                         ++b;
                         if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
                     }
                 }
 #pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    in[k] = in[k] && cl[k] != DEAD;
+                    cst[k] = crow[in[k] ? cl[k] : 0];
+                }
+#pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (ok[k]) best = min(best, (cst[k] << 16) | seq[k]);
+                    best = min(best, in[k] ? (cst[k] << 16) | seq[k] : IMAX);
             }
             // this batch's winner in global terms
             const int wbest = wave_min_i32(best);
