@@ -1631,19 +1631,19 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                         if (act && m > 0) {
                             const int *row = blk + (size_t)(idw >> ID_BITS) * nc;
                             for (int i0 = 0; i0 < m0; i0 += 8 * GRP) {
-                                int cst[8];
+                                int cl[8], cst[8];
                                 bool ok[8];
 #pragma unroll
                                 for (int u = 0; u < 8; ++u) {
                                     const int i = i0 + u * GRP + gl;
-                                    const int cl = i < m0 ? (int)mirror[mo + i] : DEAD;
-                                    ok[u] = cl != DEAD;
-                                    cst[u] = 0;
-                                    if (ok[u]) cst[u] = row[cl];
+                                    cl[u] = mirror[mo + min(i, m0 - 1)];
+                                    ok[u] = i < m0 && cl[u] != DEAD;
                                 }
 #pragma unroll
+                                for (int u = 0; u < 8; ++u) cst[u] = *(ok[u] ? row + cl[u] : S.blk);
+#pragma unroll
                                 for (int u = 0; u < 8; ++u)
-                                    if (ok[u]) key = min(key, (cst[u] << 16) | (i0 + u * GRP + gl));
+                                    key = min(key, ok[u] ? (cst[u] << 16) | (i0 + u * GRP + gl) : IMAX);
                             }
                         }
                         key = grp_min_i32(key);
