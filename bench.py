@@ -195,9 +195,9 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    tj = json.load(open(tpath))
-                    if tj.get("workload") == a.workload and tj.get("replicas") == R:
-                        traffic = tj.get("hbm_bytes_per_launch")
+                    for tj in json.load(open(tpath)).get("entries", []):
+                        if tj.get("workload") == a.workload and tj.get("replicas") == R and tj.get("kernel") == env.main_kernel():
+                            traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": env.main_kernel(),
