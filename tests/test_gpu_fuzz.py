@@ -52,16 +52,57 @@ def random_case(seed):
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 
 
+def medium_case(seed):
+    """Mid-size cities: lists longer than the register tables, bursts of arrivals, several worklist steps per round."""
+    rng = np.random.default_rng(50_000 + seed)
+    N = int(rng.integers(300, 900))
+    C = int(rng.integers(20, 150))
+    city = synth.make_city(seed * 11 + 5, N=N, C=C, with_neighbors=False)
+    cost = city.cost.copy()
+    if rng.random() < 0.3:
+        cost = (cost // 5).astype(np.int32)          # many ties
+    n2c = city.node2cluster.copy()
+    nbr = []
+    for c in range(C):
+        k = int(rng.integers(0, 9))
+        nbr.append(rng.choice(C, size=min(k, C), replace=False).tolist() if k else [])
+    V = int(rng.integers(150, 1000))
+    O = int(rng.integers(2000, 12000))
+    valid_nodes = np.flatnonzero(n2c >= 0)
+    rel = np.sort(rng.integers(0, 1440, size=O)).astype(np.int32)
+    hot = rng.random() < 0.5                          # half of the days: deliveries concentrate on a few clusters
+    pick = rng.choice(valid_nodes, size=O).astype(np.int32)
+    dele = rng.choice(valid_nodes, size=O).astype(np.int32)
+    if hot:
+        hot_nodes = np.flatnonzero(n2c < max(1, C // 10))
+        sel = rng.random(O) < 0.7
+        dele[sel] = rng.choice(hot_nodes, size=int(sel.sum()))
+    cfg = dict(neighbor=bool(rng.random() < 0.8), depth=int(rng.integers(0, 5)),
+               threshold=int(rng.choice([600_000_000_000, 600_000_000_000, 30])),
+               ring_ticks=int(rng.choice([32, 32, 4])), force_generic=int(rng.choice([0, 0, 0, 2])),
+               tick=int(rng.choice([10, 10, 5])), R=int(rng.integers(1, 4)), dispatch=bool(rng.random() < 0.3))
+    return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_MEDIUM_N", "12")))))
+def test_medium_city_matches_oracle(seed):
+    run_case(seed, medium_case(seed), idle_cap=1024)
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "60")))))
 def test_random_city_matches_oracle(seed):
-    cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg = random_case(seed)
+    run_case(seed, random_case(seed))
+
+
+def run_case(seed, case, idle_cap=None):
+    cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg = case
     off, idx = neighbors_to_csr(nbr)
     R, N = cfg["R"], cost.shape[0]
     rng = np.random.default_rng(1000 + seed)
     init = rng.choice(valid_nodes, size=(R, V)).astype(np.int32) if V else np.zeros((R, 0), np.int32)
     env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
                              tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
-                             force_generic=cfg["force_generic"], idle_cap=max(64, V), ring_cap=max(16, V), far_cap=max(64, V))
+                             force_generic=cfg["force_generic"], idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V))
     env.load_orders(rel, pick, dele)
     env.reset(init)
     oracles = []
