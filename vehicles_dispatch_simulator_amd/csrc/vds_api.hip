@@ -386,6 +386,9 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         for (int c = 0; c < C; ++c) corder[c] = c;
         std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cdesc[a].x > cdesc[b].x; });
         if ((rc = upload(h, &d, corder))) return rc; S.corder = d;
+        std::vector<int4> cdo(C);
+        for (int i = 0; i < C; ++i) cdo[i] = make_int4(cdesc[corder[i]].x, cdesc[corder[i]].y, corder[i], 0);
+        { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
     }
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;
     if ((rc = upload(h, &d, dfs_seq))) return rc; S.dfs_seq = d;

@@ -741,7 +741,8 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE) void k_tick_rows(Static S, State
     const int nchunks = gridDim.x / S.C;
     // (keeping all chunks of a cluster on one XCD - blockIdx & 7 - was measured: 99 us vs 93 us, the XCDs lose the
     // LPT balance; the static tables are small enough to sit in every L2)
-    const int c = S.corder[blockIdx.x / nchunks];
+    const int4 cd = S.cdesc_ord[blockIdx.x / nchunks];
+    const int c = cd.z;
     const int chunk = blockIdx.x % nchunks;
     const int wave = threadIdx.x >> 6;
     const int lane = lane_id();
@@ -769,7 +770,6 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE) void k_tick_rows(Static S, State
         A = D.ring_cnt[si] & 0xFFFF;
         if (l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];
     }
-    const int4 cd = S.cdesc[c];
     const int nc = cd.x;
     const int q0 = S.bkt_off[(size_t)t * S.C + c];
     const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
