@@ -1,6 +1,6 @@
 """A vectorised dispatch loop over R city replicas: observations stay on the GPU as a torch tensor, a toy policy
 moves idle vehicles from the clusters with the largest surplus towards the clusters with the largest expected
-shortage, every replica with its own vehicle seed.
+shortage, every replica with its own vehicle seed.  Observation -> policy -> action never leaves the device.
 
     python examples/batched_dispatch_loop.py [replicas]"""
 import os
@@ -18,7 +18,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 w = workloads.tiny(N=600, C=24, vehicles=400, orders=12000)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
-some_node_of = np.array([np.flatnonzero(w.city.node2cluster == c)[0] for c in range(w.city.C)], dtype=np.int32)
+some_node_of = torch.tensor([int(np.flatnonzero(w.city.node2cluster == c)[0]) for c in range(w.city.C)], dtype=torch.int32, device="cuda")
 t0 = time.time()
 for t in range(env.T):
     env.step()
@@ -28,10 +28,10 @@ for t in range(env.T):
     src = surplus.argmax(dim=1)                             # richest cluster of every replica
     dst = surplus.argmin(dim=1)                             # poorest cluster of every replica
     move = (surplus.gather(1, src[:, None])[:, 0] - surplus.gather(1, dst[:, None])[:, 0] > 4) & (idle.gather(1, src[:, None])[:, 0] > 0)
-    rep = torch.nonzero(move)[:, 0].cpu().numpy().astype(np.int32)
-    if rep.size:
-        s, d = src.cpu().numpy()[rep], dst.cpu().numpy()[rep]
-        env.apply_dispatch(rep, s.astype(np.int32), np.zeros(rep.size, np.int32), some_node_of[d])   # first idle vehicle of src
+    # the policy's decision stays on the GPU: one action slot per replica = (from_cluster | -1, idle position, target node)
+    actions = torch.stack([torch.where(move, src, torch.full_like(src, -1)).int(), torch.zeros_like(src).int(),
+                           some_node_of[dst]], dim=1).reshape(R, 1, 3).contiguous()
+    env.apply_dispatch_torch(actions)                       # vds_apply_dispatch_device: asynchronous, no host round trip
     env.advance()
 env.sync()
 cn = env.counters()

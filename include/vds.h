@@ -126,6 +126,15 @@ int vds_step(vds_handle *h);
 int vds_apply_dispatch(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
                        const int32_t *idle_pos, const int32_t *target_node);
 
+/* The same DispatchFunction body for every replica at once, from a DEVICE-resident action tensor - what a batched
+ * policy running on the GPU emits; nothing crosses PCIe and the call is asynchronous on the handle's stream (which
+ * must be ordered after the producer of the tensor).  dev_actions: int32 [replicas][K][3] =
+ * {from_cluster, idle_pos, target_node}, from_cluster < 0 = no action in this slot, K <= 64.  Within a replica the
+ * actions form one hook body: positions refer to the idle lists as they stand when the call is made, dict insertion
+ * order = slot index.  An out-of-range cluster / position / target (or a target node in no cluster) raises the
+ * sticky dispatch error reported by the next vds_sync / vds_read_*; the action is skipped. */
+int vds_apply_dispatch_device(vds_handle *h, int32_t K, const void *dev_actions);
+
 /* `self.step += 1; self.RealExpTime += self.TimePeriods` (:1090-1091). */
 int vds_advance(vds_handle *h);
 

@@ -129,7 +129,18 @@ def run_case(seed, case, idle_cap=None):
                     c = int(np.searchsorted(L["idle_off"], flat, side="right") - 1)
                     reps.append(r); cls.append(c); poss.append(int(flat - L["idle_off"][c])); tgts.append(int(tnode))
                 o.dispatch(vehs, tg)
-            if reps:
+            if reps and seed % 2 == 1:     # odd seeds: the same actions as a device-resident [R, K, 3] tensor
+                import torch
+                cntr = np.bincount(reps, minlength=R)
+                acts = np.full((R, int(cntr.max()) + 1, 3), -1, dtype=np.int32)
+                slot = np.zeros(R, dtype=np.int64)
+                for r_, c_, p_, t_ in zip(reps, cls, poss, tgts):
+                    acts[r_, slot[r_] + (slot[r_] > 0)] = (c_, p_, t_)      # leave an empty slot after the first action
+                    slot[r_] += 1
+                held = torch.from_numpy(acts).cuda()
+                env.apply_dispatch_torch(held)
+                env.sync()
+            elif reps:
                 env.apply_dispatch(reps, cls, poss, tgts)
         if t % 9 == 0:
             ob = env.obs()

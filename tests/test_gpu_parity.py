@@ -52,8 +52,11 @@ def check_lists(env, r, o, t):
     np.testing.assert_array_equal(W["cluster"][idle], cl_idle[idle])
 
 
-def run_day(g, R, same_init, list_every=1, **kw):
+def run_day(g, R, same_init, list_every=1, device_dispatch=False, **kw):
     V, N = int(g["V"]), int(g["N"])
+    if device_dispatch:
+        import torch
+        kw = dict(kw, stream=torch.cuda.current_stream().cuda_stream)
     valid = g["node2cluster"] >= 0
     init = np.empty((R, V), dtype=np.int32)
     init[0] = g["veh_node"]
@@ -98,7 +101,12 @@ def run_day(g, R, same_init, list_every=1, **kw):
                 pos.append(int(np.flatnonzero(seg == veh)[0]))
             nrep = R if same_init else 1
             rep = np.repeat(np.arange(nrep), len(rows))
-            env.apply_dispatch(rep, np.tile(rows[:, 2], nrep), np.tile(pos, nrep), np.tile(rows[:, 4], nrep))
+            if device_dispatch:       # the same hook body as a device-resident [R, K, 3] action tensor
+                acts = np.full((R, len(rows) + 3, 3), -1, dtype=np.int32)
+                acts[:nrep, 1:len(rows) + 1, 0] = rows[:, 2]; acts[:nrep, 1:len(rows) + 1, 1] = pos; acts[:nrep, 1:len(rows) + 1, 2] = rows[:, 4]
+                env.apply_dispatch_torch(torch.from_numpy(acts).cuda())
+            else:
+                env.apply_dispatch(rep, np.tile(rows[:, 2], nrep), np.tile(pos, nrep), np.tile(rows[:, 4], nrep))
             for o in oracles[:nrep]:
                 o.dispatch(rows[:, 1], rows[:, 4])
             for r, o in enumerate(oracles):
@@ -142,6 +150,13 @@ MODES = {
 def test_tiny_golden_per_tick(name, mode):
     g = load_golden(name)
     run_day(g, R=3, same_init=bool(len(g["dispatch_log"])), **MODES[mode])
+
+
+@pytest.mark.parametrize("name", ["tiny_dispatch", "tiny_dispatch_dfs2"])
+def test_device_resident_dispatch_tensor(name):
+    """vds_apply_dispatch_device: the reference-side dispatch log replayed as a GPU action tensor (with empty slots)."""
+    g = load_golden(name)
+    run_day(g, R=5, same_init=True, device_dispatch=True)
 
 
 @pytest.mark.parametrize("mode", ["fast", "generic"])

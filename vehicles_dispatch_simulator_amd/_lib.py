@@ -42,6 +42,7 @@ SYMBOLS = {
     "vds_reset_again": (C.c_int, [_VP]),
     "vds_step": (C.c_int, [_VP]),
     "vds_apply_dispatch": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    "vds_apply_dispatch_device": (C.c_int, [_VP, _I32, _VP]),
     "vds_advance": (C.c_int, [_VP]),
     "vds_run": (C.c_int, [_VP, _I32]),
     "vds_sync": (C.c_int, [_VP]),

@@ -22,6 +22,7 @@ void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, hipStream_t);
+void launch_dispatch_dense(const Static &, const State &, int, int, const int *, int, hipStream_t);
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
 void launch_selftest_dpp(const int *, int *, int *, int *, int *, int, hipStream_t);
@@ -992,6 +993,18 @@ static int read_vehicles_impl(vds_handle *h, int32_t replica, uint8_t *state, in
     return VDS_OK;
 }
 
+static int apply_dispatch_device_impl(vds_handle *h, int32_t K, const void *dev_actions) {
+    if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_apply_dispatch_device: call vds_reset first");
+    if (h->last_stepped != h->t) return fail(h, VDS_EINVAL, "vds_apply_dispatch_device: must follow vds_step of the current tick (the hook runs after Match, :1083)");
+    if (K == 0) return VDS_OK;
+    if (K < 0 || K > 64 || !dev_actions) return fail(h, VDS_EINVAL, "vds_apply_dispatch_device: K must be in [0, 64] and the action tensor non-null");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    launch_dispatch_dense(h->S, h->D, h->t, K, (const int *)dev_actions, h->dispatch_seq, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->dispatch_seq += K;
+    return VDS_OK;
+}
+
 // ---- exception-safe entry points
 int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
                       int32_t *seq_off, int32_t *seq, int64_t cap) {
@@ -1060,6 +1073,10 @@ int vds_create(const vds_config *cfg, vds_handle **out) {
 int vds_read_vehicles(vds_handle *h, int32_t replica, uint8_t *state, int32_t *node, int32_t *cluster,
                       int32_t *arrive_min, int32_t *order) {
     return guarded(h, "vds_read_vehicles", [&] { return read_vehicles_impl(h, replica, state, node, cluster, arrive_min, order); });
+}
+
+int vds_apply_dispatch_device(vds_handle *h, int32_t K, const void *dev_actions) {
+    return guarded(h, "vds_apply_dispatch_device", [&] { return apply_dispatch_device_impl(h, K, dev_actions); });
 }
 
 }  // extern "C"

@@ -1947,6 +1947,86 @@ __global__ void k_total_counters(int R, const long long *per, long long *tot) {
 
 // ---------------------------------------------------------------------------------------
 // launchers (called from vds_api.hip)
+// ---------------------------------------------------------------------------------------
+// k_dispatch_dense: the DispatchFunction body for EVERY replica from a device-resident action tensor
+// int32 [R][K][3] = {from_cluster, idle_pos, target_node} (from_cluster < 0: no action) - what a batched policy on
+// the GPU emits; no host round trip.  One wavefront per replica: its actions are grouped by cluster with one ballot
+// per bit of the cluster id; a group's vehicles are posted to their targets' arrival tables (dict insertion order =
+// action index) and the idle list is compacted once, order preserved.  Positions refer to the lists as they stand
+// before the call.  Same effects as k_dispatch.
+__global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t, int K, const int *actions, int seq_base) {
+    const int r = blockIdx.x;
+    const int lane = lane_id();
+    const int now = S.now0 + t * S.tick_minutes;
+    const int *act = actions + (size_t)r * K * 3;
+    for (int k0 = 0; k0 < K; k0 += WAVE) {
+        // one pass = up to 64 consecutive actions; passes see the lists left by the earlier ones, so an action's
+        // position must refer to the list before the CALL only within its pass: the host wrapper requires K <= 64
+        const int k = k0 + lane;
+        int cl = -1, pos = -1, tgt = 0;
+        if (k < K) { cl = act[k * 3]; pos = act[k * 3 + 1]; tgt = act[k * 3 + 2]; }
+        bool valid = cl >= 0;
+        if (valid && (cl >= S.C || tgt < 0 || tgt >= S.N)) { atomicOr(&D.err[0], ERR_DISPATCH); valid = false; }
+        const int tc = valid ? S.node2cluster[tgt] : -1;
+        if (valid && tc < 0) { atomicOr(&D.err[0], ERR_DISPATCH); valid = false; }
+        unsigned long long todo = ballot(valid);
+        unsigned long long same = todo;
+        for (int bit = 0; (1 << bit) < S.C; ++bit) {
+            const unsigned long long bb = ballot((cl >> bit) & 1);
+            same &= ((cl >> bit) & 1) ? bb : ~bb;
+        }
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned long long grp = ((unsigned long long)__builtin_amdgcn_readlane((int)(same & 0xFFFFFFFFu), leader)) |
+                                           ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(same >> 32), leader) << 32);
+            const int c = rdlane(cl, leader);
+            const size_t b = (size_t)c * S.R + r;
+            int *hdr = D.hdr + b * HDR_WORDS;
+            uint2 *idle = D.idle + b * S.idle_cap;
+            const int m = hdr[HDR_IDLE];
+            const bool mine = (grp >> lane) & 1ull;
+            bool ok = false;
+            int cst = 0;
+            if (mine) {
+                if (pos >= 0 && pos < m) {
+                    const uint2 e = idle[pos];
+                    cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
+                    post_arrival(S, D, tc, r, t, now, (int)e.x, seq_base + k, now + cst, 1, S.node_local[tgt]);
+                    ok = true;
+                } else {
+                    atomicOr(&D.err[0], ERR_DISPATCH);
+                }
+            }
+            int csum = cst;
+            for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o, WAVE);
+            const int ndone = popc64(ballot(ok));
+            wave_fence();
+            int newm = 0;
+            for (int base = 0; base < m; base += WAVE) {
+                const int i = base + lane;
+                bool keep = i < m;
+                for (unsigned long long rest = grp; rest; rest &= rest - 1)
+                    keep = keep && (rdlane(pos, __ffsll((long long)rest) - 1) != i);
+                const uint2 e = (i < m) ? idle[i] : make_uint2(0u, 0u);
+                const unsigned long long kb = ballot(keep);
+                wave_fence();
+                if (keep) idle[newm + popc64(kb & lanemask_lt())] = e;
+                newm += popc64(kb);
+                wave_fence();
+            }
+            if (m - newm != ndone && lane == 0) atomicOr(&D.err[0], ERR_DISPATCH);   // duplicate positions
+            if (lane == 0) {
+                hdr[HDR_IDLE] = newm;
+                long long *cnt = D.cnt + b * CNT_WORDS;
+                cnt[CNT_DISPATCH] += ndone;
+                cnt[CNT_DISPATCH_COST] += csum;
+            }
+            wave_fence();
+            todo &= ~grp;
+        }
+    }
+}
+
 void launch_reset(const Static &S, const State &D, const int *veh_node, hipStream_t st) {
     if (S.C <= 2048) {
         hipLaunchKernelGGL(k_reset_fast, dim3(S.R), dim3(RESET_WAVES * WAVE), (size_t)RESET_WAVES * S.C * sizeof(int), st, S, D, veh_node);
@@ -1994,6 +2074,10 @@ void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
 void launch_dispatch(const Static &S, const State &D, int t, int ngroups, const int *grp_off, const int *a_replica,
                      const int *a_cluster, const int *a_pos, const int *a_target, const int *a_seq, hipStream_t st) {
     hipLaunchKernelGGL(k_dispatch, dim3(ngroups), dim3(64), 0, st, S, D, t, ngroups, grp_off, a_replica, a_cluster, a_pos, a_target, a_seq);
+}
+
+void launch_dispatch_dense(const Static &S, const State &D, int t, int K, const int *actions, int seq_base, hipStream_t st) {
+    hipLaunchKernelGGL(k_dispatch_dense, dim3(S.R), dim3(64), 0, st, S, D, t, K, actions, seq_base);
 }
 
 void launch_pack_obs(const Static &S, const State &D, int t, int *obs, hipStream_t st) {

@@ -115,6 +115,17 @@ class BatchedDispatchEnv:
         a = [_i32(x).reshape(-1) for x in (replica, from_cluster, idle_pos, target_node)]
         self._chk(self._lib.vds_apply_dispatch(self._h, a[0].size, *[_p(x) for x in a]))
 
+    def apply_dispatch_torch(self, actions):
+        """Device-resident dispatch: ``actions`` is a contiguous int32 CUDA tensor ``[R, K, 3]`` of
+        ``(from_cluster, idle_pos, target_node)`` (``from_cluster < 0`` = empty slot, ``K <= 64``), e.g. the output
+        of a policy network.  Asynchronous, no host copy; the tensor must stay alive until the handle's stream has
+        passed the call and must have been produced on (or synchronised with) that stream."""
+        if tuple(actions.shape[:1]) != (self.R,) or actions.dim() != 3 or actions.shape[2] != 3:
+            raise Exception("apply_dispatch_torch: expected an int32 tensor [R, K, 3]")
+        if str(actions.dtype) != "torch.int32" or not actions.is_cuda or not actions.is_contiguous():
+            raise Exception("apply_dispatch_torch: expected a contiguous int32 CUDA tensor")
+        self._chk(self._lib.vds_apply_dispatch_device(self._h, int(actions.shape[1]), C.c_void_p(actions.data_ptr())))
+
     def advance(self):
         self._chk(self._lib.vds_advance(self._h))
 
