@@ -169,6 +169,14 @@ int vds_read_counters(vds_handle *h, int64_t *out);
  * all-reduce across GPUs) and, if out != NULL, copied to the host. */
 int vds_reduce_counters(vds_handle *h, int64_t *out, void **dev_ptr);
 
+/* Device-resident per-replica counters for zero-copy consumers (per-replica rewards of an RL loop): reduces the
+ * bucket-owned partial counters over clusters on the handle's stream and returns the device pointer of an
+ * int64 [replicas][8] block in DEVICE order
+ *   {OrderNum, RejectNum, TotallyWaitTime, sum OrderValue of matched orders, evaluations, arrivals seen by
+ *    UpdateFunction, DispatchNum, TotallyDispatchCost}
+ * (matched = OrderNum - RejectNum).  Asynchronous; overwritten by the next counter call. */
+int vds_counters_device(vds_handle *h, void **dev_ptr);
+
 /* As vds_reduce_counters, delivering the int64 [VDS_NUM_COUNTERS] totals of this handle's
  * replicas (raw device sums; VALUE_SUM = matched orders only) into caller-owned DEVICE memory,
  * asynchronously on the handle's stream - the send buffer of the cross-GPU RCCL all-reduce. */

@@ -259,4 +259,14 @@ def test_zero_copy_torch_observations_match_host_read():
     assert dev.shape == (5, 4, int(g["C"])) and dev.dtype == torch.int32 and dev.is_cuda
     for i, k in enumerate(("idle_pre", "idle_now", "supply", "cl_orders", "inflight")):
         np.testing.assert_array_equal(dev[i].cpu().numpy(), host[k])
+    # per-replica counters, zero copy (device order: orders, rejects, wait, matched value, evals, arrivals, dispatch, cost)
+    cn = env.counters()
+    ct = env.counters_torch()
+    torch.cuda.synchronize()
+    assert ct.shape == (4, 8) and ct.dtype == torch.int64 and ct.is_cuda
+    ct = ct.cpu().numpy()
+    np.testing.assert_array_equal(ct[:, 0], cn[:, 0]); np.testing.assert_array_equal(ct[:, 1], cn[:, 1])
+    np.testing.assert_array_equal(ct[:, 2], cn[:, 3]); np.testing.assert_array_equal(ct[:, 4], cn[:, 7])
+    np.testing.assert_array_equal(ct[:, 0] - ct[:, 1], cn[:, 2])
+    np.testing.assert_array_equal(ct[:, 6], cn[:, 4]); np.testing.assert_array_equal(ct[:, 7], cn[:, 5])
     env.close()

@@ -49,6 +49,7 @@ SYMBOLS = {
     "vds_clock": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
     "vds_read_obs": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "vds_obs_device": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "vds_counters_device": (C.c_int, [_VP, C.POINTER(_VP)]),
     "vds_read_counters": (C.c_int, [_VP, _VP]),
     "vds_reduce_counters": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     "vds_reduce_counters_into": (C.c_int, [_VP, _VP]),

@@ -759,6 +759,15 @@ static void finish_counters(const vds_handle *h, const long long *raw, int64_t *
     out[VDS_CNT_EVALS] = raw[CNT_EVALS];
 }
 
+int vds_counters_device(vds_handle *h, void **dev_ptr) {
+    if (!h || !h->have_reset || !dev_ptr) return fail(h, VDS_EINVAL, "vds_counters_device: bad argument / call order");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    launch_reduce_counters(h->S, h->D, h->d_cnt_per, h->d_cnt_tot, h->stream);
+    HIPCHK(h, hipGetLastError());
+    *dev_ptr = h->d_cnt_per;
+    return VDS_OK;
+}
+
 static int read_counters_impl(vds_handle *h, int64_t *out) {
     if (!h || !h->have_reset || !out) return fail(h, VDS_EINVAL, "vds_read_counters: bad argument / call order");
     HIPCHK(h, hipSetDevice(h->cfg.device));

@@ -168,6 +168,22 @@ class BatchedDispatchEnv:
                                         "version": 2, "strides": None}
         return torch.as_tensor(blk, device="cuda")
 
+    def counters_torch(self):
+        """Per-replica counters as a zero-copy ``torch`` int64 tensor ``[R, 8]`` on the GPU, in device order
+        ``(orders, rejects, wait_sum, matched_value_sum, evals, arrivals, dispatch_num, dispatch_cost)``;
+        aliases library memory, overwritten by the next counter call."""
+        import torch
+
+        p = C.c_void_p()
+        self._chk(self._lib.vds_counters_device(self._h, C.byref(p)))
+
+        class _Block:
+            pass
+
+        blk = _Block()
+        blk.__cuda_array_interface__ = {"shape": (self.R, 8), "typestr": "<i8", "data": (p.value, False), "version": 2, "strides": None}
+        return torch.as_tensor(blk, device="cuda")
+
     def counters(self) -> np.ndarray:
         out = np.zeros((self.R, _lib.NUM_COUNTERS), dtype=np.int64)
         self._chk(self._lib.vds_read_counters(self._h, _p(out)))
