@@ -2,7 +2,7 @@
 moves idle vehicles from the clusters with the largest surplus towards the clusters with the largest expected
 shortage, every replica with its own vehicle seed.  Observation -> policy -> action never leaves the device.
 
-    python examples/batched_dispatch_loop.py [replicas]"""
+    python examples/batched_dispatch_loop.py [replicas] [tiny|cfg2]        (cfg2 = the 192-cluster / 10k-vehicle bench city)"""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 from vehicles_dispatch_simulator_amd import workloads
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-w = workloads.tiny(N=600, C=24, vehicles=400, orders=12000)
+w = workloads.didi_day("cfg2") if (len(sys.argv) > 2 and sys.argv[2] == "cfg2") else workloads.tiny(N=600, C=24, vehicles=400, orders=12000)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
 some_node_of = torch.tensor([int(np.flatnonzero(w.city.node2cluster == c)[0]) for c in range(w.city.C)], dtype=torch.int32, device="cuda")
@@ -35,5 +35,6 @@ for t in range(env.T):
     env.advance()
 env.sync()
 cn = env.counters()
-print("replicas %d, %d ticks in %.2f s; rejects per replica: mean %.1f (min %d, max %d); dispatches %d" % (
-    R, env.T, time.time() - t0, cn[:, 1].mean(), cn[:, 1].min(), cn[:, 1].max(), int(cn[:, 4].sum())))
+dt = time.time() - t0
+print("replicas %d, %d ticks in %.2f s (%.3g env-steps*replicas/s incl. the torch policy); rejects per replica: mean %.1f (min %d, max %d); dispatches %d" % (
+    R, env.T, dt, R * env.T / dt, cn[:, 1].mean(), cn[:, 1].min(), cn[:, 1].max(), int(cn[:, 4].sum())))

@@ -1910,21 +1910,37 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
 // ---------------------------------------------------------------------------------------
 // Read-side helpers.
 // obs [5][R][C]: idle_pre, idle_now, supply, cl_orders, inflight.  `t` = tick last stepped.
-__global__ void k_pack_obs(Static S, State D, int t, int *obs) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S.R * S.C) return;
-    int r = i / S.C, c = i % S.C;
-    const size_t b = (size_t)c * S.R + r;
-    const int *h = D.hdr + b * HDR_WORDS;
+__global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int *obs) {
+    // state is cluster-major ([C][R]), the observation block replica-major ([5][R][C]): 16 x 16 tiles through LDS so
+    // that both the reads (16 consecutive replicas) and the writes (16 consecutive clusters) are 64-byte runs
+    __shared__ int tile[5][16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
     const size_t RC = (size_t)S.R * S.C;
-    int infl = h[HDR_FL] + h[HDR_INBOX0 + ((t + 1) & 1)];
-    for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
-    obs[0 * RC + i] = h[HDR_IDLE_PRE];
-    obs[1 * RC + i] = h[HDR_IDLE];
-    // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
-    obs[2 * RC + i] = (int)((unsigned)D.ring_cnt[(size_t)((t + 1) & (S.H - 1)) * RC + b] >> 16);
-    obs[3 * RC + i] = h[HDR_ORDERS];
-    obs[4 * RC + i] = infl;
+    {
+        const int r = r0 + tx, c = c0 + ty;
+        if (r < S.R && c < S.C) {
+            const size_t b = (size_t)c * S.R + r;
+            const int *h = D.hdr + b * HDR_WORDS;
+            int infl = h[HDR_FL] + h[HDR_INBOX0 + ((t + 1) & 1)];
+            for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
+            tile[0][ty][tx] = h[HDR_IDLE_PRE];
+            tile[1][ty][tx] = h[HDR_IDLE];
+            // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
+            tile[2][ty][tx] = (int)((unsigned)D.ring_cnt[(size_t)((t + 1) & (S.H - 1)) * RC + b] >> 16);
+            tile[3][ty][tx] = h[HDR_ORDERS];
+            tile[4][ty][tx] = infl;
+        }
+    }
+    __syncthreads();
+    {
+        const int r = r0 + ty, c = c0 + tx;
+        if (r < S.R && c < S.C) {
+            const size_t i = (size_t)r * S.C + c;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) obs[k * RC + i] = tile[k][tx][ty];
+        }
+    }
 }
 
 __global__ void k_reduce_counters(Static S, State D, long long *out) {
@@ -2081,8 +2097,7 @@ void launch_dispatch_dense(const Static &S, const State &D, int t, int K, const 
 }
 
 void launch_pack_obs(const Static &S, const State &D, int t, int *obs, hipStream_t st) {
-    int n = S.R * S.C;
-    hipLaunchKernelGGL(k_pack_obs, dim3((n + 255) / 256), dim3(256), 0, st, S, D, t, obs);
+    hipLaunchKernelGGL(k_pack_obs, dim3((S.R + 15) / 16, (S.C + 15) / 16), dim3(256), 0, st, S, D, t, obs);
 }
 
 void launch_reduce_counters(const Static &S, const State &D, long long *per, long long *tot, hipStream_t st) {
