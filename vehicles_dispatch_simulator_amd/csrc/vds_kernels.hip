@@ -1943,13 +1943,28 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
     }
 }
 
-__global__ void k_reduce_counters(Static S, State D, long long *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S.R * CNT_WORDS) return;
-    int r = i / CNT_WORDS, w = i % CNT_WORDS;
+__global__ __launch_bounds__(256) void k_reduce_counters(Static S, State D, long long *out) {
+    // 64 (replica, word) pairs per workgroup (consecutive addresses), the clusters split four ways and unrolled so that
+    // enough loads are in flight; partial sums meet in LDS
+    __shared__ long long part[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    const int n = S.R * CNT_WORDS;
     long long s = 0;
-    for (int c = 0; c < S.C; ++c) s += D.cnt[((size_t)c * S.R + r) * CNT_WORDS + w];
-    out[i] = s;
+    if (i < n) {
+        const int per = (S.C + 3) / 4;
+        const int c0 = slice * per, c1 = min(S.C, c0 + per);
+        const long long *p = D.cnt + i;
+        const size_t stride = (size_t)S.R * CNT_WORDS;
+        int c = c0;
+        for (; c + 4 <= c1; c += 4) {
+            const long long a0 = p[(size_t)c * stride], a1 = p[(size_t)(c + 1) * stride], a2 = p[(size_t)(c + 2) * stride], a3 = p[(size_t)(c + 3) * stride];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; c < c1; ++c) s += p[(size_t)c * stride];
+    }
+    part[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && i < n) out[i] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 __global__ void k_total_counters(int R, const long long *per, long long *tot) {
@@ -2102,7 +2117,7 @@ void launch_pack_obs(const Static &S, const State &D, int t, int *obs, hipStream
 
 void launch_reduce_counters(const Static &S, const State &D, long long *per, long long *tot, hipStream_t st) {
     int n = S.R * CNT_WORDS;
-    hipLaunchKernelGGL(k_reduce_counters, dim3((n + 255) / 256), dim3(256), 0, st, S, D, per);
+    hipLaunchKernelGGL(k_reduce_counters, dim3((n + 63) / 64), dim3(256), 0, st, S, D, per);
     hipLaunchKernelGGL(k_total_counters, dim3(CNT_WORDS), dim3(64), 0, st, S.R, per, tot);
 }
 
