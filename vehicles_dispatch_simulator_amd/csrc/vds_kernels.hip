@@ -1697,7 +1697,11 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                 mj = m_l[cj];
                 moj = moff_l[cj];
                 m0j = mj > 0 ? moff_l[cj + 1] - moj : 0;
-                if (mj > 0) atomicAdd(&ev_l[pc], mj);    // :986-991 runs for every visited cluster
+            }
+            {   // :986-991 runs for every visited cluster: its live vehicles count as evaluations of order LB
+                const int rs = row_sum_i32(mj);
+                const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
+                if (lane == 0 && tot) atomicAdd(&ev_l[pc], tot);
             }
             // slots = (cluster j of this wavefront, 64-entry chunk b of its list), walked in (j, b) order, eight cost
             // gathers in flight per lane.  key = cost << 16 | j << 9 | b: with the lane as the last tie-break this
