@@ -15,7 +15,7 @@ kern = sys.argv[2] if len(sys.argv) > 2 else "k_tick_rows"
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-st = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+st = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # gpurun merges runs: newest
 shutil.copy(st, os.path.join(dst, "kernel_stats.csv"))
 out = {"_note": "rocprofv3 --pmc, one pass per group (FETCH_SIZE | WRITE_SIZE | SQ_* ...), per-launch means for kernels matching '%s'; "
                 "FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads by up to 2x on gfx950 "
@@ -24,7 +24,7 @@ for name in ("fetch", "write", "sq", "sq2"):
     fs = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
     if not fs:
         continue
-    df = pd.read_csv(fs[0])
+    df = pd.read_csv(max(fs, key=os.path.getmtime))
     k = df[df["Kernel_Name"].str.contains(kern, regex=False)]
     g = k.groupby("Counter_Name")["Counter_Value"].agg(["mean", "count"])
     for n, row in g.iterrows():
