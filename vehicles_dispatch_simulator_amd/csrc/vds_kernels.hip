@@ -1265,17 +1265,21 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
 //     ("original positions"); LDS holds a u16 mirror of them: the cost-matrix column of every entry's node, or
 //     DEAD once the vehicle has been taken.  List order == original order, so "first strict minimum" is still
 //     the lowest position.
-//   * own-cluster matching runs on 8-LANE GROUPS, one bucket per group: all candidates of an order are gathered
-//     in one round trip (<= 8 per lane in flight), three DPP steps give the group minimum of (cost << 16 | pos).
-//     The 32 groups of a workgroup advance 32 buckets concurrently instead of one bucket per wavefront at a time.
+//   * own-cluster matching runs on 8-LANE GROUPS, one bucket per group, fed by per-wavefront worklists of the
+//     buckets that have orders older than LB: lists of up to 96 entries sit in the group's registers (12 per
+//     lane), all candidates of an order are gathered in one round trip, three DPP steps give the group minimum
+//     of (cost << 16 | position).  A workgroup advances up to 32 buckets concurrently.
 //   * the neighbour search reads its cluster list once per wavefront (lane j = j-th candidate cluster), prefetched
-//     together with the dry order's pickup node BEFORE the own-cluster pass; candidates carry one 64-bit key
-//     (cost, visit position | list position, cluster), reduced with two DPP wave minima.
+//     together with the dry order's pickup node BEFORE the own-cluster pass; it walks (cluster, 64-entry chunk)
+//     slots eight at a time - all LDS reads, then all cost gathers, then the minima of 32-bit keys
+//     cost << 16 | slot (lane = last tie-break) - and hands (cost, visit position | list position, cluster) to
+//     the winner step.
+//   * Update is row-mapped: four buckets per wavefront, arrivals ranked by dict-insertion key with DPP rotations.
 //   * results are written in a preliminary form {victim cluster << 16 | original position, wait}; after the
 //     last round one thread per order resolves the vehicle id from the untouched HBM list, posts the arrival
 //     (:954-960) and accumulates the counters, and one wavefront per bucket compacts the HBM list once (:963).
 // Preconditions (Static / vds_api dfs2_ok): order ids < 2^20, clusters <= 2047 nodes, 0 <= cost < 2^15,
-// V <= 20480, N <= 65535, C <= 3072, idle_cap <= 32767, < 32768 orders per tick.
+// V <= 20480, N <= 65534, C <= 3072, idle_cap <= 32767, < 32768 orders per tick; otherwise k_tick_replica runs.
 #define ID_BITS 20
 #define ID_MASK ((1 << ID_BITS) - 1)
 #define GRP 8                               // lanes per own-cluster group
