@@ -95,7 +95,9 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
 
 /* self.Orders after CreateAllInstantiate (:325-342): Order.ID == array index (:334-335,:973),
  * OrderValue = RoadCost(pickup, delivery) (:341-342) is computed inside.  The order stream is
- * shared by all replicas.  Also fixes the tick grid of SimCity (:1037-1040). */
+ * shared by all replicas.  Also fixes the tick grid of SimCity (:1037-1040).
+ * May be called again to replace the day on the same handle (Reload, :130-212): the static tables stay on the
+ * device, the per-replica state tables are kept while their capacities still fit, vds_reset must follow. */
 int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pickup,
                     const int32_t *delivery, int32_t O);
 

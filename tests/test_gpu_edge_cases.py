@@ -153,3 +153,34 @@ def test_handles_on_their_own_streams_advance_independently():
             for k in ("status", "vehicle", "wait"):
                 np.testing.assert_array_equal(got[k][r], exp[k], err_msg="%d %s" % (r, k))
         e.close()
+
+
+def test_another_day_on_the_same_handle():
+    """vds_load_orders again (Reload, simulator.py:130-212): the day changes, the static tables and - while they
+    still fit - the state tables stay; results equal those of a fresh handle / the oracle, in both directions."""
+    g = load_golden("tiny_kmeans")
+    R, V, N = 3, int(g["V"]), int(g["N"])
+    init = np.stack([synth.init_vehicle_nodes(random.Random(90 + r), N, V) for r in range(R)])
+    start, pick2, dele2 = synth.make_orders(4242, N, 3500)            # a longer, different day for the same city
+    rel2 = synth.release_minutes(start)
+    days = [(g["o_release_min"], g["o_pickup"], g["o_delivery"]), (rel2, pick2, dele2), (g["o_release_min"], g["o_pickup"], g["o_delivery"])]
+    env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=V)
+    first = None
+    for d, (rel, pk, dl) in enumerate(days):
+        env.load_orders(rel, pk, dl)
+        with pytest.raises(Exception, match="vds_reset"):
+            env.step()
+        env.reset(init)
+        env.run(env.T)
+        got, cn = env.orders(), env.counters()
+        for r in range(R):
+            o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], 0, False, rel, pk, dl, V)
+            o.reset(init[r]); assert o.run_day() == env.T
+            exp, oc = o.orders(), o.counters()
+            for k in ("status", "vehicle", "wait"):
+                np.testing.assert_array_equal(got[k][r], exp[k], err_msg="day %d replica %d %s" % (d, r, k))
+            assert cn[r, 0] == oc["order_num"] and cn[r, 1] == oc["reject_num"] and cn[r, 3] == oc["wait_sum"] and cn[r, 6] == oc["sum_order_value"]
+        if d == 0:
+            first = got["vehicle"].copy()
+    np.testing.assert_array_equal(got["vehicle"], first)      # day 1 again after day 2: identical
+    env.close()

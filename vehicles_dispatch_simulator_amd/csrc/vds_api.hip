@@ -56,7 +56,10 @@ struct vds_handle {
     std::vector<int> o_tick;             // order id -> tick (or -1 never processed)
     std::vector<long long> value_upto;   // [T+1] prefix of OrderValue of processed orders by tick
     long long value_all = 0;
-    std::vector<void *> dev_allocs;
+    std::vector<void *> dev_allocs;          // static tables, scratch
+    std::vector<void *> order_allocs;        // tables of the loaded day (replaced by the next vds_load_orders)
+    std::vector<void *> state_allocs;        // per-replica state (kept across days while the capacities still fit)
+    std::vector<void *> *alloc_sink = nullptr;
     // device scratch
     int *d_veh_node = nullptr;
     int *d_obs = nullptr;
@@ -92,7 +95,7 @@ static int dev_alloc(vds_handle *h, T **p, size_t n) {
     if (n == 0) n = 1;
     hipError_t e = hipMalloc((void **)p, n * sizeof(T));
     if (e != hipSuccess) return fail(h, VDS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-    h->dev_allocs.push_back((void *)*p);
+    (h->alloc_sink ? *h->alloc_sink : h->dev_allocs).push_back((void *)*p);
     return VDS_OK;
 }
 
@@ -228,6 +231,8 @@ int vds_destroy(vds_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->dev_allocs) (void)hipFree(p);
+    for (void *p : h->order_allocs) (void)hipFree(p);
+    for (void *p : h->state_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -423,9 +428,15 @@ static int alloc_state(vds_handle *h, int O) {
     ring_cap = round_up(ring_cap, 16);
     if (ring_cap > 65520) return fail(h, VDS_EINVAL, "ring_cap=%d > 65520 unsupported", ring_cap);
     int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
+    if (!h->state_allocs.empty() && S.idle_cap == idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap)
+        return VDS_OK;                                   // another day on the same handle: the state tables still fit
+    for (void *p : h->state_allocs) (void)hipFree(p);
+    h->state_allocs.clear();
     S.idle_cap = idle_cap; S.fl_cap = far_cap; S.in_cap = far_cap; S.H = H; S.ring_cap = ring_cap;
     const size_t B = (size_t)C * R;
     int rc;
+    struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
+    h->alloc_sink = &h->state_allocs;
     if ((rc = dev_alloc(h, &D.hdr, B * HDR_WORDS))) return rc;
     if ((rc = dev_alloc(h, &D.cnt, B * CNT_WORDS))) return rc;
     if ((rc = dev_alloc(h, &D.idle, B * idle_cap))) return rc;
@@ -446,9 +457,18 @@ static int alloc_state(vds_handle *h, int O) {
 
 static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
     if (!h || !h->have_static) return fail(h, VDS_EINVAL, "vds_load_orders: call vds_load_static first");
-    if (h->have_orders) return fail(h, VDS_EINVAL, "vds_load_orders: orders already loaded (create a new handle)");
     if (O < 1 || !release_min || !pickup || !delivery) return fail(h, VDS_EINVAL, "vds_load_orders: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->have_orders) {
+        // another day on the same handle (Reload, :130-212): the previous day's tables go, the static tables stay,
+        // the state tables stay while their capacities still fit; vds_reset must follow
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (void *p : h->order_allocs) (void)hipFree(p);
+        h->order_allocs.clear();
+        h->have_orders = false; h->have_reset = false;
+        h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
+        h->err.clear();
+    }
     Static &S = h->S;
     const int N = S.N, C = S.C, tick = S.tick_minutes;
     // SimCity prologue :1037-1040
@@ -511,6 +531,8 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
     int rc;
     int *d;
     int4 *d4;
+    struct Sink { vds_handle *h; ~Sink() { h->alloc_sink = nullptr; } } sink{h};
+    h->alloc_sink = &h->order_allocs;
     if ((rc = upload(h, &d4, so_rec))) return rc; S.so_rec = d4;
     if ((rc = upload(h, &d, bkt_off))) return rc; S.bkt_off = d;
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;
@@ -519,6 +541,7 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
     for (int t = 0; t < T; ++t) S.max_tick_orders = std::max(S.max_tick_orders, tick_off[t + 1] - tick_off[t]);
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
     if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(n_proc, 1)))) return rc;
+    h->alloc_sink = nullptr;
     if ((rc = alloc_state(h, O))) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
         const Static &Z = h->S;

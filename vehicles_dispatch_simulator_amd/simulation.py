@@ -206,12 +206,16 @@ class Simulation(object):
         if self.Vehicles is None:
             self.Vehicles = [Vehicle(self, i, W.driver_ids[i]) for i in range(V)]
         off, idx = neighbors_to_csr(W.neighbors)
-        if self.env is not None:
-            self.env.close()
-        self.env = BatchedDispatchEnv(W.cost, W.node2cluster, off, idx, replicas=self.Replicas, vehicles=V,
-                                      depth_limit=self.NeighborServerDeepLimit, neighbor_can_server=self.NeighborCanServer,
-                                      tick_minutes=self._tick_minutes, reject_threshold=PICKUP_REJECT_THRESHOLD,
-                                      device=self.Device, **self._device_kwargs)
+        if self.env is not None and getattr(self, "_env_world", None) is W:
+            pass                      # Reload: same city, another day - the handle keeps its static tables
+        else:
+            if self.env is not None:
+                self.env.close()
+            self.env = BatchedDispatchEnv(W.cost, W.node2cluster, off, idx, replicas=self.Replicas, vehicles=V,
+                                          depth_limit=self.NeighborServerDeepLimit, neighbor_can_server=self.NeighborCanServer,
+                                          tick_minutes=self._tick_minutes, reject_threshold=PICKUP_REJECT_THRESHOLD,
+                                          device=self.Device, **self._device_kwargs)
+            self._env_world = W
         self.env.load_orders(rel, W.o_pickup, W.o_delivery)
 
     def Reload(self, OrderFileDate="1101"):
