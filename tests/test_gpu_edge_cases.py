@@ -115,6 +115,13 @@ def test_api_misuse_is_reported_not_fatal():
         env.step()
     with pytest.raises(Exception, match="replica range"):
         env.orders(1, 5)
+    with pytest.raises(Exception, match="replica out of range"):
+        env.vehicles(7)
+    import ctypes as C
+    assert env._lib.vds_apply_dispatch_device(env._h, 65, C.c_void_p(1)) != 0          # K > 64
+    assert env._lib.vds_apply_dispatch_device(env._h, 4, None) != 0                    # no tensor
+    assert env._lib.vds_counters_device(env._h, None) != 0
+    assert env._lib.vds_main_kernel(env._h) == b"k_tick_rows"
     env.close()
 
 
