@@ -1714,27 +1714,29 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
             int b = 0, best = IMAX;
             while (live != 0) {
                 // branch-free in three passes, so that the eight LDS reads and then the eight gathers are issued
-                // back to back instead of one dependent chain per slot
-                int cl[8], cst[8], seq[8];
-                bool in[8];
+                // back to back instead of one dependent chain per slot (integer flags and byte offsets on purpose:
+                // bool && and 64-bit indexing make the compiler fall back to exec-mask branches)
+                int cl[8], cst[8], seq[8], in[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    in[k] = false; cl[k] = DEAD; seq[k] = 0;
+                    in[k] = 0; cl[k] = DEAD; seq[k] = 0;
                     if (live != 0) {
                         const int j = __ffsll((long long)live) - 1;
                         const int m0c = rdlane(m0j, j), moc = rdlane(moj, j);
                         const int i = b * WAVE + lane;
-                        in[k] = i < m0c;
+                        in[k] = i < m0c ? 1 : 0;
                         cl[k] = mirror[moc + min(i, m0c - 1)];
                         seq[k] = (j << 9) | b;
                         ++b;
                         if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
                     }
                 }
+                const char *crow_b = reinterpret_cast<const char *>(crow);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    in[k] = in[k] && cl[k] != DEAD;
-                    cst[k] = crow[in[k] ? cl[k] : 0];
+                    in[k] &= cl[k] != DEAD ? 1 : 0;
+                    const unsigned off = (unsigned)(in[k] ? cl[k] : 0) << 2;
+                    cst[k] = *reinterpret_cast<const int *>(crow_b + off);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
