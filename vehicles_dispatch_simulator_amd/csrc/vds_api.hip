@@ -43,6 +43,7 @@ struct vds_handle {
     bool have_static = false, have_orders = false, have_reset = false;
     bool dfs_mode = false;
     bool dfs2_ok = false;   // k_tick_replica2 preconditions hold (see vds_kernels.hip)
+    long long blk_ints = 0; // total size of the per-cluster cost blocks
     int cost_min = 0, cost_max = 0;
     int depth_limit = 0;
     int t = 0;              // self.step
@@ -331,6 +332,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         blk_off[c + 1] = blk_off[c] + (nc * nc + 3) / 4 * 4;   // 16-byte aligned blocks
     }
     if (blk_off[C] >= (1ll << 31)) return fail(h, VDS_EINVAL, "vds_load_static: cluster cost blocks exceed 2^31 entries");
+    h->blk_ints = blk_off[C];
     std::vector<int4> cdesc(C);
     for (int c = 0; c < C; ++c) cdesc[c] = make_int4(h->cl_off[c + 1] - h->cl_off[c], (int)blk_off[c], 0, 0);
     std::vector<int> blk((size_t)blk_off[C]);
@@ -548,7 +550,7 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
         const int ids2 = std::max(Z.max_tick_orders, 4 * Z.C);
         const size_t lds2 = ((size_t)9 * Z.C + 1 + ids2 + ((size_t)Z.V + 2) / 2) * sizeof(int) + 2048;   // + static shared
         h->dfs2_ok = h->dfs_mode && O <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 15) &&
-                     Z.V <= 20480 && Z.N <= 65534 && Z.C <= 3072 && Z.idle_cap <= 32767 && Z.max_tick_orders < 32768 &&
+                     Z.V <= 20480 && Z.N <= 65534 && Z.C <= 3072 && h->blk_ints < (1ll << 29) && Z.idle_cap <= 32767 && Z.max_tick_orders < 32768 &&
                      lds2 <= 64 * 1024;
     }
     h->have_orders = true;

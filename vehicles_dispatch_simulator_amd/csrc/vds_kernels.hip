@@ -1558,7 +1558,9 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                 const int qe = qend_l[c];
                 const int cda = cdA_l[c];
                 const int nc = cda & 2047;
-                const int *blk = S.blk + cdB_l[c] - ((cda >> 11) & 0xFFFF);    // row[column] with the mirror's matrix columns
+                // cost of (pickup p, idle entry) = S.blk[boff + p * nc + column]: 32-bit offsets from one uniform base
+                const int boff = cdB_l[c] - ((cda >> 11) & 0xFFFF);
+                const char *blk_b = reinterpret_cast<const char *>(S.blk);
                 const int mo = moff_l[c], m0 = act ? moff_l[c + 1] - mo : 0;
                 int m = m_l[c], evals = 0;
                 // longest list among this wavefront's buckets of this step: bounds the (uniform) slot loops
@@ -1591,11 +1593,15 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                         for (int o = 0; o < OB; ++o) {
                             const bool oo = (idw[o] & ID_MASK) < LB && idw[o] != IMAX;
                             const bool any = ballot(oo) != 0;       // usually one pending order: one row of gathers
-                            const int *row = blk + (size_t)(oo ? (idw[o] >> ID_BITS) : 0) * nc;
+                            const int rowoff = boff + (oo ? (idw[o] >> ID_BITS) : 0) * nc;
+                            const unsigned take = oo ? amask : 0u;
 #pragma unroll
                             for (int u = 0; u < SLOTS; ++u) {
                                 cst[o][u] = 0;
-                                if (any && u * GRP < mmaxw) cst[o][u] = *((oo && ((amask >> u) & 1u)) ? row + col[u] : S.blk);
+                                if (any && u * GRP < mmaxw) {
+                                    const unsigned off = (unsigned)(((take >> u) & 1u) ? rowoff + col[u] : 0) << 2;
+                                    cst[o][u] = *reinterpret_cast<const int *>(blk_b + off);
+                                }
                             }
                         }
 #pragma unroll
@@ -1633,18 +1639,18 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                     while (ballot(act) != 0) {
                         int key = IMAX;
                         if (act && m > 0) {
-                            const int *row = blk + (size_t)(idw >> ID_BITS) * nc;
+                            const int rowoff = boff + (idw >> ID_BITS) * nc;
                             for (int i0 = 0; i0 < m0; i0 += 8 * GRP) {
-                                int cl[8], cst[8];
-                                bool ok[8];
+                                int cl[8], cst[8], ok[8];
 #pragma unroll
                                 for (int u = 0; u < 8; ++u) {
                                     const int i = i0 + u * GRP + gl;
                                     cl[u] = mirror[mo + min(i, m0 - 1)];
-                                    ok[u] = i < m0 && cl[u] != DEAD;
+                                    ok[u] = (i < m0 ? 1 : 0) & (cl[u] != DEAD ? 1 : 0);
                                 }
 #pragma unroll
-                                for (int u = 0; u < 8; ++u) cst[u] = *(ok[u] ? row + cl[u] : S.blk);
+                                for (int u = 0; u < 8; ++u)
+                                    cst[u] = *reinterpret_cast<const int *>(blk_b + ((unsigned)(ok[u] ? rowoff + cl[u] : 0) << 2));
 #pragma unroll
                                 for (int u = 0; u < 8; ++u)
                                     key = min(key, ok[u] ? (cst[u] << 16) | (i0 + u * GRP + gl) : IMAX);
