@@ -1509,6 +1509,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
         if (evals) ev_l[c] += evals;
     };
 
+    const int thr32 = S.reject_threshold > 0x7FFF ? 0x7FFF : (S.reject_threshold < 0 ? -1 : (int)S.reject_threshold);   // costs < 2^15 here
     const int gl = lane & (GRP - 1);              // lane within its group
     const int gw = lane / GRP;                    // group within the wavefront
     const int CW = (C + REPL_WAVES - 1) / REPL_WAVES;     // buckets owned by one wavefront
@@ -1609,14 +1610,15 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
                             const bool oo = act && idw[o] != IMAX && (idw[o] & ID_MASK) < LB;
                             if (ballot(oo) == 0) break;
                             int key = IMAX;
+                            const unsigned take = oo ? amask : 0u;
 #pragma unroll
                             for (int u = 0; u < SLOTS; ++u)
-                                if (u * GRP < mmaxw && oo && ((amask >> u) & 1u)) key = min(key, (cst[o][u] << 16) | (u * GRP + gl));
+                                if (u * GRP < mmaxw) key = min(key, ((take >> u) & 1u) ? (cst[o][u] << 16) | (u * GRP + gl) : IMAX);
                             key = grp_min_i32(key);
                             if (oo) {
                                 evals += m;
                                 int2 res = make_int2(-1, -1);
-                                if (key != IMAX && (long long)(key >> 16) <= S.reject_threshold) {     // :943 (quirk Q3)
+                                if (key != IMAX && (key >> 16) <= thr32) {     // :943 (quirk Q3)
                                     const int pos = key & 0xFFFF;
                                     if ((pos & (GRP - 1)) == gl) amask &= ~(1u << (pos / GRP));
                                     if (gl == 0) mirror[mo + pos] = DEAD;
