@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_reset(Static S, State D, const int *veh
 __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, State D, const int *veh_node) {
     extern __shared__ int lds_dyn[];
     const int r = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave-uniform: keep it scalar
     const int C = S.C;
     const int seg = (((S.V + RESET_WAVES - 1) / RESET_WAVES) + WAVE - 1) / WAVE * WAVE;
     const int v0 = min(S.V, wave * seg), v1 = min(S.V, v0 + seg);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_tick(Static S, State D, int t, int lds_
     extern __shared__ int lds_dyn[];
     const int c = blockIdx.x % S.C;
     const int chunk = blockIdx.x / S.C;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int nc = S.cl_off[c + 1] - S.cl_off[c];
     const int q0 = DO_MATCH ? S.bkt_off[(size_t)t * S.C + c] : 0;
     const int k = DO_MATCH ? S.bkt_off[(size_t)t * S.C + c + 1] - q0 : 0;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE) void k_tick_rows(Static S, State
     const int4 cd = S.cdesc_ord[blockIdx.x / nchunks];
     const int c = cd.z;
     const int chunk = blockIdx.x % nchunks;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int lane = lane_id();
     const int g = lane >> 4, l16 = lane & 15;
     const int p = t & 1;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
     __shared__ int s_lb, s_lbc;
     __shared__ int s_cand[REPL_WAVES][4];
     const int r = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave-uniform: keep it scalar
     const int p = t & 1;
     const int now = S.now0 + t * S.tick_minutes;
     const int tq0 = S.bkt_off[(size_t)t * C], tq1 = S.bkt_off[(size_t)(t + 1) * C];
@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica2(Static S, State 
     __shared__ int s_cand[REPL_WAVES][2];
     __shared__ int s_wl[REPL_WAVES][WAVE];      // per-wavefront worklist of buckets with pending orders older than LB
     const int r = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave-uniform: keep it scalar
     const int p = t & 1;
     const int now = S.now0 + t * S.tick_minutes;
     const int tq0 = S.bkt_off[(size_t)t * C], tq1 = S.bkt_off[(size_t)(t + 1) * C];
