@@ -794,6 +794,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     const bool any = ballot(rowvalid) != 0;
     const bool big = ballot(m + A > 64) != 0;
     const bool big96 = ballot(m + A > 96) != 0;
+    const bool small32 = ballot(m + A > 32) == 0;
     // 2. stage the cluster's cost block and the bucket's order records in LDS
     if (blk_in_lds && k > 0) {
         // 16-byte loads, three in flight per thread before the first LDS store (blocks are padded to 4 ints)
@@ -822,6 +823,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
         PROF_STAMP(0);
         if (big && !big96) rows_body<6>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
         else if (big) rows_body<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (small32) rows_body<2>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
         else rows_body<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
     }
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
