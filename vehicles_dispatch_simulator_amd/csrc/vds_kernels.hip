@@ -674,16 +674,19 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         const int4 *ring = D.ring + si * S.ring_cap;
         int4 e[4];
         unsigned long long key[4];
+        const int Amax = max(max(rdlane(A, 0), rdlane(A, 16)), max(rdlane(A, 32), rdlane(A, 48)));
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int idx = a * 16 + l16;
             e[a] = make_int4(0, 0, 0, 0);
-            if (idx < A) e[a] = ring[idx];
-            key[a] = entry_key(e[a].y, e[a].w);
-            if (idx < A) key_row[idx] = key[a];
+            key[a] = 0;
+            if (a * 16 < Amax) {           // wave-uniform: usually only the first 16 arrival slots exist
+                if (idx < A) e[a] = ring[idx];
+                key[a] = entry_key(e[a].y, e[a].w);
+                if (idx < A) key_row[idx] = key[a];
+            }
         }
         wave_fence();
-        const int Amax = max(max(rdlane(A, 0), rdlane(A, 16)), max(rdlane(A, 32), rdlane(A, 48)));
         int rank[4] = {0, 0, 0, 0};
         if (Amax <= 16) {           // common case: one arrival per lane
 #pragma unroll 4
@@ -704,7 +707,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int idx = a * 16 + l16;
-            if (idx < A) arr_row[rank[a]] = make_uint2((unsigned)e[a].x, (unsigned)meta_dest(e[a].w));
+            if (a * 16 < Amax && idx < A) arr_row[rank[a]] = make_uint2((unsigned)e[a].x, (unsigned)meta_dest(e[a].w));
         }
         if (rowvalid && l16 == 0 && A > 0) D.ring_cnt[si] = 0;
         wave_fence();
