@@ -395,7 +395,20 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cdesc[a].x > cdesc[b].x; });
         if ((rc = upload(h, &d, corder))) return rc; S.corder = d;
         std::vector<int4> cdo(C);
-        for (int i = 0; i < C; ++i) cdo[i] = make_int4(cdesc[corder[i]].x, cdesc[corder[i]].y, corder[i], 0);
+        // byte copy of the blocks for the fast kernel (filled below once the cost range is known)
+        std::vector<long long> b8off(C + 1, 0);
+        for (int c = 0; c < C; ++c) { long long nc = cdesc[c].x; b8off[c + 1] = b8off[c] + (nc * nc + 15) / 16 * 16; }
+        bool u8 = b8off[C] < (1ll << 31);
+        for (size_t i = 0; i < blk.size() && u8; ++i) u8 = blk[i] >= 0 && blk[i] <= 255;
+        S.u8_ok = u8 ? 1 : 0;
+        std::vector<unsigned char> blk8(u8 ? (size_t)b8off[C] : 1, 0);
+        if (u8)
+            for (int c = 0; c < C; ++c) {
+                const long long nc = cdesc[c].x;
+                for (long long e = 0; e < nc * nc; ++e) blk8[(size_t)b8off[c] + e] = (unsigned char)blk[(size_t)cdesc[c].y + e];
+            }
+        { unsigned char *d8; if ((rc = upload(h, &d8, blk8))) return rc; S.blk8 = d8; }
+        for (int i = 0; i < C; ++i) cdo[i] = make_int4(cdesc[corder[i]].x, cdesc[corder[i]].y, corder[i], u8 ? (int)b8off[corder[i]] : 0);
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
     }
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;

@@ -23,6 +23,7 @@
 // "lowest position wins": a match is a row-wide DPP min-reduction of (cost << 7 | position).
 // No MFMA: this is index / gather / scan work.
 #include "vds_device.h"
+#include <type_traits>
 #include <cstring>
 
 namespace vds {
@@ -533,8 +534,8 @@ __device__ __forceinline__ void rows_load_idle(const uint2 *idle, int l16, int m
     }
 }
 
-template <int J>
-__device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const int *lds_blk, int nc,
+template <int J, typename CT>
+__device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, const uint2 *arr_row, int r, bool rowvalid, size_t b, int m, int A,
                                            uint2 *idle, long long cntv, unsigned (&veh)[J], int (&loc)[J], bool prof, unsigned long long tprev, int pwave) {
     const int lane = lane_id();
@@ -568,11 +569,11 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         const int kk = min(16, k - jj * 16);
         for (int ji = 0; ji < kk; ++ji) {
             const int p = rdlane(recy, jj * 16 + ji) & 0xFFFF;
-            const int *row = lds_blk + p * nc;
+            const CT *row = lds_blk + p * nc;
             int best = IMAX;
 #pragma unroll
             for (int s = 0; s < J; ++s) {
-                const int v = ((row[loc[s]] << 7) | (l16 * J + s)) | dead[s];
+                const int v = (((int)row[loc[s]] << 7) | (l16 * J + s)) | dead[s];
                 best = min(best, v);
             }
             const int rmin = row_min_i32(best);
@@ -657,8 +658,8 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     PROF_STAMP(6);
 }
 
-template <int J>
-__device__ __forceinline__ void rows_body(const Static &S, const State &D, int t, int now, int q0, int k, const int *lds_blk, int nc,
+template <int J, typename CT>
+__device__ __forceinline__ void rows_body(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
                                           const int4 *lds_rec, unsigned long long *key_row, int r, bool rowvalid, size_t b, size_t si,
                                           int m, int A, long long cntv, bool prof, unsigned long long tprev, int pwave) {
     const int l16 = lane_id() & 15;
@@ -727,7 +728,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         }
         return;
     }
-    rows_match<J>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
+    rows_match<J, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
 }
 
 #ifndef ROWS_WAVES
@@ -737,13 +738,18 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #ifndef ROWS_MIN_WAVES
 #define ROWS_MIN_WAVES 7
 #endif
+// U8: every cost fits a byte (Static.u8_ok): the cluster block is staged and read as bytes - a quarter of the L2 -> LDS
+// traffic, one 16-byte load per thread for blocks of up to 64 nodes
+template <bool U8>
 __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+    typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
     // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
     // the ranked arrivals) | cost block
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
     unsigned long long *scr_all = reinterpret_cast<unsigned long long *>(lds_rec + 64);
-    int *lds_blk = reinterpret_cast<int *>(scr_all + ROWS_WAVES * 4 * ROW_KEYS);
+    CT *lds_blk = reinterpret_cast<CT *>(scr_all + ROWS_WAVES * 4 * ROW_KEYS);
+    const int lds_elems = U8 ? lds_ints * 4 : lds_ints;       // capacity of the block area in cost entries
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
     // (keeping all chunks of a cluster on one XCD - blockIdx & 7 - was measured: 99 us vs 93 us, the XCDs lose the
@@ -781,13 +787,13 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     const int q0 = S.bkt_off[(size_t)t * S.C + c];
     const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
     const int now = S.now0 + t * S.tick_minutes;
-    const bool wg_ok = nc * nc <= lds_ints && k <= 64;
+    const bool wg_ok = nc * nc <= lds_elems && k <= 64;
     // rows the register tables cannot hold (or that own far arrivals): handled after the fast rows by this
     // same wavefront with the generic per-bucket code (cost block already in LDS); only when the block does
     // not fit LDS do they go to the worklist of k_tick_work.  Nothing of theirs is touched by the fast path.
     const int mnew0 = m + A;
     const bool bad = rowvalid && (!wg_ok || far != 0 || A > ROW_KEYS || A > S.ring_cap || mnew0 > ROW_MAXM || mnew0 > S.idle_cap);
-    const bool blk_in_lds = nc * nc <= lds_ints;
+    const bool blk_in_lds = nc * nc <= lds_elems;
     if (bad && !blk_in_lds && l16 == 0) {
         int slot = atomicAdd(&D.work[p], 1);
         D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
@@ -801,20 +807,24 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     // 2. stage the cluster's cost block and the bucket's order records in LDS
     if (blk_in_lds && k > 0) {
         // 16-byte loads, three in flight per thread before the first LDS store (blocks are padded to 4 ints)
-        const int4 *blk4 = reinterpret_cast<const int4 *>(S.blk + cd.y);
+        const int4 *blk4 = U8 ? reinterpret_cast<const int4 *>(S.blk8 + cd.w) : reinterpret_cast<const int4 *>(S.blk + cd.y);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
-        const int n4 = (nc * nc + 3) >> 2;
+        const int n4 = U8 ? (nc * nc + 15) >> 4 : (nc * nc + 3) >> 2;
         int4 rec = make_int4(0, 0, 0, 0);
         if ((int)threadIdx.x < min(k, 64)) rec = S.so_rec[q0 + threadIdx.x];
-        for (int i0 = 0; i0 < n4; i0 += 3 * ROWS_WAVES * WAVE) {
-            const int i = i0 + threadIdx.x;
-            int4 v0 = make_int4(0, 0, 0, 0), v1 = v0, v2 = v0;
-            if (i < n4) v0 = blk4[i];
-            if (i + ROWS_WAVES * WAVE < n4) v1 = blk4[i + ROWS_WAVES * WAVE];
-            if (i + 2 * ROWS_WAVES * WAVE < n4) v2 = blk4[i + 2 * ROWS_WAVES * WAVE];
-            if (i < n4) lds4[i] = v0;
-            if (i + ROWS_WAVES * WAVE < n4) lds4[i + ROWS_WAVES * WAVE] = v1;
-            if (i + 2 * ROWS_WAVES * WAVE < n4) lds4[i + 2 * ROWS_WAVES * WAVE] = v2;
+        if (U8) {
+            for (int i = threadIdx.x; i < n4; i += ROWS_WAVES * WAVE) lds4[i] = blk4[i];
+        } else {
+            for (int i0 = 0; i0 < n4; i0 += 3 * ROWS_WAVES * WAVE) {
+                const int i = i0 + threadIdx.x;
+                int4 v0 = make_int4(0, 0, 0, 0), v1 = v0, v2 = v0;
+                if (i < n4) v0 = blk4[i];
+                if (i + ROWS_WAVES * WAVE < n4) v1 = blk4[i + ROWS_WAVES * WAVE];
+                if (i + 2 * ROWS_WAVES * WAVE < n4) v2 = blk4[i + 2 * ROWS_WAVES * WAVE];
+                if (i < n4) lds4[i] = v0;
+                if (i + ROWS_WAVES * WAVE < n4) lds4[i + ROWS_WAVES * WAVE] = v1;
+                if (i + 2 * ROWS_WAVES * WAVE < n4) lds4[i + 2 * ROWS_WAVES * WAVE] = v2;
+            }
         }
         if ((int)threadIdx.x < min(k, 64)) lds_rec[threadIdx.x] = rec;
     }
@@ -824,15 +834,16 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
         // 3.-5. idle list + arrivals + match, specialised on the table depth
         unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
         PROF_STAMP(0);
-        if (big && !big96) rows_body<6>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (big) rows_body<8>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (small32) rows_body<2>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else rows_body<4>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        if (big && !big96) rows_body<6, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (big) rows_body<8, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (small32) rows_body<2, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else rows_body<4, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
     }
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int gg = (__ffsll((long long)rest) - 1) >> 4;
-        bucket_tick<true, true, 4, true>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, lds_blk, nc);
+        if (U8) bucket_tick<true, false, 4, true>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, S.blk + cd.y, nc);   // int block from L2
+        else bucket_tick<true, true, 4, true>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, reinterpret_cast<const int *>(lds_blk), nc);
     }
 }
 
@@ -2105,7 +2116,10 @@ static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int chunks = (S.R + 15) / 16;
     const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
-    if (S.fast_ok) hipLaunchKernelGGL(k_tick_rows, dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+    if (S.fast_ok && S.u8_ok) {
+        const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);      // byte blocks: a quarter of the LDS
+        hipLaunchKernelGGL(k_tick_rows<true>, dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(li), st, S, D, t, li);
+    } else if (S.fast_ok) hipLaunchKernelGGL(k_tick_rows<false>, dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
     else hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * 4, st, S, D, t, lds_ints);
 }
 
