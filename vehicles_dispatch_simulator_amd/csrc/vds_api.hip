@@ -370,10 +370,12 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     h->cost_host.assign(cost, cost + (size_t)N * N);
     int *d;
     long long *dl;
+    std::vector<int> costp_host;
     {
         // device copy with CLUSTER-CONTIGUOUS columns: column cl_off[c] + l holds node cl_nodes[cl_off[c] + l], so a
         // vehicle's cost-row index is (cluster offset + loc_local) with no node-table lookup on the device
-        std::vector<int> costp((size_t)N * N, 0);
+        std::vector<int> &costp = costp_host;
+        costp.assign((size_t)N * N, 0);
         const int ncol = h->cl_off[C];
         for (int i = 0; i < N; ++i) {
             const int *src = cost + (size_t)i * N;
@@ -388,7 +390,6 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     if ((rc = upload(h, &d, h->cl_nodes))) return rc; S.cl_nodes = d;
     if ((rc = upload(h, &dl, blk_off))) return rc; S.blk_off = dl;
     if ((rc = upload(h, &d, blk))) return rc; S.blk = d;
-    { int4 *d4c; if ((rc = upload(h, &d4c, cdesc))) return rc; S.cdesc = d4c; }
     {
         std::vector<int> corder(C);
         for (int c = 0; c < C; ++c) corder[c] = c;
@@ -409,6 +410,17 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
             }
         { unsigned char *d8; if ((rc = upload(h, &d8, blk8))) return rc; S.blk8 = d8; }
         for (int i = 0; i < C; ++i) cdo[i] = make_int4(cdesc[corder[i]].x, cdesc[corder[i]].y, corder[i], u8 ? (int)b8off[corder[i]] : 0);
+        for (int c = 0; c < C; ++c) cdesc[c].z = u8 ? (int)b8off[c] : 0;
+        { int4 *d4c; if ((rc = upload(h, &d4c, cdesc))) return rc; S.cdesc = d4c; }
+        // byte copy of the whole (column-permuted) matrix for the neighbour search
+        S.cost8 = nullptr;
+        if (u8) {
+            std::vector<unsigned char> c8((size_t)N * N);
+            bool fits = true;
+            for (size_t i = 0; i < c8.size() && fits; ++i) { fits = costp_host[i] >= 0 && costp_host[i] <= 255; c8[i] = (unsigned char)costp_host[i]; }
+            if (fits) { unsigned char *d8; if ((rc = upload(h, &d8, c8))) return rc; S.cost8 = d8; }
+            else S.u8_ok = 0;
+        }
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
     }
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;

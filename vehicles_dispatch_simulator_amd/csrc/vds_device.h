@@ -69,10 +69,11 @@ struct Static {
     const int *cl_nodes;             // [sum n_c]
     const long long *blk_off;        // [C+1] (16-byte aligned starts)
     const int *blk;                  // blk[c][p][l] = cost[node_p * N + node_l], each block padded to 4 ints
-    const int4 *cdesc;               // [C] {n_c, blk_off, 0, 0}: one load per workgroup
+    const int4 *cdesc;               // [C] {n_c, blk_off, blk8_off, 0}: one load per workgroup
     const int *corder;               // [C] clusters by descending size: heavy workgroups are dispatched first
     const int4 *cdesc_ord;           // [C] {n_c, blk_off, cluster, blk8_off} in that order: one dependent load less per workgroup
     const unsigned char *blk8;       // the same cost blocks as bytes (16-byte aligned starts) when every cost is <= 255
+    const unsigned char *cost8;      // byte copy of `cost` (same column order) under the same condition
     int u8_ok;
     const int *dfs_off;              // [C+1]
     const int *dfs_seq;              // visit sequence excluding the start cluster

@@ -1345,8 +1345,15 @@ struct RowRank<0> {
 #ifndef SLOTS
 #define SLOTS 12                            // candidates per lane of an 8-lane group held in registers
 #endif
+// U8 (Static.u8_ok): cost entries are read from the byte copies of the cluster blocks and of the cost matrix - a quarter of
+// the cache footprint of every gather
+template <bool U8>
 __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
+    const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
+    auto cost_at = [](const char *base, unsigned elem) -> int {
+        return U8 ? (int)*reinterpret_cast<const unsigned char *>(base + elem) : *reinterpret_cast<const int *>(base + (elem << 2));
+    };
     const int C = S.C;
     int *m_l = lds_dyn;                 // [C] idle vehicles still alive
     int *qcur_l = lds_dyn + C;          // [C] sorted position of the bucket's next pending order
@@ -1382,7 +1389,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
         const int4 cd = S.cdesc[c];
         ev_l[c] = 0; arr_l[c] = 0;
         cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (S.dfs_off[c + 1] > S.dfs_off[c] ? CAPABLE : 0);
-        cdB_l[c] = cd.y;
+        cdB_l[c] = U8 ? cd.z : cd.y;
     }
     __syncthreads();
 #define ORDER_ID2(q, qend) ((q) < (qend) ? (ids_l[(q) - tq0] & ID_MASK) : IMAX)
@@ -1503,7 +1510,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
         int idw = ids_l[qc - tq0];
         if ((idw & ID_MASK) >= limit) return;
         const int nc = cdA_l[c] & 2047;
-        const int *blk = S.blk + cdB_l[c] - ((cdA_l[c] >> 11) & 0xFFFF);
+        const int boff = cdB_l[c] - ((cdA_l[c] >> 11) & 0xFFFF);
         const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
         int m = m_l[c];
         int evals = 0;
@@ -1511,11 +1518,11 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
             evals += m;
             int best = IMAX, bpos = -1;
             if (m > 0) {
-                const int *row = blk + (size_t)(idw >> ID_BITS) * nc;
+                const int rowoff = boff + (idw >> ID_BITS) * nc;
                 for (int i = 0; i < m0; ++i) {
                     const int col = mirror[mo + i];
                     if (col == DEAD) continue;
-                    const int cst = row[col];
+                    const int cst = cost_at(blk_b, (unsigned)(rowoff + col));
                     if (cst < best) { best = cst; bpos = i; }
                 }
             }
@@ -1586,7 +1593,6 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                 const int nc = cda & 2047;
                 // cost of (pickup p, idle entry) = S.blk[boff + p * nc + column]: 32-bit offsets from one uniform base
                 const int boff = cdB_l[c] - ((cda >> 11) & 0xFFFF);
-                const char *blk_b = reinterpret_cast<const char *>(S.blk);
                 const int mo = moff_l[c], m0 = act ? moff_l[c + 1] - mo : 0;
                 int m = m_l[c], evals = 0;
                 // longest list among this wavefront's buckets of this step: bounds the (uniform) slot loops
@@ -1625,8 +1631,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                             for (int u = 0; u < SLOTS; ++u) {
                                 cst[o][u] = 0;
                                 if (any && u * GRP < mmaxw) {
-                                    const unsigned off = (unsigned)(((take >> u) & 1u) ? rowoff + col[u] : 0) << 2;
-                                    cst[o][u] = *reinterpret_cast<const int *>(blk_b + off);
+                                    cst[o][u] = cost_at(blk_b, (unsigned)(((take >> u) & 1u) ? rowoff + col[u] : 0));
                                 }
                             }
                         }
@@ -1677,7 +1682,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                                 }
 #pragma unroll
                                 for (int u = 0; u < 8; ++u)
-                                    cst[u] = *reinterpret_cast<const int *>(blk_b + ((unsigned)(ok[u] ? rowoff + cl[u] : 0) << 2));
+                                    cst[u] = cost_at(blk_b, (unsigned)(ok[u] ? rowoff + cl[u] : 0));
 #pragma unroll
                                 for (int u = 0; u < 8; ++u)
                                     key = min(key, ok[u] ? (cst[u] << 16) | (i0 + u * GRP + gl) : IMAX);
@@ -1721,7 +1726,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
         //     key = (cost << 16 | visit position, list position << 16 | cluster): lexicographic minimum == the
         //     reference's first strict minimum in visit order, then list order
         const int q = qcur_l[pc];
-        const int *crow = S.cost + (size_t)pnode * S.N;
+        const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
         int bhi = IMAX, blo = IMAX;
         for (int jb = 0; s0 + wave + jb * REPL_WAVES < s1; jb += WAVE) {
             if (jb > 0) {                               // visit sequences longer than 64 clusters per wavefront
@@ -1764,12 +1769,10 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                         if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
                     }
                 }
-                const char *crow_b = reinterpret_cast<const char *>(crow);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     in[k] &= cl[k] != DEAD ? 1 : 0;
-                    const unsigned off = (unsigned)(in[k] ? cl[k] : 0) << 2;
-                    cst[k] = *reinterpret_cast<const int *>(crow_b + off);
+                    cst[k] = cost_at(crow_b, (unsigned)(in[k] ? cl[k] : 0));
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -2141,7 +2144,8 @@ void launch_tick_replica(const Static &S, const State &D, int t, hipStream_t st)
 
 void launch_tick_replica2(const Static &S, const State &D, int t, hipStream_t st) {
     const size_t lds = replica2_lds_ints(S.C, S.V, S.max_tick_orders) * sizeof(int);
-    hipLaunchKernelGGL(k_tick_replica2, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
+    if (S.u8_ok) hipLaunchKernelGGL(k_tick_replica2<true>, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
+    else hipLaunchKernelGGL(k_tick_replica2<false>, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
