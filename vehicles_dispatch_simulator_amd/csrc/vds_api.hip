@@ -302,6 +302,15 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     Static &S = h->S;
     S.N = N; S.C = C; S.V = h->cfg.vehicles; S.R = h->cfg.replicas;
     S.tick_minutes = h->cfg.tick_minutes;
+    {   // division by the slot length without the ~28-instruction integer-division sequence
+        const unsigned long long tk = (unsigned long long)S.tick_minutes;
+        if (tk >= 2) {
+            S.tick_magic = (unsigned)(((1ull << 32) + tk - 1) / tk);
+            S.tick_div_limit = (int)std::min<unsigned long long>((1ull << 31) - 1, (1ull << 32) / tk);
+        } else {
+            S.tick_magic = 0; S.tick_div_limit = 0;
+        }
+    }
     S.reject_threshold = h->cfg.pickup_reject_threshold;
     h->node2cluster.assign(node2cluster, node2cluster + N);
     h->cl_off.assign(C + 1, 0);

@@ -57,6 +57,8 @@ __host__ __device__ inline unsigned long long entry_key(int id, int w) {
 struct Static {
     int N, C, V, R, Oq, T;
     int tick_minutes, now0;          // RealExpTime at tick 0
+    unsigned tick_magic;             // ceil(2^32 / tick_minutes): n / tick == mulhi(n, magic) for 0 <= n < tick_div_limit
+    int tick_div_limit;              // (0: always divide)
     long long reject_threshold;
     int idle_cap, fl_cap, in_cap;    // fl_cap / in_cap: far list / far inbox
     int H, ring_cap;                 // arrival ring: H ticks (power of two) x ring_cap entries

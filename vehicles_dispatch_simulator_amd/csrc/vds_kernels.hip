@@ -221,10 +221,20 @@ __device__ __forceinline__ void ring_post(const Static &S, const State &D, int d
     else atomicOr(&D.err[0], ERR_RING_CAP);
 }
 
+// ceil(rel / tick_minutes) for rel > 0.  SMALL: the caller guarantees rel < 2^25 (costs < 2^23), so the multiply-high form
+// is exact whenever the host could build the magic number (tick_minutes >= 2) - a wave-uniform choice, no per-lane fallback
+template <bool SMALL>
+__device__ __forceinline__ int ticks_until(const Static &S, int rel) {
+    const int n = rel + S.tick_minutes - 1;
+    if (SMALL && S.tick_div_limit > (1 << 26)) return (int)__umulhi((unsigned)n, S.tick_magic);
+    return n / S.tick_minutes;
+}
+
+template <bool SMALL = false>
 __device__ __forceinline__ void post_arrival(const Static &S, const State &D, int dc, int r, int t, int now,
                                              int veh, int id, int arrive, int is_dispatch, int dest_local) {
     const int rel = arrive - now;
-    const int d = rel <= 0 ? 1 : (rel + S.tick_minutes - 1) / S.tick_minutes;   // next Update is at t+1 at the earliest
+    const int d = rel <= 0 ? 1 : ticks_until<SMALL>(S, rel);   // next Update is at t+1 at the earliest
     const int4 e = make_int4(veh, id, arrive, meta_pack(t, is_dispatch, dest_local));
     if (d < S.H) {
         ring_post(S, D, dc, r, t + d, e);
@@ -256,7 +266,7 @@ __device__ void update_far(const Static &S, const State &D, int c, int r, int t,
         const int idx = I * WAVE + lane;
         int4 e = pending_load(fl, inb, f, P, idx);
         const int rel = e.z - now;
-        const int d = rel <= 0 ? 0 : (rel + S.tick_minutes - 1) / S.tick_minutes;
+        const int d = rel <= 0 ? 0 : ticks_until<false>(S, rel);
         const bool valid = idx < P;
         const bool keep = valid && d >= S.H;
         if (valid && !keep) ring_post(S, D, c, r, t + d, e);
@@ -611,12 +621,12 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (matched && !(abl & 1)) {
             if (abl & 96) {   // timing-only: bit5 = atomic without the entry store, bit6 = entry store without the atomic
                 const int rel = wait + rr.w;
-                const int dd = rel <= 0 ? 1 : (rel + S.tick_minutes - 1) / S.tick_minutes;
+                const int dd = rel <= 0 ? 1 : ticks_until<true>(S, rel);
                 const size_t i = ((size_t)((t + dd) & (S.H - 1)) * S.C + (rr.z & 0xFFFF)) * S.R + r;
                 if (abl & 32) { int o = atomicAdd(&D.ring_cnt[i], 0); if (o == 0x7FFFFFF1) D.err[1] = o; }
                 if (abl & 64) D.ring[i * S.ring_cap + (rr.x & 7)] = make_int4(vid, rr.x, now + rel, 0);
             } else {
-                post_arrival(S, D, rr.z & 0xFFFF, r, t, now, vid, rr.x, now + wait + rr.w, 0, (int)((unsigned)rr.y >> 16));
+                post_arrival<true>(S, D, rr.z & 0xFFFF, r, t, now, vid, rr.x, now + wait + rr.w, 0, (int)((unsigned)rr.y >> 16));
             }
         }
         wsum += matched ? wait : 0;
