@@ -326,9 +326,9 @@ __device__ int drain_ring(const Static &S, const State &D, size_t b, int t, int 
 // ---------------------------------------------------------------------------------------
 // Generic match phase of one bucket (own-cluster scan, :924-965).  Lane l holds idle positions
 // l*J .. l*J+J-1, so "lowest position" == "lowest lane, then lowest slot".
-template <int J, bool LDSBLK>
+template <int J, bool LDSBLK, typename CT = int>
 __device__ void match_bucket(const Static &S, const State &D, int r, int t, int now, int &m, int q0, int k,
-                             const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
+                             const CT *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
                              long long &evals, int &rejects, unsigned short *mir = nullptr) {
     const int lane = lane_id();
     unsigned veh[J], loc[J];
@@ -351,7 +351,7 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
             evals += navail;
             if (navail == 0) { rejects++; continue; }             // :966-969 / TempMin == None
             const int p = rdlane(rec.y, j) & 0xFFFF;
-            const int *row = blk + (size_t)p * nc;
+            const CT *row = blk + (size_t)p * nc;
             int bc = IMAX, bs = 0;
             bool has = false;
 #pragma unroll
@@ -420,8 +420,8 @@ __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t,
 
 // Whole generic tick of one bucket by one wavefront.  MAXJ = 4: tables up to 256 idle entries are
 // matched here, bigger ones are pushed to the worklist (match only).  MAXJ = 16: everything here.
-template <bool DO_MATCH, bool LDSBLK, int MAXJ, bool ONLY_J4 = false>
-__device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t, int q0, int k, const int *blk, int nc) {
+template <bool DO_MATCH, bool LDSBLK, int MAXJ, bool ONLY_J4 = false, typename CT = int>
+__device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t, int q0, int k, const CT *blk, int nc) {
     const int lane = lane_id();
     const int p = t & 1;
     const int now = S.now0 + t * S.tick_minutes;
@@ -445,17 +445,17 @@ __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t
     bool deferred = false;
     if (DO_MATCH && k > 0) {
         if (MAXJ < 16 && m > 256 && ONLY_J4) {
-            match_bucket_slow(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);   // any size, in place
+            match_bucket_slow(S, D, r, t, now, m, q0, k, S.blk + S.blk_off[c], nc, idle, wait_sum, value_sum, evals, rejects);   // any size, in place (int block from L2)
         } else if (MAXJ < 16 && m > 256) {
             deferred = true;
             if (lane == 0) {
                 int slot = atomicAdd(&D.work[p], 1);
                 D.work[2 + (size_t)p * S.C * S.R + slot] = (int)b;
             }
-        } else if (!ONLY_J4 && m <= 64) match_bucket<1, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-        else if (!ONLY_J4 && m <= 128) match_bucket<2, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-        else if (MAXJ < 16 || m <= 256) match_bucket<4, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-        else match_bucket<MAXJ, LDSBLK>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        } else if (!ONLY_J4 && m <= 64) match_bucket<1, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        else if (!ONLY_J4 && m <= 128) match_bucket<2, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        else if (MAXJ < 16 || m <= 256) match_bucket<4, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        else match_bucket<MAXJ, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
     }
     if (lane == 0) {
         hdr[HDR_IDLE] = m;
@@ -852,8 +852,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int gg = (__ffsll((long long)rest) - 1) >> 4;
-        if (U8) bucket_tick<true, false, 4, true>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, S.blk + cd.y, nc);   // int block from L2
-        else bucket_tick<true, true, 4, true>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, reinterpret_cast<const int *>(lds_blk), nc);
+        bucket_tick<true, true, 4, true, CT>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, lds_blk, nc);
     }
 }
 
