@@ -11,8 +11,9 @@ HBM.  Replicas shard across GPUs with no data-path collective (weak scaling: R p
 fixed); the only collective is an RCCL all-reduce of the int64[8] aggregate counters per day.
 
 The one JSON line printed by rank 0 also carries
-  roofline      dominant kernel k_tick: algorithmic bytes per launch (SURVEY.md 8(d) byte model)
-                / average launch duration (HIP events on the kernel's stream) vs 8 TB/s HBM;
+  roofline      dominant kernel: bytes its data layout moves through HBM per launch / average launch
+                duration (HIP events on the kernel's stream) vs 8 TB/s HBM; next to it the PMC-measured traffic,
+                SURVEY.md 8(d)'s accounting bytes, and the limiter the counters name (VALU issue);
   cpu_baseline  the CPU oracle (a C port of the reference algorithm, 1 thread) timed on this
                 host on a bounded sample of the same workload;
   cpu_baseline_all_cores  the same oracle as one independent single-replica process per host core.
@@ -177,34 +178,58 @@ def main():
         elapsed = vdist.max_over_ranks(elapsed, device="cuda")
     agg = totals.cpu().numpy()
 
-    # ---- roofline pass (rank 0): per-launch duration of the dominant kernel, HIP events on its stream
+    # ---- roofline pass (rank 0): per-launch duration of the dominant kernel, HIP events on its stream.  The day is
+    #      stepped slot by slot so that the packed observations (device tensors) give the exact number of idle-list
+    #      entries the kernel loaded: sum of PerMatchIdleVehicles over the (replica, cluster) buckets that had orders.
     roofline = None
     work = env.work()         # work of the last day on this rank
     if rank == 0:
         env.reset_again()
         env.profile(True)
-        env.run(T)
+        env.run(T)                                 # timing pass: nothing but the tick kernels on the stream
         ms = env.profile_read(cap=T + 8)
         env.profile(False)
+        env.reset_again()                          # counting pass (untimed): the same day, observed slot by slot
+        idle_loaded = torch.zeros((), dtype=torch.int64, device="cuda")
+        busy_buckets = torch.zeros((), dtype=torch.int64, device="cuda")
+        for _ in range(T):
+            env.step()
+            ob = env.obs_torch()                   # [5, R, C]: idle_pre, idle_now, supply, cl_orders, inflight
+            has = ob[3] > 0
+            idle_loaded += (ob[0] * has).sum()
+            busy_buckets += has.sum()
+            env.advance()
         if ms.size:
-            bytes_day = workloads.algorithmic_bytes(work, w.vehicles)
-            per_launch_bytes = bytes_day / ms.size
+            kern = env.main_kernel()
             avg_s = float(ms.mean()) * 1e-3
-            achieved = per_launch_bytes / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    for tj in json.load(open(tpath)).get("entries", []):
-                        if tj.get("workload") == a.workload and tj.get("replicas") == R and tj.get("kernel") == env.main_kernel():
-                            traffic = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": env.main_kernel(),
-                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes,
+            alg_bytes = workloads.algorithmic_bytes(work, w.vehicles) / ms.size
+            lay_bytes = workloads.layout_bytes(work, replicas=R, clusters=env.C, idle_loaded=int(idle_loaded.item()),
+                                               busy_buckets=int(busy_buckets.item())) / ms.size
+            side = workloads.profile_side_data(ROOT, a.workload, R, kern)
+            traffic = side.get("hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "kernel": kern,
+                        # bytes this DATA LAYOUT has to move through HBM per launch (headers, counters,
+                        # 8 B idle entries, 16 B arrival entries, 8 B results; costs come from LDS) / launch time
+                        "achieved": lay_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": lay_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                        "layout_bytes_per_launch": lay_bytes,
+                        "traffic": traffic,
+                        "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                        # SURVEY 8(d)'s accounting unit (16 B per evaluation as if cost / location / idle entry came
+                        # from HBM every time): NOT a lower bound for this layout, quoted for comparability only
+                        "algorithmic_bytes_per_launch": alg_bytes,
+                        "algorithmic_gbs": alg_bytes / avg_s / 1e9,
                         "avg_launch_ms": float(ms.mean()), "launches": int(ms.size),
                         "match_evals_per_s": work["evals"] / (float(ms.sum()) * 1e-3)}
+            lim = side.get("limiter")
+            if lim:
+                # what the counters say bounds the kernel: VALU issue.  floor = wave-instructions x cycles each
+                # (profiles/ubench) / (SIMDs x clock); frac = floor / measured launch time
+                floor_s = lim["valu_insts_per_launch"] * lim["cycles_per_valu_inst"] / (lim["simds"] * lim["clock_hz"])
+                roofline["limiter"] = {"kind": "valu-issue", "floor_ms": floor_s * 1e3, "frac": floor_s / avg_s,
+                                       "valu_insts_per_launch": lim["valu_insts_per_launch"],
+                                       "cycles_per_valu_inst": lim["cycles_per_valu_inst"],
+                                       "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source")}
 
     check = None
     if a.check and rank == 0:
@@ -241,6 +266,9 @@ def main():
             "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if dist is not None:
+            out["collective"] = {"backend": dist.get_backend(), "world_size": world, "allreduce_calls": vdist.ALLREDUCE_CALLS,
+                                 "payload": "int64[8] aggregate counters per day"}
         if cpu_all is not None:
             out["cpu_baseline_all_cores"] = cpu_all
         if check is not None:

@@ -63,7 +63,10 @@ typedef struct vds_config {
     int64_t pickup_reject_threshold;  /* raw integer of PICKUPTIMEWINDOW (config/setting.py:7 ->
                                          600000000000): `cost > PICKUPTIMEWINDOW` (:943) compares
                                          the integer minute cost with this raw value */
-    int32_t idle_cap;                 /* slots per (replica, cluster) idle table, <= 1024; 0 = auto */
+    int32_t idle_cap;                 /* slots per (replica, cluster) idle table (the reference's lists are unbounded,
+                                         objects.py:10); 0 = auto: sized at vds_reset from the fullest start list
+                                         (2 x + 64, at most V) and regrown by a later vds_reset that needs more.
+                                         Lists beyond 128 / 256 / 1024 entries take slower in-place paths. */
     int32_t ring_cap;                 /* arrivals one (replica, cluster) can receive for ONE tick; 0 = auto */
     int32_t ring_ticks;               /* arrival-ring horizon in ticks (power of two); trips that end later go
                                          through the slower "far" tables; 0 = 32 */
@@ -101,13 +104,37 @@ int vds_load_static(vds_handle *h, const int32_t *cost, int32_t N, const int32_t
 int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pickup,
                     const int32_t *delivery, int32_t O);
 
-/* Number of iterations of `while self.RealExpTime <= EndTime` (:1048). */
+/* Per-replica order days.  In the reference one Simulation is one city with its own self.Orders (:325-342); a batch of R
+ * replicas can therefore replay R different days.  n_days days are passed back to back: day d owns elements
+ * [day_off[d], day_off[d+1]) of release_min / pickup / delivery (each day sorted by release like self.Orders, ids = index
+ * inside the day); replica r replays day replica_day[r] (NULL: r % n_days).  Every day has its own tick grid (:1037-1040):
+ * vds_num_ticks reports the longest; a replica whose day is over is left untouched by further vds_step calls, exactly as
+ * if its SimCity loop had ended (:1048).  vds_read_orders rows are strided by the longest day.  n_days == 1 is
+ * vds_load_orders.  With more than one day the fast kernel runs its per-row order-stream variant (k_tick_rows<.., PD>). */
+int vds_load_order_days(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min,
+                        const int32_t *pickup, const int32_t *delivery, const int32_t *replica_day);
+
+/* The same in SURVEY.md 8(b)'s strided form: replica r's day of O orders starts at element r * replica_stride of the three
+ * arrays; replica_stride == 0: one day shared by all replicas (== vds_load_orders), otherwise replica_stride >= O. */
+int vds_load_orders_strided(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery,
+                            int32_t O, int64_t replica_stride);
+
+/* Ticks (:1048) and order count of the day replica `replica` replays; either pointer may be NULL. */
+int vds_replica_ticks(const vds_handle *h, int32_t replica, int32_t *T, int32_t *n_orders);
+
+/* Number of iterations of `while self.RealExpTime <= EndTime` (:1048); the longest day's when days differ. */
 int vds_num_ticks(const vds_handle *h, int32_t *T);
 
 /* Reset (:214-247) + InitVehiclesIntoCluster (:249-258) with the random nodes supplied by the
  * caller ([R*V], replica-major; vehicle v of a replica is appended to its cluster's idle list in
  * vehicle order) + SimCity prologue (:1037-1043): tick = 0, counters = 0. */
 int vds_reset(vds_handle *h, const int32_t *veh_init_node);
+
+/* Replace the idle tables by ones with `cap` slots per (replica, cluster) (rounded up to 64, at most V).  For the
+ * retry after a VDS_ECAPACITY "idle table overflow" (a day in which vehicles concentrate beyond the automatic
+ * headroom): episode state is lost, vds_reset / vds_reset_again must follow.  vds_idle_cap returns the current value. */
+int vds_set_idle_cap(vds_handle *h, int32_t cap);
+int vds_idle_cap(const vds_handle *h);
 
 /* As vds_reset, but re-using the start nodes uploaded by the previous vds_reset (they stay
  * resident in HBM): the episode restart an RL loop performs thousands of times. */
@@ -127,6 +154,16 @@ int vds_step(vds_handle *h);
  * TotallyDispatchCost += cost (:50-51).  Must be called between vds_step and vds_advance. */
 int vds_apply_dispatch(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
                        const int32_t *idle_pos, const int32_t *target_node);
+
+/* vds_apply_dispatch for hook bodies written in the reference's own idiom, i.e. that edit the containers themselves
+ * (`cluster.IdleVehicles.remove(v)`, `target_cluster.VehiclesArrivetime[v] = time`, `self.DispatchNum += 1`; objects.py:10-11,
+ * simulator.py:50-51):
+ *   arrive_min  (NULL = as vds_apply_dispatch) the arrival minute, on the day's clock, that the body stored in
+ *               VehiclesArrivetime - it need not be RealExpTime + RoadCost;
+ *   counted     (NULL = all 1) 0: DispatchNum / TotallyDispatchCost are maintained by the body, the engine leaves them alone. */
+int vds_apply_dispatch_ex(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
+                          const int32_t *idle_pos, const int32_t *target_node, const int32_t *arrive_min,
+                          const int32_t *counted);
 
 /* The same DispatchFunction body for every replica at once, from a DEVICE-resident action tensor - what a batched
  * policy running on the GPU emits; nothing crosses PCIe and the call is asynchronous on the handle's stream (which
@@ -235,6 +272,16 @@ int vds_py_random_nodes(uint64_t seed, int32_t N, int32_t count, const uint8_t *
  * total exceeds cap (call with cap = 0, seq = NULL to size the buffer).  Needs no GPU and no handle. */
 int vds_dfs_sequences(const int32_t *nbr_off, const int32_t *nbr_idx, int32_t C, int32_t depth_limit,
                       int32_t *seq_off, int32_t *seq, int64_t cap);
+
+/* Neighbour-matrix precompute of CreateCluster (:594-623) on the GPU: sums[i*C + j] = sum over k in cluster i, l in
+ * cluster j of RoadCost(k, l) = cost[l*N + k] (int64, exact; the diagonal is filled too), sizes[c] = nodes of cluster c
+ * (may be NULL).  The mean sums / (|i| |j|), the 99999 sentinel for empty clusters (:608-609), the ascending sort and the
+ * "first 4 + every later one below 15" rule (:637-646) are applied by the caller (synth.neighbors_from_sums).  Needs a
+ * GPU but no handle - the neighbour lists are an input of vds_load_static.  Message of a failure:
+ * vds_cluster_cost_sums_error(). */
+int vds_cluster_cost_sums(int32_t device, const int32_t *cost, int32_t N, const int32_t *node2cluster, int32_t C,
+                          int64_t *sums, int32_t *sizes);
+const char *vds_cluster_cost_sums_error(void);
 
 /* Name of the kernel that vds_step launches for the main part of a tick with the handle's current tables (the one
  * vds_profile_enable brackets with events): "k_tick_rows", "k_tick", "k_tick_replica2", "k_tick_replica" or

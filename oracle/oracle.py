@@ -41,6 +41,8 @@ def _lib():
         lib.vds_oracle_reset.restype = C.c_int
         lib.vds_oracle_dispatch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         lib.vds_oracle_dispatch.restype = C.c_int
+        lib.vds_oracle_dispatch_at.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.vds_oracle_dispatch_at.restype = C.c_int
         lib.vds_oracle_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.vds_oracle_obs.argtypes = [C.c_void_p] * 7
         lib.vds_oracle_orders.argtypes = [C.c_void_p] * 6
@@ -104,6 +106,16 @@ class Oracle:
         veh = np.ascontiguousarray(veh, dtype=np.int32)
         tgt = np.ascontiguousarray(target_node, dtype=np.int32)
         rc = self._lib.vds_oracle_dispatch(self._h, veh.size, _p(veh), _p(tgt))
+        if rc:
+            raise Exception("oracle dispatch failed rc=%d" % rc)
+
+    def dispatch_at(self, veh, target_node, arrive_min=None, counted=True):
+        """As ``dispatch`` with the arrival minute the hook body wrote itself; ``counted=False``: the body keeps
+        ``DispatchNum`` / ``TotallyDispatchCost`` (``simulator.py:50-51``)."""
+        veh = np.ascontiguousarray(veh, dtype=np.int32)
+        tgt = np.ascontiguousarray(target_node, dtype=np.int32)
+        arr = None if arrive_min is None else np.ascontiguousarray(arrive_min, dtype=np.int32)
+        rc = self._lib.vds_oracle_dispatch_at(self._h, veh.size, _p(veh), _p(tgt), None if arr is None else _p(arr), int(bool(counted)))
         if rc:
             raise Exception("oracle dispatch failed rc=%d" % rc)
 

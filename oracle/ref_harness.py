@@ -26,6 +26,11 @@ from typing import Callable, Dict, Optional
 
 import numpy as np
 
+try:
+    from dispatch_idiom import move_idle_vehicle
+except ImportError:          # imported as oracle.ref_harness
+    from .dispatch_idiom import move_idle_vehicle
+
 REFERENCE_ROOT = "/root/reference"
 
 
@@ -102,7 +107,8 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
                   dispatch_policy: Optional[Callable] = None, capture_lists: bool = False,
                   keep_dir: Optional[str] = None, quiet: bool = True, focus_bound=None,
                   tick_minutes: int = 10, pickup_window_raw: Optional[int] = None,
-                  neighbor_csv: Optional[str] = None, capture_dfs=()) -> Dict[str, np.ndarray]:
+                  neighbor_csv: Optional[str] = None, capture_dfs=(), dispatch_extra_minutes: int = 0,
+                  capture_neighbor_table: bool = False) -> Dict[str, np.ndarray]:
     """Run the reference end to end on the given synthetic day; return inputs + outputs.
 
     ``dispatch_policy(sim, tick) -> list[(vehicle_obj, target_node)]`` (optional) is invoked
@@ -171,6 +177,20 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
         o_val = np.array([o.OrderValue for o in S.Orders], dtype=np.int64)
         assert all(o.ID == i for i, o in enumerate(S.Orders))
         O = len(S.Orders)
+
+        # ---------------- the neighbour-distance table the reference computed and cached (:594-621) ----------------
+        nbr_table = {}
+        if capture_neighbor_table and cluster_mode != "Grid" and neighbor_csv is None:
+            import ast
+            import pandas as pd
+            written = os.path.join(root, "data", str(tuple(focus_bound or city.bound)) + str(C) + cluster_mode + "Neighbor.csv")
+            cells = pd.read_csv(written, header=None).values
+            ids = np.zeros(cells.shape, dtype=np.int32)
+            dist = np.zeros(cells.shape, dtype=np.float64)
+            for a in range(cells.shape[0]):
+                for b in range(cells.shape[1]):
+                    ids[a, b], dist[a, b] = ast.literal_eval(cells[a, b])
+            nbr_table = dict(nbr_table_id=ids, nbr_table_dist=dist)
 
         # ---------------- DFS visit order of the reference's own recursion ----------------
         dfs = {}
@@ -246,12 +266,8 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
                 for veh, target in dispatch_policy(S, S.step):
                     src = veh.Cluster
                     pos = src.IdleVehicles.index(veh)
-                    c = S.RoadCost(veh.LocationNode, target)
-                    veh.DeliveryPoint = target
-                    src.IdleVehicles.remove(veh)
-                    S.NodeID2Cluseter[target].VehiclesArrivetime[veh] = S.RealExpTime + np.timedelta64(c * setting.MINUTES)
-                    S.DispatchNum += 1
-                    S.TotallyDispatchCost += c
+                    # the hook body proper: oracle/dispatch_idiom.py, shared verbatim with the GPU shell's test
+                    c = move_idle_vehicle(S, veh, target, setting.MINUTES, dispatch_extra_minutes)
                     dispatch_log.append((S.step, veh_index[id(veh)], src.ID, pos, int(target), int(c)))
             ticks["idle_after_dispatch"].append([len(c.IdleVehicles) for c in S.Clusters])
 
@@ -302,6 +318,9 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
             ref_init_s=np.float64(t_init), ref_sim_s=np.float64(t_sim),
         )
         out.update(dfs)
+        out.update(nbr_table)
+        if dispatch_extra_minutes:
+            out["dispatch_extra_minutes"] = np.int64(dispatch_extra_minutes)
         if capture_lists:
             # context features of every order (simulator.py:842-866) and the normalised weather tables (:79-95)
             out["o_time_weather"] = np.array([S.GetTimeAndWeather(o) for o in S.Orders], dtype=np.float64)

@@ -275,6 +275,25 @@ int vds_oracle_dispatch(void *h, int32_t n, const int32_t *veh, const int32_t *t
     return 0;
 }
 
+/* The same hook body with the arrival time the body itself wrote into VehiclesArrivetime (arrive_min[i], minutes on the
+ * day clock) and with DispatchNum / TotallyDispatchCost left to the body when counted == 0 (they are plain fields the
+ * reference never touches itself, simulator.py:50-51). */
+int vds_oracle_dispatch_at(void *h, int32_t n, const int32_t *veh, const int32_t *target_node, const int32_t *arrive_min, int32_t counted) {
+    oracle_t *s = (oracle_t *)h;
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t v = veh[i], t = target_node[i];
+        if (v < 0 || v >= s->V || t < 0 || t >= s->N || s->node2cluster[t] < 0) return -1;
+        if (s->veh_dest[v] >= 0) return -3;                                /* not idle */
+        int32_t c = road_cost(s, s->veh_loc[v], t);
+        if (ivec_remove(&s->idle[s->veh_cluster[v]], v) < 0) return -3;
+        s->veh_dest[v] = t;
+        ivec_push(&s->arr_veh[s->node2cluster[t]], v);
+        ivec_push(&s->arr_min[s->node2cluster[t]], arrive_min ? arrive_min[i] : s->now_min + c);
+        if (counted) { s->dispatch_num++; s->dispatch_cost += c; }
+    }
+    return 0;
+}
+
 /* simulator.py:1090-1091 */
 void vds_oracle_end_tick(void *h) {
     oracle_t *s = (oracle_t *)h;

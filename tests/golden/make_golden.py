@@ -35,23 +35,7 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def policy_factory(N, every=3, min_idle=3, moves=2, salt=17):
-    """A deterministic DispatchFunction body for the harness (the reference's hook is empty)."""
-    def policy(S, tick):
-        if tick % every != 0:
-            return []
-        out = []
-        for c in S.Clusters:
-            n = len(c.IdleVehicles)
-            if n >= min_idle:
-                for m in range(min(moves, n - 1)):
-                    veh = c.IdleVehicles[(tick * 7 + m * 3 + c.ID) % n]
-                    if any(veh is v for v, _ in out):
-                        continue
-                    target = int((tick * 2654435761 + c.ID * 40503 + m * salt) % N)
-                    out.append((veh, target))
-        return out
-    return policy
+from dispatch_idiom import policy_factory  # noqa: E402  (oracle/dispatch_idiom.py: shared with the GPU shell test)
 
 
 TINY = {
@@ -82,6 +66,15 @@ TINY = {
                          run=dict(V=140, seed=23, cluster_mode="KmeansClustering", side_m=3200, service_m=3200, pickup_window_raw=6)),
     "tiny_window4_dfs2": dict(city=dict(seed=114, N=300, C=12), O=3000, oseed=14,
                               run=dict(V=70, seed=24, cluster_mode="SpectralClustering", side_m=3200, service_m=8000, neighbor_can_server=True, pickup_window_raw=4)),
+    # the dispatch body books 7 extra minutes on top of the road cost (arrival time written by the body itself)
+    "tiny_dispatch_delay": dict(city=dict(seed=115, N=300, C=12), O=2500, oseed=15, dispatch=True, extra_minutes=7, nbr_table=True,
+                                run=dict(V=140, seed=25, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
+    # 20 000 orders on a tiny city: ~14 per minute, so ReadOrder's unstable sort (readfiles.py:78) really permutes ties
+    "tiny_sort_ties": dict(city=dict(seed=116, N=300, C=12), O=20000, oseed=16, nbr_table=True,
+                           run=dict(V=150, seed=26, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
+    # the neighbour-distance table the reference computes and caches (:594-621), with two empty clusters (99999 rows)
+    "tiny_nbr_empty": dict(city=dict(seed=117, N=260, C=12), O=600, oseed=17, empty=[2, 9], nbr_table=True,
+                           run=dict(V=40, seed=27, cluster_mode="TransportationClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
     "tiny_two_orders": dict(city=dict(seed=110, N=120, C=12), O=2, oseed=10,
                             run=dict(V=30, seed=20, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
 }
@@ -177,6 +170,10 @@ def generate(name, spec, real=False, shipped=False):
     run = dict(spec["run"], **extra)
     pol = policy_factory(city.N) if spec.get("dispatch") else None
     focus = spec.get("focus")
+    if spec.get("extra_minutes"):
+        run["dispatch_extra_minutes"] = spec["extra_minutes"]
+    if spec.get("nbr_table"):
+        run["capture_neighbor_table"] = True
     out = rh.run_reference(city, start, pick, dele, dispatch_policy=pol, capture_lists=not real, focus_bound=focus, **run)
     # the generator's tables must be exactly what the reference loaded / derived
     assert out["cost_is_integral"]

@@ -72,6 +72,7 @@ def run_day(g, R, same_init, list_every=1, device_dispatch=False, **kw):
     T = env.T
     assert T == int(g["n_ticks"]) == oracles[0].num_ticks
     disp = dispatch_by_tick(g)
+    extra = int(g["dispatch_extra_minutes"]) if "dispatch_extra_minutes" in g else 0
     for t in range(T):
         env.step()
         for o in oracles:
@@ -105,10 +106,16 @@ def run_day(g, R, same_init, list_every=1, device_dispatch=False, **kw):
                 acts = np.full((R, len(rows) + 3, 3), -1, dtype=np.int32)
                 acts[:nrep, 1:len(rows) + 1, 0] = rows[:, 2]; acts[:nrep, 1:len(rows) + 1, 1] = pos; acts[:nrep, 1:len(rows) + 1, 2] = rows[:, 4]
                 env.apply_dispatch_torch(torch.from_numpy(acts).cuda())
+            elif extra:       # the hook body wrote its own arrival time (golden tiny_dispatch_delay): vds_apply_dispatch_ex
+                env.apply_dispatch(rep, np.tile(rows[:, 2], nrep), np.tile(pos, nrep), np.tile(rows[:, 4], nrep),
+                                   arrive_min=np.tile(oracles[0].now_min + rows[:, 5] + extra, nrep))
             else:
                 env.apply_dispatch(rep, np.tile(rows[:, 2], nrep), np.tile(pos, nrep), np.tile(rows[:, 4], nrep))
             for o in oracles[:nrep]:
-                o.dispatch(rows[:, 1], rows[:, 4])
+                if extra:
+                    o.dispatch_at(rows[:, 1], rows[:, 4], arrive_min=o.now_min + rows[:, 5] + extra)
+                else:
+                    o.dispatch(rows[:, 1], rows[:, 4])
             for r, o in enumerate(oracles):
                 check_lists(env, r, o, t)
             np.testing.assert_array_equal(env.obs()["idle_now"][0], g["t_idle_after_dispatch"][t])

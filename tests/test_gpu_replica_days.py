@@ -1,0 +1,169 @@
+"""Per-replica order days (vds_load_order_days / vds_load_orders_strided): in the reference one Simulation is one city with
+its own self.Orders (simulator.py:325-342), so R replicas may replay R different days with different tick grids.
+Every replica is compared with ITS OWN oracle, per tick (counters, observations, container order) and per order, in every
+engine mode; a replica whose day is over must stand still; identical days through the per-row kernel variant must equal
+the shared-day kernel bit for bit."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import engine_settings, load_golden
+from oracle.oracle import Oracle
+from test_gpu_parity import check_lists
+from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth, workloads
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"fast": dict(), "generic": dict(force_generic=1), "gen1": dict(force_generic=2)}
+
+
+def synth_days(g, n_days, seed):
+    """n_days synthetic days on the fixture's city: different order counts, different first / last release (so
+    different now0 and tick counts), one of them much shorter."""
+    N = int(g["N"])
+    days = []
+    for d in range(n_days):
+        O = [2500, 1800, 700, 3100, 40][d % 5]
+        start, pick, dele = synth.make_orders(seed + 17 * d, N, O)
+        rel = synth.release_minutes(start)
+        if d % 5 == 2:
+            keep = rel < rel[0] + 300            # a day that ends after five hours
+            rel, pick, dele = rel[keep], pick[keep], dele[keep]
+        valid = (g["node2cluster"][pick] >= 0) & (g["node2cluster"][dele] >= 0)
+        rel, pick, dele = rel[valid], pick[valid], dele[valid]
+        days.append(((rel - rel[0] + 3 * d).astype(np.int32), pick.astype(np.int32), dele.astype(np.int32)))
+    return days
+
+
+def mk_env(g, R, **kw):
+    return BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=int(g["V"]),
+                              depth_limit=int(g["depth_limit"]), neighbor_can_server=bool(g["neighbor_can_server"]),
+                              **{**engine_settings(g), **kw})
+
+
+def mk_oracle(g, day):
+    return Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], int(g["depth_limit"]), bool(g["neighbor_can_server"]),
+                  day[0], day[1], day[2], int(g["V"]), **engine_settings(g))
+
+
+@pytest.mark.parametrize("name,mode", [("tiny_kmeans", "fast"), ("tiny_kmeans", "generic"), ("tiny_grid", "fast"),
+                                       ("tiny_kmeans_dfs2", "fast"), ("tiny_kmeans_dfs2", "gen1"), ("tiny_kmeans_dfs2", "generic"),
+                                       ("tiny_window6", "fast"), ("tiny_empty_clusters_dfs2", "fast")])
+def test_every_replica_replays_its_own_day(name, mode):
+    g = load_golden(name)
+    V, N, R = int(g["V"]), int(g["N"]), 7
+    days = synth_days(g, 4, seed=900 + len(name))
+    replica_day = np.array([0, 1, 2, 3, 2, 0, 1], dtype=np.int32)
+    valid = g["node2cluster"] >= 0
+    init = np.stack([synth.init_vehicle_nodes(random.Random(50 + r), N, V, valid) for r in range(R)]).astype(np.int32)
+    init[5] = init[0]                             # same day, same start: must stay identical
+    env = mk_env(g, R, **MODES[mode])
+    env.load_order_days(days, replica_day)
+    env.reset(init)
+    oracles = []
+    for r in range(R):
+        o = mk_oracle(g, days[replica_day[r]])
+        o.reset(init[r])
+        oracles.append(o)
+    Ts = [o.num_ticks for o in oracles]
+    assert env.T == max(Ts) and len(set(Ts)) > 1
+    for r in range(R):
+        assert env.replica_ticks(r) == (Ts[r], days[replica_day[r]][0].size)
+    frozen = {}
+    for t in range(env.T):
+        env.step()
+        ob, cn = env.obs(), env.counters()
+        for r, o in enumerate(oracles):
+            if t < Ts[r]:
+                o.begin_tick()
+                oo, oc = o.obs(), o.counters()
+                for a, b in (("idle_pre", "idle_pre"), ("idle_now", "idle_post"), ("supply", "supply"), ("cl_orders", "cl_orders"), ("inflight", "inflight")):
+                    np.testing.assert_array_equal(ob[a][r], oo[b], err_msg="tick %d replica %d obs %s" % (t, r, a))
+                for i, k in enumerate(("order_num", "reject_num", "matched", "wait_sum")):
+                    assert cn[r, i] == oc[k], (t, r, k, cn[r, i], oc[k])
+                assert cn[r, 7] == oc["evals"] and cn[r, 6] == oc["sum_order_value"], (t, r)
+                if t % 7 == 0 or t == Ts[r] - 1:
+                    check_lists(env, r, o, t)
+                o.end_tick()
+                if t == Ts[r] - 1:
+                    frozen[r] = (env.lists(r), cn[r].copy())
+            else:
+                # SimCity of this city has returned (:1048): nothing moves any more
+                L0, c0 = frozen[r]
+                assert (cn[r] == c0).all(), (t, r)
+                if t % 5 == 0:
+                    L1 = env.lists(r)
+                    for k in L0:
+                        np.testing.assert_array_equal(L1[k], L0[k], err_msg="replica %d moved after its day ended (%s)" % (r, k))
+        env.advance()
+    env.sync()
+    od = env.orders()
+    for r, o in enumerate(oracles):
+        exp = o.orders()
+        n = exp["status"].size
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(od[k][r][:n], exp[k], err_msg="replica %d %s" % (r, k))
+        assert (od["status"][r][n:] == 0).all() and (od["vehicle"][r][n:] == -1).all()
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(od[k][5], od[k][0])
+    tot = env.total_counters()
+    assert tot[0] == sum(o.counters()["order_num"] for o in oracles) and tot[6] == sum(o.counters()["sum_order_value"] for o in oracles)
+    # the same days again (episode restart), through vds_run
+    env.reset_again(); env.run(env.T)
+    assert (env.total_counters() == tot).all()
+    env.close()
+
+
+def test_strided_form_and_identical_days_equal_the_shared_day_kernel():
+    g = load_golden("tiny_kmeans")
+    V, N, R = int(g["V"]), int(g["N"]), 6
+    valid = g["node2cluster"] >= 0
+    init = np.stack([synth.init_vehicle_nodes(random.Random(70 + r), N, V, valid) for r in range(R)]).astype(np.int32)
+    day = (g["o_release_min"], g["o_pickup"], g["o_delivery"])
+    O = day[0].size
+    ref = mk_env(g, R); ref.load_orders(*day); ref.reset(init); ref.run(ref.T)
+    assert ref.main_kernel() == "k_tick_rows"
+    exp, expc = ref.orders(), ref.counters()
+    # (a) R copies of the day, stride O: every row goes through the per-row variant
+    a = mk_env(g, R)
+    a.load_orders_strided(np.tile(day[0], R), np.tile(day[1], R), np.tile(day[2], R), O, O)
+    a.reset(init); a.run(a.T)
+    # (b) padded stride, (c) stride 0 == shared day
+    pad = 13
+    rows = [np.concatenate([np.tile(np.concatenate([x, np.zeros(pad, np.int32)]), R)]) for x in day]
+    b = mk_env(g, R); b.load_orders_strided(rows[0], rows[1], rows[2], O, O + pad); b.reset(init); b.run(b.T)
+    c = mk_env(g, R); c.load_orders_strided(day[0], day[1], day[2], O, 0); c.reset(init); c.run(c.T)
+    for env in (a, b, c):
+        got = env.orders()
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k], exp[k])
+        assert (env.counters() == expc).all()
+        env.close()
+    with pytest.raises(Exception, match="replica_stride"):
+        d = mk_env(g, R); d.load_orders_strided(day[0], day[1], day[2], O, O - 1)
+    ref.close()
+
+
+def test_full_size_distinct_days_config2():
+    """configs[1] at bench size with 8 distinct synthetic days over 1024 replicas: anchors against the oracle."""
+    R, D = 1024, 8
+    w = workloads.didi_day("cfg2")
+    days = workloads.distinct_days(w, D)
+    init = w.vehicle_nodes(R)
+    env = w.make_env(R, load=False)
+    env.load_order_days(days)
+    env.reset(init)
+    env.run(env.T)
+    env.sync()
+    cn = env.counters()
+    for r in (0, 1, 7, 8, 515, 1023):
+        d = days[r % D]
+        o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, d[0], d[1], d[2], w.vehicles)
+        o.reset(init[r]); o.run_day()
+        exp, oc, got = o.orders(), o.counters(), env.orders(r, 1)
+        n = exp["status"].size
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][0][:n], exp[k], err_msg="replica %d %s" % (r, k))
+        assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
+    env.close()

@@ -147,11 +147,14 @@ def test_drop_in_from_data_directory_with_focus_region_and_reload(tmp_path):
     np.testing.assert_array_equal(sim._init_nodes[0], g["veh_node"])
     assert len(sim.Orders) == g["o_pickup"].size and len(sim.Clusters) == int(g["C"])
     sim.SimCity()
-    # same-minute ties may be ordered differently from the reference's unstable sort: compare what is invariant
+    # ReadOrder's unstable sort is reproduced exactly (world.read_orders): the day is the reference's, order for order
     assert sim.step == int(g["n_ticks"]) and sim.OrderNum == int(g["order_num"])
-    same_order = np.array_equal(sim._world.o_pickup, g["o_pickup"]) and np.array_equal(sim._world.o_delivery, g["o_delivery"])
-    if same_order:
-        assert (sim.RejectNum, sim.TotallyWaitTime, sim.SumOrderValue) == (int(g["reject_num"]), int(g["wait_sum"]), int(g["sum_order_value"]))
+    np.testing.assert_array_equal(sim._world.o_pickup, g["o_pickup"])
+    np.testing.assert_array_equal(sim._world.o_delivery, g["o_delivery"])
+    assert (sim.RejectNum, sim.TotallyWaitTime, sim.SumOrderValue) == (int(g["reject_num"]), int(g["wait_sum"]), int(g["sum_order_value"]))
+    st = sim.env.orders(0, 1)
+    np.testing.assert_array_equal(st["status"][0], g["o_status"])
+    np.testing.assert_array_equal(st["vehicle"][0], g["o_vehicle"])
     # Reload: another day from data/test
     os.makedirs(os.path.join(data, "test"))
     start2, pick2, dele2 = synth.make_orders(77, city.N, 1500)

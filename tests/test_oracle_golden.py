@@ -35,7 +35,11 @@ def replay(g, check_lists):
             np.testing.assert_array_equal(L["arr_min"], g["l_arr_min"][t])
         if t in disp:
             rows = np.array(disp[t])
-            o.dispatch(rows[:, 1], rows[:, 4])
+            extra = int(g["dispatch_extra_minutes"]) if "dispatch_extra_minutes" in g else 0
+            if extra:      # the hook body wrote its own arrival time: RealExpTime + road cost + a loading delay
+                o.dispatch_at(rows[:, 1], rows[:, 4], arrive_min=o.now_min + rows[:, 5] + extra)
+            else:
+                o.dispatch(rows[:, 1], rows[:, 4])
         np.testing.assert_array_equal(o.obs()["idle_now"], g["t_idle_after_dispatch"][t])
         o.end_tick()
     return o

@@ -37,11 +37,17 @@ SYMBOLS = {
     "vds_set_stream": (C.c_int, [_VP, _VP]),
     "vds_load_static": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP, _I32]),
     "vds_load_orders": (C.c_int, [_VP, _VP, _VP, _VP, _I32]),
+    "vds_load_order_days": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP]),
+    "vds_load_orders_strided": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I64]),
+    "vds_replica_ticks": (C.c_int, [_VP, _I32, C.POINTER(_I32), C.POINTER(_I32)]),
+    "vds_set_idle_cap": (C.c_int, [_VP, _I32]),
+    "vds_idle_cap": (C.c_int, [_VP]),
     "vds_num_ticks": (C.c_int, [_VP, C.POINTER(_I32)]),
     "vds_reset": (C.c_int, [_VP, _VP]),
     "vds_reset_again": (C.c_int, [_VP]),
     "vds_step": (C.c_int, [_VP]),
     "vds_apply_dispatch": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    "vds_apply_dispatch_ex": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vds_apply_dispatch_device": (C.c_int, [_VP, _I32, _VP]),
     "vds_advance": (C.c_int, [_VP]),
     "vds_run": (C.c_int, [_VP, _I32]),
@@ -60,6 +66,8 @@ SYMBOLS = {
     "vds_read_vehicles": (C.c_int, [_VP, _I32] + [_VP] * 5),
     "vds_read_work": (C.c_int, [_VP, _VP]),
     "vds_py_random_nodes": (C.c_int, [C.c_uint64, _I32, _I32, _VP, _VP]),
+    "vds_cluster_cost_sums": (C.c_int, [_I32, _VP, _I32, _VP, _I32, _VP, _VP]),
+    "vds_cluster_cost_sums_error": (C.c_char_p, []),
     "vds_main_kernel": (C.c_char_p, [_VP]),
     "vds_dfs_sequences": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, C.c_int64]),
 }
@@ -98,6 +106,8 @@ def load():
                 pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in {**SYMBOLS, **TEST_SYMBOLS}.items():
+            if os.environ.get("VDS_LIB") and not hasattr(lib, name):
+                continue                 # an older build loaded on purpose for an A/B timing (profiles/ab.sh)
             fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args

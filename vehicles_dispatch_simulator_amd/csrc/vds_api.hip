@@ -21,7 +21,7 @@ void launch_match_dfs(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
-                     const int *, const int *, hipStream_t);
+                     const int *, const int *, const int *, const int *, hipStream_t);
 void launch_dispatch_dense(const Static &, const State &, int, int, const int *, int, hipStream_t);
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
@@ -33,6 +33,16 @@ void read_prof(unsigned long long *, hipStream_t);
 using namespace vds;
 
 static thread_local std::string g_create_error;
+
+// One loaded order day on the host side (the device side is vds::DayDesc)
+struct DayHost {
+    int O = 0;                           // all orders of the day incl. never-processed ones
+    int T = 0, now0 = 0, q_base = 0, Oq = 0;
+    std::vector<int> so_id;              // q - q_base -> order id
+    std::vector<int> o_tick;             // order id -> tick (or -1 never processed)
+    std::vector<long long> value_upto;   // [T+1] prefix of OrderValue of processed orders by tick
+    long long value_all = 0;
+};
 
 struct vds_handle {
     vds_config cfg{};
@@ -53,13 +63,13 @@ struct vds_handle {
     int lds_ints = 0;
     // host mirrors
     std::vector<int> node2cluster, node_local, cl_off, cl_nodes, cost_host;
-    std::vector<int> so_id;              // q -> order id
-    std::vector<int> o_tick;             // order id -> tick (or -1 never processed)
-    std::vector<long long> value_upto;   // [T+1] prefix of OrderValue of processed orders by tick
-    long long value_all = 0;
+    std::vector<DayHost> days;         // the loaded order days
+    std::vector<int> replica_day;        // [R]
     std::vector<void *> dev_allocs;          // static tables, scratch
     std::vector<void *> order_allocs;        // tables of the loaded day (replaced by the next vds_load_orders)
     std::vector<void *> state_allocs;        // per-replica state (kept across days while the capacities still fit)
+    std::vector<void *> idle_allocs;         // the idle table alone (regrown by vds_reset / vds_set_idle_cap)
+    int idle_cap_grown = 0;                  // capacity chosen by a reset histogram or vds_set_idle_cap (0: none)
     std::vector<void *> *alloc_sink = nullptr;
     // device scratch
     int *d_veh_node = nullptr;
@@ -234,6 +244,7 @@ int vds_destroy(vds_handle *h) {
     for (void *p : h->dev_allocs) (void)hipFree(p);
     for (void *p : h->order_allocs) (void)hipFree(p);
     for (void *p : h->state_allocs) (void)hipFree(p);
+    for (void *p : h->idle_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -455,8 +466,11 @@ static int alloc_state(vds_handle *h, int O) {
     const int V = S.V, R = S.R, C = S.C;
     const int per = (V + C - 1) / C;
     int idle_cap = h->cfg.idle_cap > 0 ? h->cfg.idle_cap : std::min(round_up(std::max(V, 1), 64), round_up(4 * per + 64, 64));
+    if (h->idle_cap_grown > idle_cap) idle_cap = h->idle_cap_grown;      // a previous reset / vds_set_idle_cap raised it
     idle_cap = round_up(idle_cap, 64);
-    if (idle_cap > 1024) return fail(h, VDS_EINVAL, "idle_cap=%d > 1024 slots per (replica, cluster) is not supported by the register-resident match kernels", idle_cap);
+    // lists longer than the register tables of the match kernels (128 / 256 / 1024 entries) take their in-place
+    // slow paths: any length up to V works
+    if (idle_cap > (1 << 24)) return fail(h, VDS_EINVAL, "idle_cap=%d > 2^24 slots per (replica, cluster) unsupported", idle_cap);
     int H = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
     if (H < 2 || (H & (H - 1))) return fail(h, VDS_EINVAL, "ring_ticks=%d must be a power of two >= 2", H);
     const long long per_tick = ((long long)O + (long long)std::max(S.T, 1) * C - 1) / ((long long)std::max(S.T, 1) * C);
@@ -464,7 +478,7 @@ static int alloc_state(vds_handle *h, int O) {
     ring_cap = round_up(ring_cap, 16);
     if (ring_cap > 65520) return fail(h, VDS_EINVAL, "ring_cap=%d > 65520 unsupported", ring_cap);
     int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
-    if (!h->state_allocs.empty() && S.idle_cap == idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap)
+    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap)
         return VDS_OK;                                   // another day on the same handle: the state tables still fit
     for (void *p : h->state_allocs) (void)hipFree(p);
     h->state_allocs.clear();
@@ -475,7 +489,15 @@ static int alloc_state(vds_handle *h, int O) {
     h->alloc_sink = &h->state_allocs;
     if ((rc = dev_alloc(h, &D.hdr, B * HDR_WORDS))) return rc;
     if ((rc = dev_alloc(h, &D.cnt, B * CNT_WORDS))) return rc;
-    if ((rc = dev_alloc(h, &D.idle, B * idle_cap))) return rc;
+    {   // the idle table lives in its own allocation list: vds_reset / vds_set_idle_cap may replace it alone
+        std::vector<void *> *keep = h->alloc_sink;
+        h->alloc_sink = &h->idle_allocs;
+        for (void *p : h->idle_allocs) (void)hipFree(p);
+        h->idle_allocs.clear();
+        rc = dev_alloc(h, &D.idle, B * idle_cap);
+        h->alloc_sink = keep;
+        if (rc) return rc;
+    }
     if ((rc = dev_alloc(h, &D.ring, (size_t)H * B * ring_cap))) return rc;
     if ((rc = dev_alloc(h, &D.ring_cnt, (size_t)H * B))) return rc;
     if ((rc = dev_alloc(h, &D.fl, B * far_cap))) return rc;
@@ -491,9 +513,13 @@ static int alloc_state(vds_handle *h, int O) {
     return VDS_OK;
 }
 
-static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
+// self.Orders after CreateAllInstantiate (:325-342) for n_days independent days; replica r replays day replica_day[r].
+static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min, const int32_t *pickup,
+                          const int32_t *delivery, const int32_t *replica_day) {
     if (!h || !h->have_static) return fail(h, VDS_EINVAL, "vds_load_orders: call vds_load_static first");
-    if (O < 1 || !release_min || !pickup || !delivery) return fail(h, VDS_EINVAL, "vds_load_orders: bad argument");
+    if (n_days < 1 || !day_off || !release_min || !pickup || !delivery) return fail(h, VDS_EINVAL, "vds_load_orders: bad argument");
+    for (int d = 0; d < n_days; ++d)
+        if (day_off[d + 1] - day_off[d] < 1 || day_off[d + 1] - day_off[d] > 0x7fffffff) return fail(h, VDS_EINVAL, "vds_load_orders: day %d has no orders (or more than 2^31)", d);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->have_orders) {
         // another day on the same handle (Reload, :130-212): the previous day's tables go, the static tables stay,
@@ -507,63 +533,97 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
     }
     Static &S = h->S;
     const int N = S.N, C = S.C, tick = S.tick_minutes;
-    // SimCity prologue :1037-1040
-    const long long now0 = (long long)release_min[0] - tick;
-    const long long end = (long long)release_min[O - 1] + 3LL * tick;
-    const int T = end >= now0 ? (int)((end - now0) / tick) + 1 : 0;
-    if (T > 65535) return fail(h, VDS_EINVAL, "vds_load_orders: %d ticks > 65535 unsupported", T);
-    S.now0 = (int)now0; S.T = T; h->O = O;
-    std::vector<int> value(O);
-    {
-        const std::vector<int> &costh = h->cost_host;
-        for (int i = 0; i < O; ++i) {
-            if (pickup[i] < 0 || pickup[i] >= N || delivery[i] < 0 || delivery[i] >= N) return fail(h, VDS_EINVAL, "vds_load_orders: order %d has a node outside [0,%d)", i, N);
-            value[i] = costh[(size_t)delivery[i] * N + pickup[i]];           // :341-342
+    h->replica_day.assign(S.R, 0);
+    for (int r = 0; r < S.R; ++r) {
+        const int d = replica_day ? replica_day[r] : r % n_days;
+        if (d < 0 || d >= n_days) return fail(h, VDS_EINVAL, "vds_load_order_days: replica %d is mapped to day %d of %d", r, d, n_days);
+        h->replica_day[r] = d;
+    }
+    h->days.assign(n_days, DayHost());
+    std::vector<int4> so_rec;
+    std::vector<int> bkt_off, tick_off, ord_q, so_pnode;
+    std::vector<DayDesc> ddesc(n_days);
+    int Tmax = 0, Oqmax = 0, Omax = 0, mto = 0;
+    long long Ototal = 0;
+    for (int d = 0; d < n_days; ++d) {
+        DayHost &H = h->days[d];
+        const int32_t *rel = release_min + day_off[d], *pk = pickup + day_off[d], *dl = delivery + day_off[d];
+        const int O = (int)(day_off[d + 1] - day_off[d]);
+        // SimCity prologue :1037-1040
+        const long long now0 = (long long)rel[0] - tick;
+        const long long end = (long long)rel[O - 1] + 3LL * tick;
+        const int T = end >= now0 ? (int)((end - now0) / tick) + 1 : 0;
+        if (T > 65535) return fail(h, VDS_EINVAL, "vds_load_orders: %d ticks > 65535 unsupported", T);
+        H.O = O; H.T = T; H.now0 = (int)now0; H.q_base = (int)so_rec.size();
+        std::vector<int> value(O);
+        {
+            const std::vector<int> &costh = h->cost_host;
+            for (int i = 0; i < O; ++i) {
+                if (pk[i] < 0 || pk[i] >= N || dl[i] < 0 || dl[i] >= N) return fail(h, VDS_EINVAL, "vds_load_orders: order %d has a node outside [0,%d)", i, N);
+                value[i] = costh[(size_t)dl[i] * N + pk[i]];           // :341-342
+            }
         }
-    }
-    // the cursor of MatchFunction (:912-973): order i is processed at the first tick whose window
-    // covers every order up to i; the last order is never processed (quirk Q1, :914-915)
-    h->o_tick.assign(O, -1);
-    std::vector<int> cnt((size_t)T * C + 1, 0);
-    long long run = 0;
-    int n_proc = 0;
-    h->value_all = 0;
-    for (int i = 0; i < O; ++i) {
-        h->value_all += value[i];
-        long long x = (long long)release_min[i] - now0;
-        long long ti = x < 0 ? 0 : x / tick;
-        run = std::max(run, ti);
-        if (i == O - 1 || run >= T) continue;
-        int pc = h->node2cluster[pickup[i]], dc = h->node2cluster[delivery[i]];
-        if (pc < 0 || dc < 0) return fail(h, VDS_ESTATE, "vds_load_orders: order %d touches a node outside every cluster (KeyError in the reference, :918/:960)", i);
-        h->o_tick[i] = (int)run;
-        cnt[(size_t)run * C + pc + 1]++;
-        n_proc++;
-    }
-    for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
-    std::vector<int> bkt_off(cnt);
-    std::vector<int4> so_rec(n_proc);
-    h->so_id.assign(n_proc, 0);
-    std::vector<int> ord_q(n_proc), tick_off(T + 1, 0), so_pnode(n_proc);
-    h->value_upto.assign(T + 1, 0);
-    {
-        std::vector<int> fill(bkt_off.begin(), bkt_off.end() - 1);
-        int k = 0;
+        // the cursor of MatchFunction (:912-973): order i is processed at the first tick whose window
+        // covers every order up to i; the last order is never processed (quirk Q1, :914-915)
+        H.o_tick.assign(O, -1);
+        std::vector<int> cnt((size_t)T * C + 1, 0);
+        long long run = 0;
+        int n_proc = 0;
+        H.value_all = 0;
         for (int i = 0; i < O; ++i) {
-            int ti = h->o_tick[i];
-            if (ti < 0) continue;
-            int pc = h->node2cluster[pickup[i]], dc = h->node2cluster[delivery[i]];
-            int q = fill[(size_t)ti * C + pc]++;
-            so_rec[q] = make_int4(i, h->node_local[pickup[i]] | (h->node_local[delivery[i]] << 16), dc | (pc << 16), value[i]);
-            h->so_id[q] = i;
-            so_pnode[q] = pickup[i];
-            ord_q[k++] = q;
-            tick_off[ti + 1]++;
-            h->value_upto[ti + 1] += value[i];
+            H.value_all += value[i];
+            long long x = (long long)rel[i] - now0;
+            long long ti = x < 0 ? 0 : x / tick;
+            run = std::max(run, ti);
+            if (i == O - 1 || run >= T) continue;
+            int pc = h->node2cluster[pk[i]], dc = h->node2cluster[dl[i]];
+            if (pc < 0 || dc < 0) return fail(h, VDS_ESTATE, "vds_load_orders: order %d touches a node outside every cluster (KeyError in the reference, :918/:960)", i);
+            H.o_tick[i] = (int)run;
+            cnt[(size_t)run * C + pc + 1]++;
+            n_proc++;
         }
-        for (int t = 0; t < T; ++t) { tick_off[t + 1] += tick_off[t]; h->value_upto[t + 1] += h->value_upto[t]; }
+        if ((long long)so_rec.size() + n_proc >= (1ll << 31)) return fail(h, VDS_EINVAL, "vds_load_orders: more than 2^31 processed orders on one handle");
+        for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+        H.Oq = n_proc;
+        H.so_id.assign(n_proc, 0);
+        H.value_upto.assign(T + 1, 0);
+        std::vector<int> toff(T + 1, 0);
+        const size_t rec0 = so_rec.size(), oq0 = ord_q.size();
+        so_rec.resize(rec0 + n_proc);
+        so_pnode.resize(rec0 + n_proc);
+        ord_q.resize(oq0 + n_proc);
+        {
+            std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+            int k = 0;
+            for (int i = 0; i < O; ++i) {
+                int ti = H.o_tick[i];
+                if (ti < 0) continue;
+                int pc = h->node2cluster[pk[i]], dc = h->node2cluster[dl[i]];
+                int q = fill[(size_t)ti * C + pc]++;
+                so_rec[rec0 + q] = make_int4(i, h->node_local[pk[i]] | (h->node_local[dl[i]] << 16), dc | (pc << 16), value[i]);
+                H.so_id[q] = i;
+                so_pnode[rec0 + q] = pk[i];
+                ord_q[oq0 + k++] = (int)rec0 + q;                       // absolute positions
+                toff[ti + 1]++;
+                H.value_upto[ti + 1] += value[i];
+            }
+            for (int t = 0; t < T; ++t) { toff[t + 1] += toff[t]; H.value_upto[t + 1] += H.value_upto[t]; }
+        }
+        int day_mto = 0;
+        for (int t = 0; t < T; ++t) day_mto = std::max(day_mto, toff[t + 1] - toff[t]);
+        ddesc[d].bkt_base = (int)bkt_off.size();
+        ddesc[d].tick_base = (int)tick_off.size();
+        ddesc[d].now0 = H.now0; ddesc[d].T = T; ddesc[d].q_base = H.q_base; ddesc[d].Oq = n_proc;
+        ddesc[d].max_tick_orders = day_mto; ddesc[d].pad = 0;
+        if ((long long)bkt_off.size() + (long long)cnt.size() >= (1ll << 31)) return fail(h, VDS_EINVAL, "vds_load_orders: bucket table exceeds 2^31 entries");
+        for (int v : cnt) bkt_off.push_back(v + (int)rec0);            // absolute positions
+        for (int v : toff) tick_off.push_back(v + (int)oq0);
+        Tmax = std::max(Tmax, T); Oqmax = std::max(Oqmax, n_proc); Omax = std::max(Omax, O); mto = std::max(mto, day_mto);
+        Ototal += O;
     }
-    S.Oq = n_proc;
+    S.now0 = h->days[0].now0; S.T = Tmax; S.Oq = Oqmax; h->O = Omax;
+    S.n_days = n_days;
+    S.max_tick_orders = mto;
     int rc;
     int *d;
     int4 *d4;
@@ -573,22 +633,53 @@ static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int
     if ((rc = upload(h, &d, bkt_off))) return rc; S.bkt_off = d;
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;
     if ((rc = upload(h, &d, so_pnode))) return rc; S.so_pnode = d;
-    S.max_tick_orders = 0;
-    for (int t = 0; t < T; ++t) S.max_tick_orders = std::max(S.max_tick_orders, tick_off[t + 1] - tick_off[t]);
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
-    if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(n_proc, 1)))) return rc;
+    { DayDesc *dd; if ((rc = upload(h, &dd, ddesc))) return rc; S.day = dd; }
+    if ((rc = upload(h, &d, h->replica_day))) return rc; S.replica_day = d;
+    if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1)))) return rc;
     h->alloc_sink = nullptr;
-    if ((rc = alloc_state(h, O))) return rc;
+    if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
         const Static &Z = h->S;
         const int ids2 = std::max(Z.max_tick_orders, 4 * Z.C);
         const size_t lds2 = ((size_t)9 * Z.C + 1 + ids2 + ((size_t)Z.V + 2) / 2) * sizeof(int) + 2048;   // + static shared
-        h->dfs2_ok = h->dfs_mode && O <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 15) &&
+        h->dfs2_ok = h->dfs_mode && Omax <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 15) &&
                      Z.V <= 20480 && Z.N <= 65534 && Z.C <= 3072 && h->blk_ints < (1ll << 29) && Z.idle_cap <= 32767 && Z.max_tick_orders < 32768 &&
                      lds2 <= 64 * 1024;
     }
     h->have_orders = true;
     return VDS_OK;
+}
+
+static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
+    if (O < 1) return fail(h, VDS_EINVAL, "vds_load_orders: bad argument");
+    const int64_t off[2] = {0, O};
+    return load_days_impl(h, 1, off, release_min, pickup, delivery, nullptr);
+}
+
+// replica r's day starts at element r * replica_stride of the three arrays; stride 0 = one shared day
+static int load_orders_strided_impl(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O,
+                                    int64_t replica_stride) {
+    if (!h) return VDS_EINVAL;
+    if (replica_stride == 0) return load_orders_impl(h, release_min, pickup, delivery, O);
+    if (O < 1 || replica_stride < O) return fail(h, VDS_EINVAL, "vds_load_orders_strided: replica_stride must be 0 (shared day) or >= O");
+    const int R = h->cfg.replicas;
+    if (replica_stride == O) {
+        std::vector<int64_t> off(R + 1);
+        for (int r = 0; r <= R; ++r) off[r] = (int64_t)r * O;
+        return load_days_impl(h, R, off.data(), release_min, pickup, delivery, nullptr);
+    }
+    // padded rows: compact them
+    std::vector<int32_t> a((size_t)R * O), b((size_t)R * O), c((size_t)R * O);
+    std::vector<int64_t> off(R + 1);
+    for (int r = 0; r < R; ++r) {
+        memcpy(a.data() + (size_t)r * O, release_min + (size_t)r * replica_stride, (size_t)O * 4);
+        memcpy(b.data() + (size_t)r * O, pickup + (size_t)r * replica_stride, (size_t)O * 4);
+        memcpy(c.data() + (size_t)r * O, delivery + (size_t)r * replica_stride, (size_t)O * 4);
+        off[r] = (int64_t)r * O;
+    }
+    off[R] = (int64_t)R * O;
+    return load_days_impl(h, R, off.data(), a.data(), b.data(), c.data(), nullptr);
 }
 
 int vds_num_ticks(const vds_handle *h, int32_t *T) {
@@ -611,6 +702,29 @@ static int reset_device(vds_handle *h) {
     return VDS_OK;
 }
 
+// Replace the idle tables by ones with `cap` slots per (replica, cluster).  Episode state is lost: vds_reset /
+// vds_reset_again must follow.
+static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
+    if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_set_idle_cap: load static tables and orders first");
+    if (cap < 1) return fail(h, VDS_EINVAL, "vds_set_idle_cap: bad capacity %d", cap);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    cap = std::min(round_up(cap, 64), round_up(std::max(h->S.V, 1), 64));
+    if (cap > (1 << 24)) return fail(h, VDS_EINVAL, "vds_set_idle_cap: %d > 2^24 unsupported", cap);
+    if (cap == h->S.idle_cap) return VDS_OK;
+    for (void *p : h->idle_allocs) (void)hipFree(p);
+    h->idle_allocs.clear();
+    h->alloc_sink = &h->idle_allocs;
+    const int rc = dev_alloc(h, &h->D.idle, (size_t)h->S.C * h->S.R * cap);
+    h->alloc_sink = nullptr;
+    if (rc) return rc;
+    h->S.idle_cap = cap;
+    h->idle_cap_grown = cap;
+    // k_tick_replica2 addresses list positions with 15 bits
+    if (cap > 32767) h->dfs2_ok = false;
+    return VDS_OK;
+}
+
 static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
     if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_reset: load static tables and orders first");
     if (!veh_init_node && h->S.V > 0) return fail(h, VDS_EINVAL, "vds_reset: null veh_init_node");
@@ -621,6 +735,22 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
         int node = veh_init_node[i];
         if (node < 0 || node >= S.N || h->node2cluster[node] < 0)
             return fail(h, VDS_ESTATE, "vds_reset: vehicle %zu starts on node %d which is in no cluster (:254)", i, node);
+    }
+    if (h->cfg.idle_cap <= 0 && S.V > 0) {
+        // automatic capacity: the fullest start list plus headroom for the day (vehicles concentrate where trips end).
+        // An explicit vds_config.idle_cap is taken as given (overflow is then reported, never silently grown).
+        std::vector<int> cnt((size_t)S.C);
+        int fullest = 0;
+        for (int r = 0; r < S.R; ++r) {
+            std::fill(cnt.begin(), cnt.end(), 0);
+            const int32_t *vn = veh_init_node + (size_t)r * S.V;
+            for (int v = 0; v < S.V; ++v) fullest = std::max(fullest, ++cnt[h->node2cluster[vn[v]]]);
+        }
+        const int want = std::min(round_up(std::max(S.V, 1), 64), round_up(2 * fullest + 64, 64));
+        if (want > S.idle_cap) {
+            int rc2 = set_idle_cap_impl(h, want);
+            if (rc2) return rc2;
+        }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_veh_node, veh_init_node, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     int rc = reset_device(h);
@@ -725,7 +855,13 @@ int vds_sync(vds_handle *h) {
     if (err[0] & ERR_FL_CAP) return fail(h, VDS_ECAPACITY, "far-arrival table overflow: more than far_cap=%d vehicles on trips longer than the ring horizon to one (replica, cluster); raise vds_config.far_cap", h->S.fl_cap);
     if (err[0] & ERR_INBOX_CAP) return fail(h, VDS_ECAPACITY, "far-arrival inbox overflow: more than far_cap=%d long trips sent to one (replica, cluster) in one tick; raise vds_config.far_cap", h->S.in_cap);
     if (err[0] & ERR_RING_CAP) return fail(h, VDS_ECAPACITY, "arrival ring overflow: more than ring_cap=%d vehicles due in one (replica, cluster) in one tick; raise vds_config.ring_cap", h->S.ring_cap);
-    if (err[0] & ERR_DISPATCH) return fail(h, VDS_ESTATE, "dispatch of an idle position that does not exist (or listed twice)");
+    if (err[0] & ERR_DISPATCH) {
+        // refused actions were skipped before anything of theirs was posted, so the episode stays consistent: report the
+        // error once and clear it (capacity overflows above are different: vehicles were lost, they stay sticky)
+        const int keep = err[0] & ~ERR_DISPATCH;
+        HIPCHK(h, hipMemcpy(h->D.err, &keep, sizeof(int), hipMemcpyHostToDevice));
+        return fail(h, VDS_ESTATE, "dispatch of an idle position that does not exist (or listed twice); the action was skipped");
+    }
     return VDS_OK;
 }
 
@@ -737,7 +873,8 @@ int vds_clock(const vds_handle *h, int32_t *step, int32_t *now_min) {
 }
 
 static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
-                       const int32_t *idle_pos, const int32_t *target_node) {
+                       const int32_t *idle_pos, const int32_t *target_node, const int32_t *arrive_min = nullptr,
+                       const int32_t *counted = nullptr) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_apply_dispatch: call vds_reset first");
     if (h->last_stepped != h->t) return fail(h, VDS_EINVAL, "vds_apply_dispatch: must follow vds_step of the current tick (the hook runs after Match, :1083)");
     if (n == 0) return VDS_OK;
@@ -756,19 +893,29 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
         if (replica[a] != replica[b]) return replica[a] < replica[b];
         return from_cluster[a] < from_cluster[b];
     });
-    // packed: grp_off | replica | cluster | pos | target | seq
+    for (int k = 1; k < n; ++k) {          // the same idle position twice in one hook body: refuse the call, nothing is applied
+        const int a = order[k - 1], b = order[k];
+        if (replica[a] == replica[b] && from_cluster[a] == from_cluster[b]) {
+            for (int j = k - 1; j >= 0 && replica[order[j]] == replica[b] && from_cluster[order[j]] == from_cluster[b]; --j)
+                if (idle_pos[order[j]] == idle_pos[b])
+                    return fail(h, VDS_ESTATE, "vds_apply_dispatch: actions %d and %d name the same idle position %d of cluster %d, replica %d",
+                                order[j], b, idle_pos[b], from_cluster[b], replica[b]);
+        }
+    }
+    // packed: replica | cluster | pos | target | seq | arrive | counted | grp_off
     std::vector<int> grp_off;
-    std::vector<int> pack((size_t)5 * n);
+    std::vector<int> pack((size_t)7 * n);
     for (int k = 0; k < n; ++k) {
         int i = order[k];
         if (k == 0 || replica[i] != replica[order[k - 1]] || from_cluster[i] != from_cluster[order[k - 1]]) grp_off.push_back(k);
         pack[k] = replica[i]; pack[(size_t)n + k] = from_cluster[i]; pack[(size_t)2 * n + k] = idle_pos[i];
         pack[(size_t)3 * n + k] = target_node[i]; pack[(size_t)4 * n + k] = h->dispatch_seq + i;   // dict insertion order = action order
+        pack[(size_t)5 * n + k] = arrive_min ? arrive_min[i] : 0; pack[(size_t)6 * n + k] = counted ? counted[i] : 1;
     }
     const int ngroups = (int)grp_off.size();
     grp_off.push_back(n);
     h->dispatch_seq += n;
-    const size_t need = (size_t)5 * n + grp_off.size();
+    const size_t need = (size_t)7 * n + grp_off.size();
     if (need > h->actions_cap) {
         int *p;
         int rc = dev_alloc(h, &p, need * 2);
@@ -778,7 +925,8 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
     HIPCHK(h, hipMemcpyAsync(h->d_actions, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_actions + pack.size(), grp_off.data(), grp_off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     const int *a = h->d_actions;
-    launch_dispatch(S, h->D, h->t, ngroups, a + pack.size(), a, a + n, a + 2 * (size_t)n, a + 3 * (size_t)n, a + 4 * (size_t)n, h->stream);
+    launch_dispatch(S, h->D, h->t, ngroups, a + pack.size(), a, a + n, a + 2 * (size_t)n, a + 3 * (size_t)n, a + 4 * (size_t)n,
+                    arrive_min ? a + 5 * (size_t)n : nullptr, counted ? a + 6 * (size_t)n : nullptr, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));   // pack/grp_off are stack-owned
     return VDS_OK;
@@ -803,10 +951,16 @@ static int read_obs_impl(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, in
     return vds_sync(h);
 }
 
-static void finish_counters(const vds_handle *h, const long long *raw, int64_t *out) {
-    // raw: CNT_* slots; out: VDS_CNT_* slots
+// value of the orders of replica r's day that have not been processed (yet): they count in SumOrderValue (:1095-1100)
+static long long unprocessed_value(const vds_handle *h, int r) {
+    const DayHost &H = h->days[h->replica_day[r]];
     const int tdone = h->last_stepped + 1;   // ticks whose orders have been processed
-    const long long processed_value = h->value_upto.empty() ? 0 : h->value_upto[std::min<size_t>(tdone, h->value_upto.size() - 1)];
+    const long long processed_value = H.value_upto.empty() ? 0 : H.value_upto[std::min<size_t>(tdone, H.value_upto.size() - 1)];
+    return H.value_all - processed_value;
+}
+
+static void finish_counters(const vds_handle *h, int r, const long long *raw, int64_t *out) {
+    // raw: CNT_* slots; out: VDS_CNT_* slots
     out[VDS_CNT_ORDER_NUM] = raw[CNT_ORDERS];
     out[VDS_CNT_REJECT_NUM] = raw[CNT_REJECTS];
     out[VDS_CNT_MATCHED] = raw[CNT_ORDERS] - raw[CNT_REJECTS];
@@ -814,7 +968,7 @@ static void finish_counters(const vds_handle *h, const long long *raw, int64_t *
     out[VDS_CNT_DISPATCH_NUM] = raw[CNT_DISPATCH];
     out[VDS_CNT_DISPATCH_COST] = raw[CNT_DISPATCH_COST];
     // :1095-1100 sums OrderValue over every order whose ArriveInfo != "Reject": matched + not (yet) processed
-    out[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + (h->value_all - processed_value);
+    out[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + unprocessed_value(h, r);
     out[VDS_CNT_EVALS] = raw[CNT_EVALS];
 }
 
@@ -836,7 +990,7 @@ static int read_counters_impl(vds_handle *h, int64_t *out) {
     HIPCHK(h, hipMemcpyAsync(raw.data(), h->d_cnt_per, raw.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     int rc = vds_sync(h);
     if (rc) return rc;
-    for (int r = 0; r < h->S.R; ++r) finish_counters(h, raw.data() + (size_t)r * CNT_WORDS, out + (size_t)r * VDS_NUM_COUNTERS);
+    for (int r = 0; r < h->S.R; ++r) finish_counters(h, r, raw.data() + (size_t)r * CNT_WORDS, out + (size_t)r * VDS_NUM_COUNTERS);
     return VDS_OK;
 }
 
@@ -853,10 +1007,10 @@ static int reduce_counters_impl(vds_handle *h, int64_t *out, void **dev_ptr) {
         if (rc) return rc;
         // value of unprocessed orders counts once per replica
         int64_t tmp[VDS_NUM_COUNTERS];
-        finish_counters(h, raw, tmp);
-        const int tdone = h->last_stepped + 1;
-        const long long processed_value = h->value_upto.empty() ? 0 : h->value_upto[std::min<size_t>(tdone, h->value_upto.size() - 1)];
-        tmp[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + (long long)h->S.R * (h->value_all - processed_value);
+        finish_counters(h, 0, raw, tmp);
+        long long rest = 0;
+        for (int r = 0; r < h->S.R; ++r) rest += unprocessed_value(h, r);
+        tmp[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + rest;
         memcpy(out, tmp, sizeof(tmp));
     }
     return VDS_OK;
@@ -879,7 +1033,8 @@ static int read_work_impl(vds_handle *h, int64_t *out) {
     HIPCHK(h, hipMemcpyAsync(raw, h->d_cnt_tot, sizeof(raw), hipMemcpyDeviceToHost, h->stream));
     int rc = vds_sync(h);
     if (rc) return rc;
-    out[0] = (int64_t)(h->last_stepped + 1) * h->S.R;
+    out[0] = 0;
+    for (int r = 0; r < h->S.R; ++r) out[0] += std::min(h->last_stepped + 1, h->days[h->replica_day[r]].T);
     out[1] = raw[CNT_ORDERS]; out[2] = raw[CNT_ORDERS] - raw[CNT_REJECTS]; out[3] = raw[CNT_EVALS];
     out[4] = raw[CNT_ARRIVALS]; out[5] = raw[CNT_DISPATCH]; out[6] = 0; out[7] = 0;
     return VDS_OK;
@@ -892,11 +1047,13 @@ static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *stat
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = vds_sync(h);
     if (rc) return rc;
-    const int Oq = S.Oq, O = h->O;
+    const int Oq = S.Oq, O = h->O;     // row strides: the longest day's (a shorter day leaves the tail of its row at 0 / -1)
     std::vector<int2> res((size_t)nr * std::max(Oq, 1));
     if (Oq > 0 && nr > 0)
         HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)r0 * Oq, (size_t)nr * Oq * sizeof(int2), hipMemcpyDeviceToHost));
     for (int r = 0; r < nr; ++r) {
+        const DayHost &H = h->days[h->replica_day[r0 + r]];
+        const int last = std::min(h->last_stepped, H.T - 1);
         uint8_t *st = status ? status + (size_t)r * O : nullptr;
         int32_t *vv = vehicle ? vehicle + (size_t)r * O : nullptr;
         int32_t *ww = wait ? wait + (size_t)r * O : nullptr;
@@ -905,9 +1062,9 @@ static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *stat
             if (vv) vv[i] = -1;
             if (ww) ww[i] = -1;
         }
-        for (int q = 0; q < Oq; ++q) {
-            const int i = h->so_id[q];
-            if (h->o_tick[i] > h->last_stepped) continue;        // cursor has not reached it yet
+        for (int q = 0; q < H.Oq; ++q) {
+            const int i = H.so_id[q];
+            if (H.o_tick[i] > last) continue;                    // cursor has not reached it yet
             const int2 e = res[(size_t)r * Oq + q];
             if (st) st[i] = e.x >= 0 ? 1 : 2;
             if (vv) vv[i] = e.x;
@@ -1088,6 +1245,30 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
     return guarded(h, "vds_load_orders", [&] { return load_orders_impl(h, release_min, pickup, delivery, O); });
 }
 
+int vds_set_idle_cap(vds_handle *h, int32_t cap) {
+    return guarded(h, "vds_set_idle_cap", [&] { return set_idle_cap_impl(h, cap); });
+}
+
+int vds_idle_cap(const vds_handle *h) { return (h && h->have_orders) ? h->S.idle_cap : VDS_EINVAL; }
+
+int vds_load_order_days(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min, const int32_t *pickup,
+                        const int32_t *delivery, const int32_t *replica_day) {
+    return guarded(h, "vds_load_order_days", [&] { return load_days_impl(h, n_days, day_off, release_min, pickup, delivery, replica_day); });
+}
+
+int vds_load_orders_strided(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O,
+                            int64_t replica_stride) {
+    return guarded(h, "vds_load_orders_strided", [&] { return load_orders_strided_impl(h, release_min, pickup, delivery, O, replica_stride); });
+}
+
+int vds_replica_ticks(const vds_handle *h, int32_t replica, int32_t *T, int32_t *n_orders) {
+    if (!h || !h->have_orders || replica < 0 || replica >= h->S.R) return VDS_EINVAL;
+    const DayHost &H = h->days[h->replica_day[replica]];
+    if (T) *T = H.T;
+    if (n_orders) *n_orders = H.O;
+    return VDS_OK;
+}
+
 int vds_reset(vds_handle *h, const int32_t *veh_init_node) {
     return guarded(h, "vds_reset", [&] { return reset_impl(h, veh_init_node); });
 }
@@ -1099,6 +1280,11 @@ int vds_step(vds_handle *h) {
 int vds_apply_dispatch(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster,
                        const int32_t *idle_pos, const int32_t *target_node) {
     return guarded(h, "vds_apply_dispatch", [&] { return apply_dispatch_impl(h, n, replica, from_cluster, idle_pos, target_node); });
+}
+
+int vds_apply_dispatch_ex(vds_handle *h, int32_t n, const int32_t *replica, const int32_t *from_cluster, const int32_t *idle_pos,
+                          const int32_t *target_node, const int32_t *arrive_min, const int32_t *counted) {
+    return guarded(h, "vds_apply_dispatch_ex", [&] { return apply_dispatch_impl(h, n, replica, from_cluster, idle_pos, target_node, arrive_min, counted); });
 }
 
 int vds_read_obs(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {

@@ -54,8 +54,26 @@ __host__ __device__ inline unsigned long long entry_key(int id, int w) {
 
 // sorted order record: x = order id, y = pick_local | dest_local << 16,
 // z = dest_cluster | pick_cluster << 16, w = OrderValue
+// One order day.  A handle holds n_days of them (vds_load_order_days); replica r replays day replica_day[r] - the
+// reference's one Simulation == one city == its own Orders (simulator.py:325-342).  The per-day tables are concatenated;
+// bkt_off / tick_off / ord_q hold ABSOLUTE positions (into so_rec / ord_q), results live at out[r][q - q_base].
+struct DayDesc {
+    int bkt_base;         // start of the day's [T*C + 1] slice of bkt_off
+    int tick_base;        // start of the day's [T + 1] slice of tick_off
+    int now0;             // RealExpTime at tick 0 (:1037)
+    int T;                // iterations of `while self.RealExpTime <= EndTime` (:1048) of this day: the city stands still afterwards
+    int q_base;           // first sorted-order position of the day
+    int Oq;               // processed orders of the day
+    int max_tick_orders;
+    int pad;
+};
+struct DayView { const int *bkt_off; const int *tick_off; int now0, T, q_base; };
+
 struct Static {
-    int N, C, V, R, Oq, T;
+    int N, C, V, R, Oq, T;           // Oq: result slots per replica (max over days); T: longest day
+    int n_days;                      // 1: one order stream shared by every replica (the fast path of k_tick_rows)
+    const DayDesc *day;              // [n_days]
+    const int *replica_day;          // [R]
     int tick_minutes, now0;          // RealExpTime at tick 0
     unsigned tick_magic;             // ceil(2^32 / tick_minutes): n / tick == mulhi(n, magic) for 0 <= n < tick_div_limit
     int tick_div_limit;              // (0: always divide)
@@ -99,5 +117,16 @@ struct State {
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
 };
+
+__device__ __forceinline__ DayView day_view(const Static &S, int r) {
+    if (S.n_days <= 1) return DayView{S.bkt_off, S.tick_off, S.now0, S.T, 0};
+    const DayDesc d = S.day[S.replica_day[r]];
+    return DayView{S.bkt_off + d.bkt_base, S.tick_off + d.tick_base, d.now0, d.T, d.q_base};
+}
+// results of replica r, indexed by ABSOLUTE sorted-order position q
+__device__ __forceinline__ int2 *out_row(const Static &S, const State &D, int r) {
+    const int qb = S.n_days <= 1 ? 0 : S.day[S.replica_day[r]].q_base;
+    return D.out + (size_t)r * S.Oq - qb;
+}
 
 }  // namespace vds

@@ -381,8 +381,7 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
             changed = true;
         }
         if (lane < kk) {
-            const size_t o = (size_t)r * S.Oq + q0 + base + lane;
-            D.out[o] = make_int2(res_veh, res_wait);
+            out_row(S, D, r)[q0 + base + lane] = make_int2(res_veh, res_wait);
             if (res_veh >= 0)   // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery)
                 post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
@@ -421,10 +420,14 @@ __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t,
 // Whole generic tick of one bucket by one wavefront.  MAXJ = 4: tables up to 256 idle entries are
 // matched here, bigger ones are pushed to the worklist (match only).  MAXJ = 16: everything here.
 template <bool DO_MATCH, bool LDSBLK, int MAXJ, bool ONLY_J4 = false, typename CT = int>
-__device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t, int q0, int k, const CT *blk, int nc) {
+__device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t, const CT *blk, int nc) {
     const int lane = lane_id();
     const int p = t & 1;
-    const int now = S.now0 + t * S.tick_minutes;
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;                       // this replica's day is over (:1048): its city stands still
+    const int q0 = DO_MATCH ? dv.bkt_off[(size_t)t * S.C + c] : 0;
+    const int k = DO_MATCH ? dv.bkt_off[(size_t)t * S.C + c + 1] - q0 : 0;
+    const int now = dv.now0 + t * S.tick_minutes;
     const size_t b = (size_t)c * S.R + r;
     int *hdr = D.hdr + b * HDR_WORDS;
     int hv = lane < HDR_WORDS ? hdr[lane] : 0;
@@ -452,6 +455,8 @@ __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t
                 int slot = atomicAdd(&D.work[p], 1);
                 D.work[2 + (size_t)p * S.C * S.R + slot] = (int)b;
             }
+        } else if (MAXJ >= 16 && m > WAVE * MAXJ) {
+            match_bucket_slow(S, D, r, t, now, m, q0, k, S.blk + S.blk_off[c], nc, idle, wait_sum, value_sum, evals, rejects);   // beyond the register tables
         } else if (!ONLY_J4 && m <= 64) match_bucket<1, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
         else if (!ONLY_J4 && m <= 128) match_bucket<2, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
         else if (MAXJ < 16 || m <= 256) match_bucket<4, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
@@ -475,18 +480,18 @@ __global__ __launch_bounds__(256) void k_tick(Static S, State D, int t, int lds_
     const int chunk = blockIdx.x / S.C;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int nc = S.cl_off[c + 1] - S.cl_off[c];
-    const int q0 = DO_MATCH ? S.bkt_off[(size_t)t * S.C + c] : 0;
-    const int k = DO_MATCH ? S.bkt_off[(size_t)t * S.C + c + 1] - q0 : 0;
+    const bool multi = S.n_days > 1;             // per-replica order days: every wavefront looks its bucket up itself
+    const int k = (DO_MATCH && !multi && t < S.T) ? S.bkt_off[(size_t)t * S.C + c + 1] - S.bkt_off[(size_t)t * S.C + c] : 0;
     const int *blk_g = S.blk + S.blk_off[c];
-    const bool use_lds = DO_MATCH && k > 0 && nc * nc <= lds_ints;
+    const bool use_lds = DO_MATCH && (multi || k > 0) && nc * nc <= lds_ints;
     if (use_lds)
         for (int i = threadIdx.x; i < nc * nc; i += blockDim.x) lds_dyn[i] = blk_g[i];
     __syncthreads();
     for (int i = 0; i < 4; ++i) {
         const int r = (chunk * 4 + i) * 4 + wave;
         if (r >= S.R) break;
-        if (use_lds) bucket_tick<DO_MATCH, true, 4>(S, D, c, r, t, q0, k, lds_dyn, nc);
-        else bucket_tick<DO_MATCH, false, 4>(S, D, c, r, t, q0, k, blk_g, nc);
+        if (use_lds) bucket_tick<DO_MATCH, true, 4>(S, D, c, r, t, lds_dyn, nc);
+        else bucket_tick<DO_MATCH, false, 4>(S, D, c, r, t, blk_g, nc);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) D.work[(t & 1) ^ 1] = 0;   // next tick's worklist
 }
@@ -497,23 +502,25 @@ __global__ __launch_bounds__(256) void k_tick_work(Static S, State D, int t) {
     const int p = t & 1;
     const int n = D.work[p];
     const int nwaves = gridDim.x * 4;
-    const int now = S.now0 + t * S.tick_minutes;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += nwaves) {
         const unsigned wv = (unsigned)D.work[2 + (size_t)p * S.C * S.R + i];
         const size_t b = (size_t)(wv & ~WORK_FULL);
         const int c = (int)(b / S.R), r = (int)(b % S.R);
         const int nc = S.cl_off[c + 1] - S.cl_off[c];
-        const int q0 = S.bkt_off[(size_t)t * S.C + c];
-        const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
+        const DayView dv = day_view(S, r);
+        const int q0 = dv.bkt_off[(size_t)t * S.C + c];
+        const int k = dv.bkt_off[(size_t)t * S.C + c + 1] - q0;
+        const int now = dv.now0 + t * S.tick_minutes;
         const int *blk = S.blk + S.blk_off[c];
         if (wv & WORK_FULL) {
-            bucket_tick<true, false, 16>(S, D, c, r, t, q0, k, blk, nc);
+            bucket_tick<true, false, 16>(S, D, c, r, t, blk, nc);
         } else {
             int *hdr = D.hdr + b * HDR_WORDS;
             int m = hdr[HDR_IDLE];
             long long wait_sum = 0, value_sum = 0, evals = 0;
             int rejects = 0;
-            match_bucket<16, false>(S, D, r, t, now, m, q0, k, blk, nc, D.idle + b * S.idle_cap, wait_sum, value_sum, evals, rejects);
+            if (m > WAVE * 16) match_bucket_slow(S, D, r, t, now, m, q0, k, blk, nc, D.idle + b * S.idle_cap, wait_sum, value_sum, evals, rejects);
+            else match_bucket<16, false>(S, D, r, t, now, m, q0, k, blk, nc, D.idle + b * S.idle_cap, wait_sum, value_sum, evals, rejects);
             if (lane_id() == 0) hdr[HDR_IDLE] = m;
             add_counters(D.cnt + b * CNT_WORDS, k, rejects, wait_sum, value_sum, evals, 0);
         }
@@ -544,9 +551,12 @@ __device__ __forceinline__ void rows_load_idle(const uint2 *idle, int l16, int m
     }
 }
 
-template <int J, typename CT>
+// PD (per-replica order days, Static.n_days > 1): q0 / k / now / out_r differ per 16-lane row; the rows fetch their own
+// order records from HBM (lane l of a row holds order jj*16 + l) and the pickup of order j reaches the row's lanes
+// through the LDS crossbar (ds_bpermute) instead of a scalar readlane; the loop runs to the longest row of the wavefront.
+template <int J, typename CT, bool PD>
 __device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
-                                           const int4 *lds_rec, const uint2 *arr_row, int r, bool rowvalid, size_t b, int m, int A,
+                                           const int4 *lds_rec, const uint2 *arr_row, int2 *out_r, int r, bool rowvalid, size_t b, int m, int A,
                                            uint2 *idle, long long cntv, unsigned (&veh)[J], int (&loc)[J], bool prof, unsigned long long tprev, int pwave) {
     const int lane = lane_id();
     const int l16 = lane & 15;
@@ -569,16 +579,26 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         dead[s] = pos < mnew ? 0 : IMAX;
     }
     int recy = 0;
-    if (lane < k) recy = lds_rec[lane].y;
+    int recy4[4] = {0, 0, 0, 0};
+    int kmax = k;
+    if (PD) {
+        kmax = max(max(rdlane(k, 0), rdlane(k, 16)), max(rdlane(k, 32), rdlane(k, 48)));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (jj * 16 < kmax && jj * 16 + l16 < k) recy4[jj] = S.so_rec[q0 + jj * 16 + l16].y;
+    } else {
+        if (lane < k) recy = lds_rec[lane].y;
+    }
     PROF_STAMP(3);
     int navail = mnew, evals = 0;
     int res[4] = {IMAX, IMAX, IMAX, IMAX};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        if (jj * 16 >= k || (abl & 4)) break;
-        const int kk = min(16, k - jj * 16);
+        if (jj * 16 >= kmax || (abl & 4)) break;
+        const int kk = min(16, kmax - jj * 16);
         for (int ji = 0; ji < kk; ++ji) {
-            const int p = rdlane(recy, jj * 16 + ji) & 0xFFFF;
+            const int p = (PD ? __builtin_amdgcn_ds_bpermute((rowbase + ji) << 2, recy4[jj]) : rdlane(recy, jj * 16 + ji)) & 0xFFFF;
+            const bool live = !PD || jj * 16 + ji < k;          // this row still has an order at this step
             const CT *row = lds_blk + p * nc;
             int best = IMAX;
 #pragma unroll
@@ -586,13 +606,13 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
                 const int v = (((int)row[loc[s]] << 7) | (l16 * J + s)) | dead[s];
                 best = min(best, v);
             }
-            const int rmin = row_min_i32(best);
+            const int rmin = live ? row_min_i32(best) : IMAX;
             const bool hit = rmin != IMAX;
             const int wpos = rmin & 127;
 #pragma unroll
             for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? IMAX : dead[s];
             res[jj] = (l16 == ji) ? rmin : res[jj];
-            evals += navail;
+            evals += live ? navail : 0;
             navail -= hit ? 1 : 0;
         }
     }
@@ -602,10 +622,10 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     int wsum = 0, vsum = 0, rej = 0;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        if (jj * 16 >= k) break;
+        if (jj * 16 >= kmax) break;
         const int j = jj * 16 + l16;
         const bool has = rowvalid && j < k;
-        const int4 rr = lds_rec[j < k ? j : 0];
+        const int4 rr = PD ? (has ? S.so_rec[q0 + j] : make_int4(0, 0, 0, 0)) : lds_rec[j < k ? j : 0];
         const int rv = res[jj];
         const bool matched = has && rv != IMAX;
         const int wait = rv >> 7;
@@ -617,7 +637,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             const int got = __builtin_amdgcn_ds_bpermute(src, (int)veh[s]);
             vid = (matched && (wpos % J) == s) ? got : vid;
         }
-        if (has && !(abl & 8)) D.out[(size_t)r * S.Oq + q0 + j] = make_int2(vid, matched ? wait : -1);
+        if (has && !(abl & 8)) out_r[q0 + j] = make_int2(vid, matched ? wait : -1);
         if (matched && !(abl & 1)) {
             if (abl & 96) {   // timing-only: bit5 = atomic without the entry store, bit6 = entry store without the atomic
                 const int rel = wait + rr.w;
@@ -668,16 +688,17 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     PROF_STAMP(6);
 }
 
-template <int J, typename CT>
+template <int J, typename CT, bool PD>
 __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
-                                          const int4 *lds_rec, unsigned long long *key_row, int r, bool rowvalid, size_t b, size_t si,
+                                          const int4 *lds_rec, unsigned long long *key_row, int2 *out_r, int r, bool rowvalid, size_t b, size_t si,
                                           int m, int A, long long cntv, bool prof, unsigned long long tprev, int pwave) {
     const int l16 = lane_id() & 15;
     // 3. the idle list and this tick's arrivals: both loads in flight together
     uint2 *idle = D.idle + b * S.idle_cap;
     unsigned veh[J];
     int loc[J];
-    if (k > 0) rows_load_idle<J>(idle, l16, m, veh, loc);      // k is workgroup-uniform
+    if (PD) rows_load_idle<J>(idle, l16, k > 0 ? m : 0, veh, loc);      // an order-less row never writes its old entries back
+    else if (k > 0) rows_load_idle<J>(idle, l16, m, veh, loc); // k is workgroup-uniform
     uint2 *arr_row = reinterpret_cast<uint2 *>(key_row);
     PROF_STAMP(1);
     // 4. arrivals of this tick (UpdateFunction :1014-1024): rank by dict insertion key
@@ -724,7 +745,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         wave_fence();
     }
     PROF_STAMP(2);
-    if (k == 0) {
+    if (PD ? ballot(k > 0) == 0 : k == 0) {
         // no order in this (tick, cluster) bucket: the idle list is not even read - the ranked arrivals are
         // appended behind it in HBM and the header is updated
         if (rowvalid) {
@@ -738,7 +759,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         }
         return;
     }
-    rows_match<J, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
+    rows_match<J, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, out_r, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
 }
 
 #ifndef ROWS_WAVES
@@ -750,7 +771,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #endif
 // U8: every cost fits a byte (Static.u8_ok): the cluster block is staged and read as bytes - a quarter of the L2 -> LDS
 // traffic, one 16-byte load per thread for blocks of up to 64 nodes
-template <bool U8>
+template <bool U8, bool PD>
 __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
@@ -781,6 +802,26 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     const int pwave = (int)((blockIdx.x * ROWS_WAVES + wave) & (PROF_WAVES - 1));
     const int r = (chunk * ROWS_WAVES + wave) * 4 + g;
     bool rowvalid = r < S.R;
+    // the row's order day: shared by all replicas (scalar values) or looked up per row
+    int q0, k, now;
+    int2 *out_r = D.out + (size_t)(rowvalid ? r : 0) * S.Oq;
+    if (PD) {
+        q0 = 0; k = 0; now = 0;
+        if (rowvalid) {
+            const DayDesc dd = S.day[S.replica_day[r]];
+            rowvalid = t < dd.T;                     // the row's day is over: its city stands still
+            if (rowvalid) {
+                const int *bo = S.bkt_off + dd.bkt_base + (size_t)t * S.C + c;
+                q0 = bo[0]; k = bo[1] - q0;
+                now = dd.now0 + t * S.tick_minutes;
+                out_r -= dd.q_base;
+            }
+        }
+    } else {
+        q0 = S.bkt_off[(size_t)t * S.C + c];
+        k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
+        now = S.now0 + t * S.tick_minutes;
+    }
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
     // 1. bucket header words
@@ -794,9 +835,6 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
         if (l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];
     }
     const int nc = cd.x;
-    const int q0 = S.bkt_off[(size_t)t * S.C + c];
-    const int k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
-    const int now = S.now0 + t * S.tick_minutes;
     const bool wg_ok = nc * nc <= lds_elems && k <= 64;
     // rows the register tables cannot hold (or that own far arrivals): handled after the fast rows by this
     // same wavefront with the generic per-bucket code (cost block already in LDS); only when the block does
@@ -815,13 +853,13 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     const bool big96 = ballot(m + A > 96) != 0;
     const bool small32 = ballot(m + A > 32) == 0;
     // 2. stage the cluster's cost block and the bucket's order records in LDS
-    if (blk_in_lds && k > 0) {
+    if (blk_in_lds && (PD || k > 0)) {
         // 16-byte loads, three in flight per thread before the first LDS store (blocks are padded to 4 ints)
         const int4 *blk4 = U8 ? reinterpret_cast<const int4 *>(S.blk8 + cd.w) : reinterpret_cast<const int4 *>(S.blk + cd.y);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
         const int n4 = U8 ? (nc * nc + 15) >> 4 : (nc * nc + 3) >> 2;
         int4 rec = make_int4(0, 0, 0, 0);
-        if ((int)threadIdx.x < min(k, 64)) rec = S.so_rec[q0 + threadIdx.x];
+        if (!PD && (int)threadIdx.x < min(k, 64)) rec = S.so_rec[q0 + threadIdx.x];
         if (U8) {
             for (int i = threadIdx.x; i < n4; i += ROWS_WAVES * WAVE) lds4[i] = blk4[i];
         } else {
@@ -836,7 +874,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
                 if (i + 2 * ROWS_WAVES * WAVE < n4) lds4[i + 2 * ROWS_WAVES * WAVE] = v2;
             }
         }
-        if ((int)threadIdx.x < min(k, 64)) lds_rec[threadIdx.x] = rec;
+        if (!PD && (int)threadIdx.x < min(k, 64)) lds_rec[threadIdx.x] = rec;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) D.work[p ^ 1] = 0;   // next tick's worklist
     __syncthreads();
@@ -844,15 +882,15 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
         // 3.-5. idle list + arrivals + match, specialised on the table depth
         unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
         PROF_STAMP(0);
-        if (big && !big96) rows_body<6, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (big) rows_body<8, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (small32) rows_body<2, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else rows_body<4, CT>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        if (big && !big96) rows_body<6, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (big) rows_body<8, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (small32) rows_body<2, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else rows_body<4, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
     }
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int gg = (__ffsll((long long)rest) - 1) >> 4;
-        bucket_tick<true, true, 4, true, CT>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, q0, k, lds_blk, nc);
+        bucket_tick<true, true, 4, true, CT>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, lds_blk, nc);
     }
 }
 
@@ -877,8 +915,11 @@ __device__ __forceinline__ void list_remove(uint2 *idle, int m, int pos) {
 __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
     const int r = blockIdx.x;
     const int lane = lane_id();
-    const int now = S.now0 + t * S.tick_minutes;
-    const int o0 = S.tick_off[t], o1 = S.tick_off[t + 1];
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;
+    const int now = dv.now0 + t * S.tick_minutes;
+    const int o0 = dv.tick_off[t], o1 = dv.tick_off[t + 1];
+    int2 *out_r = out_row(S, D, r);
     for (int oi = o0; oi < o1; ++oi) {
         const int q = S.ord_q[oi];
         const int4 rec = S.so_rec[q];
@@ -948,7 +989,7 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
             }
         }
         if (lane == 0) {
-            D.out[(size_t)r * S.Oq + q] = make_int2(res_veh, res_wait);
+            out_r[q] = make_int2(res_veh, res_wait);
             cnt[CNT_ORDERS] += 1;
             hdr[HDR_ORDERS] += 1;
             if (!matched) cnt[CNT_REJECTS] += 1;
@@ -1017,7 +1058,7 @@ __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t,
         }
         if (res_veh < 0) rejects++;
         if (lane == 0) {
-            D.out[(size_t)r * S.Oq + qs + j] = make_int2(res_veh, res_wait);
+            out_row(S, D, r)[qs + j] = make_int2(res_veh, res_wait);
             if (res_veh >= 0) post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
         wave_fence();
@@ -1056,8 +1097,11 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
     const int r = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave-uniform: keep it scalar
     const int p = t & 1;
-    const int now = S.now0 + t * S.tick_minutes;
-    const int tq0 = S.bkt_off[(size_t)t * C], tq1 = S.bkt_off[(size_t)(t + 1) * C];
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;                       // whole workgroup: this replica's day is over
+    const int now = dv.now0 + t * S.tick_minutes;
+    const int *bkt_off = dv.bkt_off;
+    const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
 #ifdef VDS_PROF
     const bool prof = (g_ablate & 128) != 0;
     unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1080,7 +1124,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
             wave_fence();
         }
         const int A = drain_ring(S, D, b, t, m, D.idle + b * S.idle_cap);
-        const int q0 = S.bkt_off[(size_t)t * C + c], q1 = S.bkt_off[(size_t)t * C + c + 1];
+        const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
         if (lane == 0) {
             hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
             m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
@@ -1263,7 +1307,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
                 }
             }
             if (lane == 0) {
-                D.out[(size_t)r * S.Oq + q] = make_int2(res_veh, res_wait);
+                out_row(S, D, r)[q] = make_int2(res_veh, res_wait);
                 int *cl = cnt_l + pc * LCNT;
                 cl[CNT_ORDERS] += 1;
                 if (!matched) cl[CNT_REJECTS] += 1;
@@ -1383,8 +1427,11 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
     const int r = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave-uniform: keep it scalar
     const int p = t & 1;
-    const int now = S.now0 + t * S.tick_minutes;
-    const int tq0 = S.bkt_off[(size_t)t * C], tq1 = S.bkt_off[(size_t)(t + 1) * C];
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;                       // whole workgroup: this replica's day is over
+    const int now = dv.now0 + t * S.tick_minutes;
+    const int *bkt_off = dv.bkt_off;
+    const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
 #ifdef VDS_PROF
     const bool prof = (g_ablate & 128) != 0;
     unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1417,7 +1464,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
             wave_fence();
         }
         const int A = drain_ring(S, D, b, t, m, D.idle + b * S.idle_cap);
-        const int q0 = S.bkt_off[(size_t)t * C + c], q1 = S.bkt_off[(size_t)t * C + c + 1];
+        const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
         if (lane == 0) {
             hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
             m_l[c] = m; qcur_l[c] = q0; qend_l[c] = q1;
@@ -1437,7 +1484,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                 m = hdr[HDR_IDLE];
                 far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
                 A = D.ring_cnt[si] & 0xFFFF;
-                q0 = S.bkt_off[(size_t)t * C + c]; q1 = S.bkt_off[(size_t)t * C + c + 1];
+                q0 = bkt_off[(size_t)t * C + c]; q1 = bkt_off[(size_t)t * C + c + 1];
             }
             const bool slow = valid && (far != 0 || A > 16 || A > S.ring_cap);
             const bool fast = valid && !slow;
@@ -1509,7 +1556,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
     }
     __syncthreads();
     PROF_STAMP(1);
-    int2 *out_r = D.out + (size_t)r * S.Oq;
+    int2 *out_r = D.out + (size_t)r * S.Oq - dv.q_base;
 
     // own-cluster match of bucket c by ONE thread (rare path: order LB found its cluster not dry after all)
     auto own_match_thread = [&](int c, int limit) {
@@ -1904,24 +1951,26 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
 // k_dispatch: one wavefront per (replica, from_cluster) group of actions (host-sorted).
 // grp_off[g]..grp_off[g+1] index the group's actions; positions refer to the idle list as it
 // stands at call time.
+// a_arrive (nullable): the arrival minute the hook body wrote into VehiclesArrivetime itself (default RealExpTime + road
+// cost); a_counted (nullable): 0 = DispatchNum / TotallyDispatchCost are kept by the hook body, not by the engine.
 __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int ngroups, const int *grp_off,
                                                  const int *a_replica, const int *a_cluster, const int *a_pos,
-                                                 const int *a_target, const int *a_seq) {
+                                                 const int *a_target, const int *a_seq, const int *a_arrive, const int *a_counted) {
     const int g = blockIdx.x;
     if (g >= ngroups) return;
     const int lane = lane_id();
     const int a0 = grp_off[g], a1 = grp_off[g + 1];
     const int r = a_replica[a0], c = a_cluster[a0];
-    const int now = S.now0 + t * S.tick_minutes;
+    const int now = day_view(S, r).now0 + t * S.tick_minutes;
     const size_t b = (size_t)c * S.R + r;
     int *hdr = D.hdr + b * HDR_WORDS;
     uint2 *idle = D.idle + b * S.idle_cap;
     const int m = hdr[HDR_IDLE];
     long long cost_sum = 0;
-    int ndone = 0;
+    int ndone = 0, ncount = 0;
     for (int base = a0; base < a1; base += WAVE) {
         int a = base + lane;
-        bool ok = false;
+        bool ok = false, counted = false;
         int cst = 0;
         if (a < a1) {
             int pos = a_pos[a], tgt = a_target[a];
@@ -1929,15 +1978,18 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
                 uint2 e = idle[pos];
                 int tc = S.node2cluster[tgt];
                 cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
-                post_arrival(S, D, tc, r, t, now, (int)e.x, a_seq[a], now + cst, 1, S.node_local[tgt]);
+                post_arrival(S, D, tc, r, t, now, (int)e.x, a_seq[a], a_arrive ? a_arrive[a] : now + cst, 1, S.node_local[tgt]);
                 ok = true;
+                counted = !(a_counted && !a_counted[a]);
             } else {
                 atomicOr(&D.err[0], ERR_DISPATCH);
             }
         }
+        if (!counted) cst = 0;
         for (int o = 32; o > 0; o >>= 1) cst += __shfl_xor(cst, o, WAVE);
         cost_sum += cst;
         ndone += popc64(ballot(ok));
+        ncount += popc64(ballot(counted));
     }
     wave_fence();
     int newm = 0;
@@ -1957,7 +2009,7 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
     if (lane == 0) {
         hdr[HDR_IDLE] = newm;
         long long *cnt = D.cnt + b * CNT_WORDS;
-        cnt[CNT_DISPATCH] += ndone;
+        cnt[CNT_DISPATCH] += ncount;
         cnt[CNT_DISPATCH_COST] += cost_sum;
     }
 }
@@ -2043,7 +2095,7 @@ __global__ void k_total_counters(int R, const long long *per, long long *tot) {
 __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t, int K, const int *actions, int seq_base) {
     const int r = blockIdx.x;
     const int lane = lane_id();
-    const int now = S.now0 + t * S.tick_minutes;
+    const int now = day_view(S, r).now0 + t * S.tick_minutes;
     const int *act = actions + (size_t)r * K * 3;
     for (int k0 = 0; k0 < K; k0 += WAVE) {
         // one pass = up to 64 consecutive actions; passes see the lists left by the earlier ones, so an action's
@@ -2070,7 +2122,17 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
             int *hdr = D.hdr + b * HDR_WORDS;
             uint2 *idle = D.idle + b * S.idle_cap;
             const int m = hdr[HDR_IDLE];
-            const bool mine = (grp >> lane) & 1ull;
+            bool mine = (grp >> lane) & 1ull;
+            {   // a position named twice: the first action (lowest slot) stands, the others are refused - nothing of
+                // theirs is posted, so the vehicle cannot end up in two arrival tables
+                bool dup = false;
+                for (unsigned long long rest = grp; rest; rest &= rest - 1) {
+                    const int l2 = __ffsll((long long)rest) - 1;
+                    const int p2 = rdlane(pos, l2);
+                    dup = dup || (mine && l2 < lane && p2 == pos);
+                }
+                if (dup) { atomicOr(&D.err[0], ERR_DISPATCH); mine = false; }
+            }
             bool ok = false;
             int cst = 0;
             if (mine) {
@@ -2128,10 +2190,15 @@ static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int chunks = (S.R + 15) / 16;
     const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+    const bool pd = S.n_days > 1;
     if (S.fast_ok && S.u8_ok) {
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);      // byte blocks: a quarter of the LDS
-        hipLaunchKernelGGL(k_tick_rows<true>, dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(li), st, S, D, t, li);
-    } else if (S.fast_ok) hipLaunchKernelGGL(k_tick_rows<false>, dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        if (pd) hipLaunchKernelGGL((k_tick_rows<true, true>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(li), st, S, D, t, li);
+        else hipLaunchKernelGGL((k_tick_rows<true, false>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(li), st, S, D, t, li);
+    } else if (S.fast_ok) {
+        if (pd) hipLaunchKernelGGL((k_tick_rows<false, true>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        else hipLaunchKernelGGL((k_tick_rows<false, false>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+    }
     else hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * 4, st, S, D, t, lds_ints);
 }
 
@@ -2162,8 +2229,9 @@ void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
 }
 
 void launch_dispatch(const Static &S, const State &D, int t, int ngroups, const int *grp_off, const int *a_replica,
-                     const int *a_cluster, const int *a_pos, const int *a_target, const int *a_seq, hipStream_t st) {
-    hipLaunchKernelGGL(k_dispatch, dim3(ngroups), dim3(64), 0, st, S, D, t, ngroups, grp_off, a_replica, a_cluster, a_pos, a_target, a_seq);
+                     const int *a_cluster, const int *a_pos, const int *a_target, const int *a_seq, const int *a_arrive,
+                     const int *a_counted, hipStream_t st) {
+    hipLaunchKernelGGL(k_dispatch, dim3(ngroups), dim3(64), 0, st, S, D, t, ngroups, grp_off, a_replica, a_cluster, a_pos, a_target, a_seq, a_arrive, a_counted);
 }
 
 void launch_dispatch_dense(const Static &S, const State &D, int t, int K, const int *actions, int seq_base, hipStream_t st) {

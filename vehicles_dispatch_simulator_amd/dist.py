@@ -12,6 +12,7 @@ from typing import Tuple
 
 import numpy as np
 
+ALLREDUCE_CALLS = 0      # collectives issued by this process (reported by bench.py)
 RAW_COUNTER_NAMES = ("orders", "rejects", "wait_sum", "matched_value", "evals", "arrivals", "dispatches", "dispatch_cost")
 
 
@@ -26,10 +27,13 @@ def shard(total_replicas: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 def allreduce_counters(tensor, group=None):
-    """In-place sum of an int64[8] counter tensor over all ranks (no-op without a process group)."""
+    """In-place sum of an int64[8] counter tensor over all ranks (no-op without a process group; with a group the
+    collective is issued even for a world of one, so a single-rank launch exercises the same RCCL path)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+        global ALLREDUCE_CALLS
+        ALLREDUCE_CALLS += 1
     return tensor
 
 
@@ -37,7 +41,7 @@ def max_over_ranks(value: float, device=None) -> float:
     """The slowest rank's time: what the job's throughput is quoted on."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

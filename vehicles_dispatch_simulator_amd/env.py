@@ -97,6 +97,48 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_num_ticks(self._h, C.byref(t)))
         self.T = t.value
 
+    def load_order_days(self, days, replica_day=None):
+        """Per-replica order days (``vds_load_order_days``): ``days`` is a sequence of ``(release_min, pickup,
+        delivery)`` triples, replica ``r`` replays ``days[replica_day[r]]`` (default ``r % len(days)``) - one
+        ``Simulation`` = one city = its own ``Orders`` in the reference (``simulator.py:325-342``).  ``T`` is the
+        longest day; a replica whose day is over stands still."""
+        rel = np.concatenate([_i32(d[0]).reshape(-1) for d in days])
+        pk = np.concatenate([_i32(d[1]).reshape(-1) for d in days])
+        dl = np.concatenate([_i32(d[2]).reshape(-1) for d in days])
+        off = np.zeros(len(days) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([np.asarray(d[0]).size for d in days])
+        rd = None if replica_day is None else _i32(replica_day)
+        if rd is not None and rd.size != self.R:
+            raise Exception("load_order_days: replica_day needs %d entries" % self.R)
+        self._chk(self._lib.vds_load_order_days(self._h, len(days), _p(off), _p(rel), _p(pk), _p(dl), _p(rd)))
+        self._after_load(int(np.diff(off).max()))
+
+    def load_orders_strided(self, release_min, pickup, delivery, O: int, replica_stride: int):
+        """SURVEY 8(b) form: replica ``r``'s day starts at element ``r * replica_stride`` (0 = one shared day)."""
+        r, p, d = _i32(release_min).reshape(-1), _i32(pickup).reshape(-1), _i32(delivery).reshape(-1)
+        self._chk(self._lib.vds_load_orders_strided(self._h, _p(r), _p(p), _p(d), int(O), int(replica_stride)))
+        self._after_load(int(O))
+
+    def _after_load(self, omax: int):
+        self.O = omax
+        t = C.c_int32()
+        self._chk(self._lib.vds_num_ticks(self._h, C.byref(t)))
+        self.T = t.value
+
+    def replica_ticks(self, replica: int):
+        """(ticks, orders) of the day ``replica`` replays."""
+        t, n = C.c_int32(), C.c_int32()
+        self._chk(self._lib.vds_replica_ticks(self._h, int(replica), C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    def set_idle_cap(self, cap: int):
+        """Regrow the idle tables (after an "idle table overflow"); ``reset`` / ``reset_again`` must follow."""
+        self._chk(self._lib.vds_set_idle_cap(self._h, int(cap)))
+
+    @property
+    def idle_cap(self) -> int:
+        return int(self._lib.vds_idle_cap(self._h))
+
     def reset(self, veh_init_node):
         v = _i32(veh_init_node).reshape(-1)
         if v.size != self.R * self.V:
@@ -111,9 +153,16 @@ class BatchedDispatchEnv:
         """Update -> Match -> SupplyExpect of the current tick for every replica (asynchronous)."""
         self._chk(self._lib.vds_step(self._h))
 
-    def apply_dispatch(self, replica, from_cluster, idle_pos, target_node):
+    def apply_dispatch(self, replica, from_cluster, idle_pos, target_node, arrive_min=None, counted=None):
+        """Body of a ``DispatchFunction``.  ``arrive_min`` / ``counted`` (``vds_apply_dispatch_ex``): the arrival minute
+        the body stored itself, and 0 where the body keeps ``DispatchNum`` / ``TotallyDispatchCost`` on its own."""
         a = [_i32(x).reshape(-1) for x in (replica, from_cluster, idle_pos, target_node)]
-        self._chk(self._lib.vds_apply_dispatch(self._h, a[0].size, *[_p(x) for x in a]))
+        if arrive_min is None and counted is None:
+            self._chk(self._lib.vds_apply_dispatch(self._h, a[0].size, *[_p(x) for x in a]))
+            return
+        am = None if arrive_min is None else _i32(arrive_min).reshape(-1)
+        ct = None if counted is None else _i32(counted).reshape(-1)
+        self._chk(self._lib.vds_apply_dispatch_ex(self._h, a[0].size, *[_p(x) for x in a], _p(am), _p(ct)))
 
     def apply_dispatch_torch(self, actions):
         """Device-resident dispatch: ``actions`` is a contiguous int32 CUDA tensor ``[R, K, 3]`` of

@@ -10,9 +10,13 @@ module handed to ``LoadDispatchComponent`` (:260) - drops in.  The per-tick work
 reference exposes (``Clusters`` / ``Vehicles`` / ``Orders``) is served as lazy views of replica
 ``Replica`` (``objects.py``).
 
-Differences a maintainer should know (also in INTEGRATION.md):
-  * idle vehicles are moved with ``DispatchVehicle(vehicle, target_node)`` inside
-    ``DispatchFunction`` instead of editing ``Cluster.IdleVehicles`` in place;
+What a maintainer should know (also in INTEGRATION.md):
+  * a ``DispatchFunction`` body may move idle vehicles in the reference's own idiom - ``IdleVehicles.remove(veh)``,
+    ``VehiclesArrivetime[veh] = time``, ``veh.DeliveryPoint = node``, ``self.DispatchNum += 1`` - the edits are diffed
+    and applied to the device when the hook returns (``_flush_dispatch``); ``DispatchVehicle(vehicle, target_node)``
+    is the one-call form of the same thing;
+  * ``UpdateFunction`` / ``MatchFunction`` / ``SupplyExpectFunction`` are ONE fused device launch: overriding them is
+    refused with a clear error instead of being silently ignored;
   * extra optional keywords: ``Replicas``, ``Replica``, ``Device``, ``VehicleSeed``, ``DataDir``.
 """
 from __future__ import annotations
@@ -30,6 +34,7 @@ from .env import BatchedDispatchEnv, neighbors_to_csr
 from .objects import Cluster, Grid, Order, Transition, Vehicle  # noqa: F401
 
 _HOOKS = ("DemandPredictFunction", "DispatchFunction", "RewardFunction", "GetNextStateFunction", "LearningFunction")
+_FUSED = ("UpdateFunction", "MatchFunction", "SupplyExpectFunction", "FindServerVehicleFunction")
 
 
 class _RoadCostMap(object):
@@ -101,6 +106,11 @@ class Simulation(object):
         self._version = 0
         self._cache = {}
         self._pending = []
+        self._stepped_current = False
+        self._order_override = {}            # (order id, field) -> value assigned by user code (objects.Order setters)
+        self._idle_objs = {}                 # cluster -> [list object, version it was filled at, vehicle ids at fill time]
+        self._arr_objs = {}                  # cluster -> [dict object, version, {vehicle id: minute} at fill time]
+        self._dev_dispatch_seen = [0, 0]     # device DispatchNum / TotallyDispatchCost already folded into the fields
         self.CalculateTheScaleOfDivision()
 
     # ---------------------------------------------------------------- context features (simulator.py:697-706, 833-866)
@@ -256,6 +266,10 @@ class Simulation(object):
             init[r] = synth.init_vehicle_nodes(rng, N, V, None if valid.all() else valid)
         self._init_nodes = init
         self.env.reset(init)
+        self._dev_dispatch_seen = [0, 0]
+        self._order_override.clear()
+        self._pending = []
+        self._stepped_current = False
         self._mirror_state = dict(loc=init[self.Replica].astype(np.int64), cluster=W.node2cluster[init[self.Replica]].astype(np.int64),
                                   dest=np.full(V, -1, dtype=np.int64), order=np.full(V, -1, dtype=np.int64),
                                   arr=np.full(V, -1, dtype=np.int64))
@@ -275,6 +289,7 @@ class Simulation(object):
         for c in self.Clusters:
             c.RebalanceNumber = 0
             c.PerRebalanceIdleVehicles = 0
+            c._per_match_override = None
         self.InitVehiclesIntoCluster()
 
     def LoadDispatchComponent(self, DispatchModule):
@@ -298,6 +313,42 @@ class Simulation(object):
 
     def _obs(self):
         return self._cached("obs", lambda: {k: v[self.Replica] for k, v in self.env.obs().items()})
+
+    def _idle_container(self, c):
+        """The permanent ``list`` behind ``Cluster.IdleVehicles`` (filled / refreshed in place from the device)."""
+        ent = self._idle_objs.get(c)
+        if ent is None:
+            ent = self._idle_objs[c] = [[], -1, []]
+        if ent[1] != self._version:
+            L = self._lists()
+            ids = [int(v) for v in L["idle_veh"][L["idle_off"][c]:L["idle_off"][c + 1]]]
+            V = self.Vehicles
+            ent[0][:] = [V[v] for v in ids]
+            ent[1], ent[2] = self._version, ids
+        return ent[0]
+
+    def _arrival_container(self, c):
+        """The permanent ``dict`` behind ``Cluster.VehiclesArrivetime``."""
+        ent = self._arr_objs.get(c)
+        if ent is None:
+            ent = self._arr_objs[c] = [{}, -1, {}]
+        if ent[1] != self._version:
+            L = self._lists()
+            a, b = L["arr_off"][c], L["arr_off"][c + 1]
+            snap = {int(v): int(m) for v, m in zip(L["arr_veh"][a:b], L["arr_min"][a:b])}
+            V = self.Vehicles
+            ent[0].clear()
+            ent[0].update((V[v], self._minute_to_time(m)) for v, m in snap.items())
+            ent[1], ent[2] = self._version, snap
+        return ent[0]
+
+    def _refresh_containers(self):
+        """Bring every container object user code may still hold up to date with the device (the reference's
+        containers are permanent objects, so a reference taken in an earlier slot must stay valid)."""
+        for c in list(self._idle_objs):
+            self._idle_container(c)
+        for c in list(self._arr_objs):
+            self._arrival_container(c)
 
     def _orders_snapshot(self):
         return self._cached("orders", lambda: {k: v[0] for k, v in self.env.orders(self.Replica, 1).items()})
@@ -341,7 +392,9 @@ class Simulation(object):
         na = L["arr_off"][-1]
         av = L["arr_veh"][:na].astype(np.int64)
         dest[av] = L["arr_node"][:na]; order[av] = L["arr_order"][:na]; arr[av] = L["arr_min"][:na]
-        restarted = av[(P["dest"][av] >= 0) & ((P["order"][av] != order[av]) | (P["arr"][av] != arr[av]) | (P["dest"][av] != dest[av]))]
+        # was already on the way (its arrival minute was known; "dest" alone may have been written by a hook body that
+        # is about to dispatch the vehicle) and is on another trip now: it arrived and left again in between
+        restarted = av[(P["arr"][av] >= 0) & ((P["order"][av] != order[av]) | (P["arr"][av] != arr[av]) | (P["dest"][av] != dest[av]))]
         loc[restarted] = P["dest"][restarted]
         cl[restarted] = W.node2cluster[P["dest"][restarted]]
         self._mirror_state = dict(loc=loc, cluster=cl, dest=dest, order=order, arr=arr)
@@ -349,7 +402,11 @@ class Simulation(object):
     def _pull_counters(self):
         c = self.env.counters()[self.Replica]
         self.OrderNum, self.RejectNum, self.TotallyWaitTime = int(c[0]), int(c[1]), int(c[3])
-        self.DispatchNum, self.TotallyDispatchCost = int(c[4]), int(c[5])
+        # DispatchNum / TotallyDispatchCost are plain fields a hook body may increment itself (reference idiom,
+        # simulator.py:50-51); the device counts only what went through DispatchVehicle: add its increments
+        self.DispatchNum += int(c[4]) - self._dev_dispatch_seen[0]
+        self.TotallyDispatchCost += int(c[5]) - self._dev_dispatch_seen[1]
+        self._dev_dispatch_seen = [int(c[4]), int(c[5])]
         self._sum_order_value = int(c[6])
 
     # ---------------------------------------------------------------- the main modules (hooks are overridable)
@@ -379,6 +436,7 @@ class Simulation(object):
         """``:900-975`` - already executed by the fused launch; publishes its counters and cursor."""
         self._pull_counters()
         self._advance_mirror()
+        self._refresh_containers()
         nxt = min(int(np.searchsorted(self._o_tick, self.env.clock[0], side="right")), len(self.Orders) - 1)
         self.NowOrder = self.Orders[nxt]
 
@@ -392,27 +450,133 @@ class Simulation(object):
         v = vehicle._index if isinstance(vehicle, Vehicle) else int(vehicle)
         self._pending.append((v, int(target_node)))
 
+    def _container_edits(self):
+        """Edits a hook body made to ``Cluster.IdleVehicles`` / ``Cluster.VehiclesArrivetime`` in the reference's idiom,
+        as dispatch actions ``(vehicle, target node, arrival minute)`` in dict-insertion order.  Only what the device can
+        express is accepted: an idle vehicle removed from its list AND entered into the arrival dict of the cluster that
+        holds its new ``DeliveryPoint``.  Anything else raises, naming the edit."""
+        removed = {}                       # vehicle -> cluster it left
+        for c, (lst, ver, ids) in self._idle_objs.items():
+            if ver != self._version:
+                continue                   # not looked at since the last device step: cannot have been edited
+            now = [v._index for v in lst]
+            if now == ids:
+                continue
+            it = iter(ids)
+            if not all(any(x == y for y in it) for x in now):
+                raise Exception("Cluster %d: IdleVehicles was reordered or extended inside a hook; only removals (dispatch) "
+                                "can be applied to the device" % c)
+            keep = set(now)
+            for v in ids:
+                if v not in keep:
+                    removed[v] = c
+        acts = []
+        for c, (dct, ver, snap) in self._arr_objs.items():
+            if ver != self._version:
+                continue
+            cur = {veh._index: t for veh, t in dct.items()}
+            for v in snap:
+                if v not in cur:
+                    raise Exception("Cluster %d: vehicle %d was deleted from VehiclesArrivetime inside a hook; early arrivals "
+                                    "cannot be applied to the device" % (c, v))
+            for v, t in cur.items():
+                if v in snap:
+                    if int((pd.Timestamp(t) - self._t0) / pd.Timedelta(minutes=1)) != snap[v]:
+                        raise Exception("Cluster %d: the arrival time of vehicle %d was changed inside a hook; not supported" % (c, v))
+                    continue
+                if v not in removed:
+                    raise Exception("Cluster %d: vehicle %d was entered into VehiclesArrivetime but is still in an idle list" % (c, v))
+                dest = int(self._mirror_state["dest"][v])
+                if dest < 0 or int(self._world.node2cluster[dest]) != c:
+                    raise Exception("vehicle %d: VehiclesArrivetime of cluster %d was written but Vehicle.DeliveryPoint (%s) is "
+                                    "not a node of that cluster" % (v, c, None if dest < 0 else dest))
+                delta = pd.Timestamp(t) - self._t0
+                minute = delta // pd.Timedelta(minutes=1)
+                if delta != minute * pd.Timedelta(minutes=1):
+                    raise Exception("vehicle %d: arrival time %s is not on a whole minute" % (v, t))
+                acts.append((v, dest, int(minute)))
+                del removed[v]
+        if removed:
+            v, c = next(iter(removed.items()))
+            raise Exception("vehicle %d was removed from IdleVehicles of cluster %d inside a hook but entered into no "
+                            "VehiclesArrivetime" % (v, c))
+        return acts
+
     def _flush_dispatch(self):
-        if not self._pending:
+        """Apply what the hook body did - ``DispatchVehicle`` calls and container edits - to the device."""
+        edits = self._container_edits()
+        if not self._pending and not edits:
             return
         L = self._lists()
         pos_of = {}
         for c in range(len(self.Clusters)):
             for p, v in enumerate(L["idle_veh"][L["idle_off"][c]:L["idle_off"][c + 1]]):
                 pos_of[int(v)] = (c, p)
-        cl, ps, tg = [], [], []
+        cl, ps, tg, am, ct, seen = [], [], [], [], [], set()
         for v, t in self._pending:
             if v not in pos_of:
                 raise Exception("DispatchVehicle: vehicle %d is not idle" % v)
-            cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t)
+            if v in seen:
+                raise Exception("DispatchVehicle: vehicle %d was dispatched twice in one hook" % v)
+            seen.add(v)
+            cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t); am.append(-1); ct.append(1)
+        for v, t, minute in edits:
+            if v in seen:
+                raise Exception("vehicle %d was dispatched twice in one hook" % v)
+            seen.add(v)
+            cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t); am.append(minute); ct.append(0)
         self._pending = []
-        self.env.apply_dispatch([self.Replica] * len(cl), cl, ps, tg)
+        if edits:
+            # DispatchVehicle entries carry -1: the device computes RealExpTime + RoadCost for them
+            now = self.env.clock[1]
+            W = self._world
+            am = [m if m >= 0 else now + int(W.cost[t, int(L["idle_node"][L["idle_off"][c] + p])]) for m, t, c, p in zip(am, tg, cl, ps)]
+            self.env.apply_dispatch([self.Replica] * len(cl), cl, ps, tg, arrive_min=am, counted=ct)
+        else:
+            self.env.apply_dispatch([self.Replica] * len(cl), cl, ps, tg)
         self._touch()
         self._pull_counters()
         self._advance_mirror()
+        self._refresh_containers()
 
     def _hooks_overridden(self):
+        fused = [h for h in _FUSED if getattr(type(self), h, None) is not getattr(Simulation, h, None)]
+        if fused:
+            raise Exception("%s overridden: Update, Match (incl. FindServerVehicle) and SupplyExpect run as ONE fused device "
+                            "launch for all replicas and cannot be replaced from Python - put the custom logic into "
+                            "DispatchFunction / RewardFunction / GetNextStateFunction / LearningFunction / "
+                            "DemandPredictFunction, or use the reference for this experiment" % ", ".join(fused))
         return self.DispatchModule is not None or any(getattr(type(self), h) is not getattr(Simulation, h) for h in _HOOKS)
+
+    def FindServerVehicleFunction(self, *a, **k):
+        raise Exception("FindServerVehicleFunction (simulator.py:978-996) runs inside the fused device launch")
+
+    def _rebuild_mirror_after_run(self):
+        """Vehicle views after a fast-forwarded day.  Idle vehicles: from the idle lists.  Vehicles on the way keep
+        ``LocationNode`` / ``Cluster`` at the trip ORIGIN until they arrive (``objects.py:84-89``): the origin is where
+        the vehicle stood when it was matched, i.e. the delivery node of the order it served before (or its start
+        node) - recovered from the per-order results, since no hook (hence no dispatch) ran."""
+        L, W = self._lists(), self._world
+        V = len(self.Vehicles)
+        loc = self._init_nodes[self.Replica].astype(np.int64).copy()
+        res = self._orders_snapshot()
+        served = np.flatnonzero(res["status"] == 1)
+        veh = res["vehicle"][served].astype(np.int64)
+        order = np.lexsort((served, veh))                 # by vehicle, then order id (= time)
+        sv, so = veh[order], served[order]
+        first = np.ones(sv.size, dtype=bool); first[1:] = sv[1:] != sv[:-1]
+        prev_dest = np.where(first, self._init_nodes[self.Replica][sv], np.concatenate([[0], W.o_delivery[so[:-1]]])).astype(np.int64)
+        origin_of_order = np.full(len(self.Orders), -1, dtype=np.int64)
+        origin_of_order[so] = prev_dest
+        dest = np.full(V, -1, dtype=np.int64); ordr = np.full(V, -1, dtype=np.int64); arr = np.full(V, -1, dtype=np.int64)
+        n = L["idle_off"][-1]
+        iv = L["idle_veh"][:n].astype(np.int64)
+        loc[iv] = L["idle_node"][:n]
+        na = L["arr_off"][-1]
+        av = L["arr_veh"][:na].astype(np.int64)
+        dest[av] = L["arr_node"][:na]; ordr[av] = L["arr_order"][:na]; arr[av] = L["arr_min"][:na]
+        loc[av] = origin_of_order[ordr[av]]
+        self._mirror_state = dict(loc=loc, cluster=W.node2cluster[loc].astype(np.int64), dest=dest, order=ordr, arr=arr)
 
     def SimCity(self, FastForward=None):
         """``:1036-1130``.  With no hook overridden (``FastForward``), the whole day is issued to
@@ -430,10 +594,23 @@ class Simulation(object):
         if fast:
             t0 = dt.datetime.now()
             T = self.env.T
-            self.env.run(T)
-            self.env.sync()
+            while True:
+                try:
+                    self.env.run(T)
+                    self.env.sync()
+                    break
+                except Exception as e:
+                    # vehicles concentrated beyond the automatic idle-table headroom: the day is deterministic (same
+                    # start nodes, same orders), so it is simply replayed with bigger tables
+                    cap = self.env.idle_cap
+                    if "idle table overflow" not in str(e) or cap >= len(self.Vehicles):
+                        raise
+                    self.env.set_idle_cap(min(2 * cap, len(self.Vehicles) + 63))
+                    self.env.reset_again()
             self._touch()
             self._pull_counters()
+            self._rebuild_mirror_after_run()
+            self._refresh_containers()
             self._stepped_current = False
             self.step = T
             self.RealExpTime = self.RealExpTime + T * pd.Timedelta(minutes=tm)

@@ -195,40 +195,79 @@ def grid_neighbors(gw: int, gh: int) -> List[List[int]]:
     return out
 
 
-def cluster_neighbors_from_cost(cost: np.ndarray, node2cluster: np.ndarray, C: int,
-                                threshold: float = 15.0, first: int = 4) -> List[List[int]]:
-    """Neighbour lists of ``CreateCluster`` (``simulator.py:594-646``).
-
-    For every ordered pair (i, j != i): mean over k in i, l in j of
-    ``RoadCost(k, l) == cost[l, k]``; 99999 when either cluster is empty; rows
-    sorted ascending by that float with Python's stable sort (ties keep cluster
-    id order); neighbours = first ``first`` entries plus every later entry with
-    mean < ``threshold``.
-    """
-    members = [np.flatnonzero(node2cluster == c) for c in range(C)]
-    onehot = np.zeros((cost.shape[0], C), dtype=np.float64)
-    valid = node2cluster >= 0
-    onehot[np.flatnonzero(valid), node2cluster[valid]] = 1
-    # S[i, j] = sum_{k in i, l in j} cost[l, k]; float64 BLAS is exact here (sums << 2**53)
-    S = np.rint(onehot.T @ (cost.T.astype(np.float64) @ onehot)).astype(np.int64)
-    out: List[List[int]] = []
+def neighbor_table_from_sums(sums: np.ndarray, sizes: np.ndarray):
+    """Rows of the reference's ``...Neighbor.csv`` (``simulator.py:596-621``) from the integer pair sums: for cluster
+    ``i`` the list of ``(j, mean cost)`` over ``j != i``, ``99999`` when either cluster is empty (:608-609), sorted
+    ascending by the mean with Python's stable sort (:614; ties keep cluster-id order).  Same float64 arithmetic as
+    the reference: an exact Python ``int / int``."""
+    C = sizes.size
+    table = []
     for i in range(C):
         row = []
         for j in range(C):
             if i == j:
                 continue
-            denom = len(members[i]) * len(members[j])
-            dist = 99999 if denom == 0 else int(S[i, j]) / denom
-            row.append((j, dist))
+            denom = int(sizes[i]) * int(sizes[j])
+            row.append((j, 99999 if denom == 0 else int(sums[i, j]) / denom))
         row.sort(key=lambda t: t[1])
+        table.append(row)
+    return table
+
+
+def neighbors_from_table(table, threshold: float = 15.0, first: int = 4) -> List[List[int]]:
+    """``simulator.py:637-646``: the first ``first`` cells of a row plus every later cell below ``threshold``."""
+    out = []
+    for row in table:
         nb = []
         for j, dist in row:
-            if len(nb) < first:
-                nb.append(j)
-            elif dist < threshold:
-                nb.append(j)
+            if len(nb) < first or dist < threshold:
+                nb.append(int(j))
         out.append(nb)
     return out
+
+
+def cluster_cost_sums_gpu(cost: np.ndarray, node2cluster: np.ndarray, C: int, device: int = 0):
+    """``vds_cluster_cost_sums``: the O(C^2 n^2) loop of ``simulator.py:600-607`` as one HIP segmented reduction over
+    the cost matrix.  Returns ``(sums [C, C] int64, sizes [C] int32)``.  No CPU fallback."""
+    import ctypes as ct
+    from . import _lib
+    lib = _lib.load()
+    cost = np.ascontiguousarray(cost, dtype=np.int32)
+    n2c = np.ascontiguousarray(node2cluster, dtype=np.int32)
+    sums = np.zeros((C, C), dtype=np.int64)
+    sizes = np.zeros(C, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(ct.c_void_p)
+    rc = lib.vds_cluster_cost_sums(int(device), p(cost), cost.shape[0], p(n2c), int(C), p(sums), p(sizes))
+    if rc:
+        raise Exception("vds_cluster_cost_sums failed (%d): %s" % (rc, lib.vds_cluster_cost_sums_error().decode()))
+    return sums, sizes
+
+
+def cluster_neighbors_gpu(cost: np.ndarray, node2cluster: np.ndarray, C: int, device: int = 0,
+                          threshold: float = 15.0, first: int = 4) -> List[List[int]]:
+    """Neighbour lists of ``CreateCluster`` (``simulator.py:594-646``) with the pair sums computed on the GPU."""
+    sums, sizes = cluster_cost_sums_gpu(cost, node2cluster, C, device)
+    return neighbors_from_table(neighbor_table_from_sums(sums, sizes), threshold, first)
+
+
+def cluster_cost_sums_host(cost: np.ndarray, node2cluster: np.ndarray, C: int):
+    """The pair sums of ``simulator.py:600-607`` with numpy on the host: used by the synthetic-city generator (which
+    also runs where there is no GPU) and by the tests as the check of ``cluster_cost_sums_gpu``.  float64 BLAS is exact
+    here (sums << 2**53)."""
+    onehot = np.zeros((cost.shape[0], C), dtype=np.float64)
+    valid = node2cluster >= 0
+    onehot[np.flatnonzero(valid), node2cluster[valid]] = 1
+    # S[i, j] = sum_{k in i, l in j} cost[l, k]
+    sums = np.rint(onehot.T @ (cost.T.astype(np.float64) @ onehot)).astype(np.int64)
+    sizes = np.bincount(node2cluster[valid], minlength=C).astype(np.int32)
+    return sums, sizes
+
+
+def cluster_neighbors_from_cost(cost: np.ndarray, node2cluster: np.ndarray, C: int,
+                                threshold: float = 15.0, first: int = 4) -> List[List[int]]:
+    """Neighbour lists of ``CreateCluster`` (``simulator.py:594-646``) for the synthetic-city generator (host numpy;
+    ``world.load_world`` uses the GPU kernel)."""
+    return neighbors_from_table(neighbor_table_from_sums(*cluster_cost_sums_host(cost, node2cluster, C)), threshold, first)
 
 
 def lattice_cost(seed: int, ix: np.ndarray, iy: np.ndarray, minutes_per_m_inv: int = 280) -> np.ndarray:

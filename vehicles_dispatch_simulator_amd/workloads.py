@@ -31,12 +31,13 @@ class Workload:
         return native_vehicle_nodes(self.veh_seed + first_replica, self.city.N, self.vehicles, replicas,
                                     None if valid.all() else valid)
 
-    def make_env(self, replicas: int, device: int = 0, stream: Optional[int] = None, **kw):
+    def make_env(self, replicas: int, device: int = 0, stream: Optional[int] = None, load: bool = True, **kw):
         from .env import BatchedDispatchEnv
         env = BatchedDispatchEnv(self.city.cost, self.city.node2cluster, self.nbr_off, self.nbr_idx, replicas=replicas,
                                  vehicles=self.vehicles, depth_limit=self.depth_limit,
                                  neighbor_can_server=self.neighbor_can_server, device=device, stream=stream, **kw)
-        env.load_orders(self.release_min, self.pickup, self.delivery)
+        if load:
+            env.load_orders(self.release_min, self.pickup, self.delivery)
         return env
 
 
@@ -121,3 +122,55 @@ def algorithmic_bytes(work: dict, vehicles: int) -> int:
     (idle entry 8 + vehicle location 4 + cost 4), 24 B per processed order, 24 B per match,
     4 B per vehicle per tick (arrival scan) and 28 B per arrival."""
     return (16 * work["evals"] + 24 * work["orders"] + 24 * work["matches"] + 4 * vehicles * work["ticks"] + 28 * work["arrivals"])
+
+
+def layout_bytes(work: dict, *, replicas: int, clusters: int, idle_loaded: int, busy_buckets: int) -> int:
+    """Bytes the tick kernel's DATA LAYOUT (csrc/vds_device.h) has to move through HBM for the work in ``work`` - the
+    lower bound that is specific to this implementation, as opposed to ``algorithmic_bytes``:
+
+      every (replica, cluster) bucket, every tick   header 12 B + arrival-slot counter 4 B + counters 64 B read,
+                                                    header 12 B written
+      buckets with orders (``busy_buckets``)        5 counter words (40 B) written
+      idle entries loaded (``idle_loaded``)         8 B each ({vehicle, node}); lists of order-less buckets are not read
+      arrivals                                      16 B entry read + 8 B idle entry appended
+      processed orders                              1 B (16 B record shared by the 16 replicas of a workgroup) + 8 B result
+      matches                                       16 B arrival entry + 8 B slot-counter read-modify-write
+
+    Cost lookups are served from the LDS copy of the cluster block and compaction rewrites are not counted (their
+    minimum is zero), so measured traffic lies above this figure."""
+    buckets = work["ticks"] * clusters              # work["ticks"] = ticks x replicas
+    return (buckets * (12 + 4 + 64 + 12) + 40 * busy_buckets + 8 * idle_loaded + 24 * work["arrivals"]
+            + 9 * work["orders"] + 24 * work["matches"])
+
+
+def profile_side_data(root: str, workload: str, replicas: int, kernel: str) -> dict:
+    """Committed rocprofv3 results for (workload, replicas, kernel): PMC-measured HBM bytes per launch
+    (profiles/traffic.json) and the VALU-issue limiter inputs (profiles/limiter.json).  Empty when none matches."""
+    import json
+    import os
+    out = {}
+    for fn, key in (("traffic.json", None), ("limiter.json", "limiter")):
+        path = os.path.join(root, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        try:
+            for e in json.load(open(path)).get("entries", []):
+                if e.get("workload") == workload and e.get("replicas") == replicas and e.get("kernel") == kernel:
+                    if key is None:
+                        out["hbm_bytes_per_launch"] = e.get("hbm_bytes_per_launch")
+                    else:
+                        out[key] = e
+        except Exception:
+            pass
+    return out
+
+
+def distinct_days(w: Workload, n_days: int, order_seed: int = 7001):
+    """``n_days`` different synthetic days of the workload's shape (same city, same order count, other seeds): what R
+    independent cities replay when each has its own ``Orders`` (``simulator.py:325-342``).  Day 0 is the workload's own."""
+    days = [(w.release_min, w.pickup, w.delivery)]
+    for d in range(1, n_days):
+        start, pick, dele = synth.make_orders(order_seed + d, w.city.N, w.release_min.size)
+        rel = synth.release_minutes(start)
+        days.append(((rel - rel[0]).astype(np.int32), pick, dele))
+    return days

@@ -58,16 +58,26 @@ def filter_orders_to_region(minute, pick, dele, node2cluster):
 
 def read_orders(path: str, node_index: dict) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """``ReadOrder`` (readfiles.py:70-81): keep ID/Start_time/NodeS/NodeE, truncate the unix
-    start time to the minute in the process-local time zone, sort by time, renumber.  The
-    reference sorts with pandas' default (unstable) quicksort; a stable sort is used here, so
-    orders released in the same minute keep file order (documented difference: INTEGRATION.md)."""
+    start time to the minute in the process-local time zone (``timestamp_datetime`` :8-11), sort by
+    time, renumber.
+
+    The sort is the reference's, bit for bit: ``DataFrame.sort_values(by="Start_time")`` (:78) with
+    pandas' default ``kind="quicksort"`` reduces to ``numpy.argsort(<datetime64[ns] column>,
+    kind="quicksort")`` (``pandas.core.sorting.nargsort``), an UNSTABLE sort: orders released in
+    the same minute are permuted the way numpy's scalar introsort leaves them, not kept in file
+    order.  The key TYPE matters: for ``datetime64`` numpy runs its generic introsort, for the
+    ``int64`` view of the same values it dispatches to a SIMD sort that leaves ties in a different
+    order (checked against the reference: only the ``datetime64`` call reproduces its order ids).
+    The same call on the same key type is made here, so a day loaded from the CSV carries the
+    reference's order ids (tests/test_world_loader.py pins this against arrays captured from the
+    reference's own ``ReadOrder``, incl. a day with ~14 orders per minute)."""
     import pandas as pd
     from datetime import datetime
 
     df = pd.read_csv(path)
     minute = np.array([np.datetime64(datetime.fromtimestamp(int(v)).replace(second=0, microsecond=0), "m")
                        for v in df["Start_time"].values])
-    order = np.argsort(minute, kind="stable")
+    order = np.argsort(minute.astype("datetime64[ns]"), kind="quicksort")     # NOT the int64 view: see the docstring
     pick = np.array([node_index[int(v)] for v in df["NodeS"].values[order]], dtype=np.int32)
     dele = np.array([node_index[int(v)] for v in df["NodeE"].values[order]], dtype=np.int32)
     return minute[order], pick, dele
@@ -104,9 +114,16 @@ def _parse_neighbor_csv(path: str, C: int, threshold: float = 15.0, first: int =
     return out
 
 
+def write_neighbor_csv(path: str, table) -> None:
+    """The cache file of ``simulator.py:616-621``: one row per cluster, cells ``"(cluster, mean cost)"``, no header."""
+    import pandas as pd
+    pd.DataFrame([[(int(j), d) for j, d in row] for row in table]).to_csv(path, header=0, index=0)
+
+
 def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_length_meter: float,
                vehicles_service_meter: float, order_file_date: str = "1101",
-               focus_on_local_region: bool = False, order_path: Optional[str] = None) -> World:
+               focus_on_local_region: bool = False, order_path: Optional[str] = None, device: int = 0,
+               write_neighbor_cache: bool = True) -> World:
     """Read ``data_dir`` (the reference's ``./data``) and derive every static table.
 
     ``focus_on_local_region``: nodes outside ``local_region_bound`` belong to no cluster
@@ -147,7 +164,13 @@ def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_len
         if os.path.exists(nb_path):
             neighbors = _parse_neighbor_csv(nb_path, C)
         else:
-            neighbors = synth.cluster_neighbors_from_cost(cost, node2cluster, C)
+            # the reference computes the table here (simulator.py:594-623) and caches it as ...Neighbor.csv: the same
+            # computation as a HIP segmented reduction (vds_cluster_cost_sums), and the same cache file
+            sums, sizes = synth.cluster_cost_sums_gpu(cost, node2cluster, C, device)
+            table = synth.neighbor_table_from_sums(sums, sizes)
+            neighbors = synth.neighbors_from_table(table)
+            if write_neighbor_cache:
+                write_neighbor_csv(nb_path, table)
     cluster_nodes = [np.flatnonzero(node2cluster == c).tolist() for c in range(C)]
 
     minute, pick, dele = read_orders(order_path or os.path.join(data_dir, "order_2016" + str(order_file_date) + ".csv"), index)
