@@ -556,7 +556,7 @@ __device__ __forceinline__ void rows_load_idle(const uint2 *idle, int l16, int m
 // through the LDS crossbar (ds_bpermute) instead of a scalar readlane; the loop runs to the longest row of the wavefront.
 template <int J, typename CT, bool PD>
 __device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
-                                           const int4 *lds_rec, const uint2 *arr_row, int2 *out_r, int r, bool rowvalid, size_t b, int m, int A,
+                                           const int4 *lds_rec, const uint2 *arr_row, int qb, int r, bool rowvalid, size_t b, int m, int A,
                                            uint2 *idle, long long cntv, unsigned (&veh)[J], int (&loc)[J], bool prof, unsigned long long tprev, int pwave) {
     const int lane = lane_id();
     const int l16 = lane & 15;
@@ -637,7 +637,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             const int got = __builtin_amdgcn_ds_bpermute(src, (int)veh[s]);
             vid = (matched && (wpos % J) == s) ? got : vid;
         }
-        if (has && !(abl & 8)) out_r[q0 + j] = make_int2(vid, matched ? wait : -1);
+        if (has && !(abl & 8)) D.out[(size_t)r * S.Oq + (PD ? q0 - qb : q0) + j] = make_int2(vid, matched ? wait : -1);
         if (matched && !(abl & 1)) {
             if (abl & 96) {   // timing-only: bit5 = atomic without the entry store, bit6 = entry store without the atomic
                 const int rel = wait + rr.w;
@@ -690,7 +690,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
 
 template <int J, typename CT, bool PD>
 __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
-                                          const int4 *lds_rec, unsigned long long *key_row, int2 *out_r, int r, bool rowvalid, size_t b, size_t si,
+                                          const int4 *lds_rec, unsigned long long *key_row, int qb, int r, bool rowvalid, size_t b, size_t si,
                                           int m, int A, long long cntv, bool prof, unsigned long long tprev, int pwave) {
     const int l16 = lane_id() & 15;
     // 3. the idle list and this tick's arrivals: both loads in flight together
@@ -759,7 +759,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         }
         return;
     }
-    rows_match<J, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, out_r, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
+    rows_match<J, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, qb, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
 }
 
 #ifndef ROWS_WAVES
@@ -771,8 +771,10 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #endif
 // U8: every cost fits a byte (Static.u8_ok): the cluster block is staged and read as bytes - a quarter of the L2 -> LDS
 // traffic, one 16-byte load per thread for blocks of up to 64 nodes
+// (the per-row variant holds its rows' pickup words and day descriptors: scheduled for 5 wavefronts per SIMD - at 7 it
+// spills 198 VGPRs into the match loop)
 template <bool U8, bool PD>
-__global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+__global__ __launch_bounds__(ROWS_WAVES * WAVE, PD ? 5 : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
     // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
@@ -803,8 +805,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
     const int r = (chunk * ROWS_WAVES + wave) * 4 + g;
     bool rowvalid = r < S.R;
     // the row's order day: shared by all replicas (scalar values) or looked up per row
-    int q0, k, now;
-    int2 *out_r = D.out + (size_t)(rowvalid ? r : 0) * S.Oq;
+    int q0, k, now, qb = 0;
     if (PD) {
         q0 = 0; k = 0; now = 0;
         if (rowvalid) {
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
                 const int *bo = S.bkt_off + dd.bkt_base + (size_t)t * S.C + c;
                 q0 = bo[0]; k = bo[1] - q0;
                 now = dd.now0 + t * S.tick_minutes;
-                out_r -= dd.q_base;
+                qb = dd.q_base;
             }
         }
     } else {
@@ -882,10 +883,10 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, ROWS_MIN_WAVES) void k_tick_rows
         // 3.-5. idle list + arrivals + match, specialised on the table depth
         unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
         PROF_STAMP(0);
-        if (big && !big96) rows_body<6, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (big) rows_body<8, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (small32) rows_body<2, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else rows_body<4, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, out_r, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        if (big && !big96) rows_body<6, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (big) rows_body<8, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (small32) rows_body<2, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else rows_body<4, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
     }
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {

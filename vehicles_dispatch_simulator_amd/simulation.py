@@ -37,6 +37,23 @@ _HOOKS = ("DemandPredictFunction", "DispatchFunction", "RewardFunction", "GetNex
 _FUSED = ("UpdateFunction", "MatchFunction", "SupplyExpectFunction", "FindServerVehicleFunction")
 
 
+class _ArrivalDict(dict):
+    """``Cluster.VehiclesArrivetime``: a plain dict that also remembers WHEN (in hook-body order) a key was assigned, so
+    that dispatches expressed as container edits and ``DispatchVehicle`` calls made in the same hook keep their
+    relative order - it decides the insertion order of the target's arrival dict, hence later list order."""
+    __slots__ = ("_sim", "_stamp")
+
+    def __init__(self, sim):
+        super().__init__()
+        self._sim = sim
+        self._stamp = {}
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        self._sim._hook_seq += 1
+        self._stamp[key] = self._sim._hook_seq
+
+
 class _RoadCostMap(object):
     """``self.Map[start][end]`` with the reference's DataFrame semantics (column, then row):
     ``int(self.Map[start][end]) == values[end, start]`` (``simulator.py:263-264``)."""
@@ -111,6 +128,7 @@ class Simulation(object):
         self._idle_objs = {}                 # cluster -> [list object, version it was filled at, vehicle ids at fill time]
         self._arr_objs = {}                  # cluster -> [dict object, version, {vehicle id: minute} at fill time]
         self._dev_dispatch_seen = [0, 0]     # device DispatchNum / TotallyDispatchCost already folded into the fields
+        self._hook_seq = 0                   # order of dispatch-relevant statements inside one hook body
         self.CalculateTheScaleOfDivision()
 
     # ---------------------------------------------------------------- context features (simulator.py:697-706, 833-866)
@@ -331,14 +349,15 @@ class Simulation(object):
         """The permanent ``dict`` behind ``Cluster.VehiclesArrivetime``."""
         ent = self._arr_objs.get(c)
         if ent is None:
-            ent = self._arr_objs[c] = [{}, -1, {}]
+            ent = self._arr_objs[c] = [_ArrivalDict(self), -1, {}]
         if ent[1] != self._version:
             L = self._lists()
             a, b = L["arr_off"][c], L["arr_off"][c + 1]
             snap = {int(v): int(m) for v, m in zip(L["arr_veh"][a:b], L["arr_min"][a:b])}
             V = self.Vehicles
             ent[0].clear()
-            ent[0].update((V[v], self._minute_to_time(m)) for v, m in snap.items())
+            ent[0].update((V[v], self._minute_to_time(m)) for v, m in snap.items())     # (update does not stamp)
+            ent[0]._stamp.clear()
             ent[1], ent[2] = self._version, snap
         return ent[0]
 
@@ -448,7 +467,8 @@ class Simulation(object):
         """Move one idle vehicle towards ``target_node`` (what a ``DispatchFunction`` body does by
         hand in the reference).  Queued; applied when the hook returns."""
         v = vehicle._index if isinstance(vehicle, Vehicle) else int(vehicle)
-        self._pending.append((v, int(target_node)))
+        self._hook_seq += 1
+        self._pending.append((self._hook_seq, v, int(target_node)))
 
     def _container_edits(self):
         """Edits a hook body made to ``Cluster.IdleVehicles`` / ``Cluster.VehiclesArrivetime`` in the reference's idiom,
@@ -494,7 +514,7 @@ class Simulation(object):
                 minute = delta // pd.Timedelta(minutes=1)
                 if delta != minute * pd.Timedelta(minutes=1):
                     raise Exception("vehicle %d: arrival time %s is not on a whole minute" % (v, t))
-                acts.append((v, dest, int(minute)))
+                acts.append((dct._stamp.get(self.Vehicles[v], 1 << 60), v, dest, int(minute)))
                 del removed[v]
         if removed:
             v, c = next(iter(removed.items()))
@@ -513,19 +533,17 @@ class Simulation(object):
             for p, v in enumerate(L["idle_veh"][L["idle_off"][c]:L["idle_off"][c + 1]]):
                 pos_of[int(v)] = (c, p)
         cl, ps, tg, am, ct, seen = [], [], [], [], [], set()
-        for v, t in self._pending:
+        # one action list in hook-body order (it is the insertion order of the targets' arrival dicts): DispatchVehicle
+        # calls are counted by the engine and timed RealExpTime + RoadCost; container edits carry the body's own time
+        todo = sorted([(q, v, t, -1, 1) for q, v, t in self._pending] + [(q, v, t, m, 0) for q, v, t, m in edits])
+        self._pending = []
+        for _, v, t, minute, counted in todo:
             if v not in pos_of:
                 raise Exception("DispatchVehicle: vehicle %d is not idle" % v)
             if v in seen:
-                raise Exception("DispatchVehicle: vehicle %d was dispatched twice in one hook" % v)
-            seen.add(v)
-            cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t); am.append(-1); ct.append(1)
-        for v, t, minute in edits:
-            if v in seen:
                 raise Exception("vehicle %d was dispatched twice in one hook" % v)
             seen.add(v)
-            cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t); am.append(minute); ct.append(0)
-        self._pending = []
+            cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t); am.append(minute); ct.append(counted)
         if edits:
             # DispatchVehicle entries carry -1: the device computes RealExpTime + RoadCost for them
             now = self.env.clock[1]
