@@ -17,6 +17,11 @@ env._lib.vds_debug_ablate(env._h, 0)
 names = ["0 update (drain + hdr)", "1 node mirror build", "2 LB reduction", "3 bucket-parallel own-cluster match", "4 DFS candidate scan", "5 DFS winner (+ removal + post in v1)",
          None, "7 resolve results + compaction + flush (v2)"]
 nw = R * 4
+if env.main_kernel() == "k_tick_replica3":
+    names = ["0 update (drain + hdr)", "1 mirror build", "2 phase 1: own-cluster pass, every bucket once", "3 dry bitset", "4 per dry order: pick + row + candidate scan",
+             "5 per dry order: barrier + winner (+ redo) + barrier", None, "7 evaluations + resolve + compaction + flush"]
+    nw = R * 8
+print(env.main_kernel())
 tot = float(buf[:6].sum() + buf[7])
 print("instrumented: %.2f ms/launch; DFS rounds per replica-tick: %.1f" % (ms.mean(), buf[6] / nw / T))
 for i, n in enumerate(names):

@@ -20,6 +20,9 @@ void launch_update_only(const Static &, const State &, int, hipStream_t);
 void launch_match_dfs(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
+void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
+size_t replica3_lds(const Static &);
+int replica3_prepare();
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, const int *, const int *, hipStream_t);
 void launch_dispatch_dense(const Static &, const State &, int, int, const int *, int, hipStream_t);
@@ -53,6 +56,7 @@ struct vds_handle {
     bool have_static = false, have_orders = false, have_reset = false;
     bool dfs_mode = false;
     bool dfs2_ok = false;   // k_tick_replica2 preconditions hold (see vds_kernels.hip)
+    bool dfs3_ok = false;   // k_tick_replica3 preconditions hold
     long long blk_ints = 0; // total size of the per-cluster cost blocks
     int cost_min = 0, cost_max = 0;
     int depth_limit = 0;
@@ -212,7 +216,10 @@ void vds_config_init(vds_config *cfg) {
 const char *vds_main_kernel(const vds_handle *h) {
     if (!h || !h->have_orders) return "";
     if (!h->dfs_mode) return h->S.fast_ok ? "k_tick_rows" : "k_tick";
-    if (h->S.C <= 3072 && h->cfg.force_generic != 1) return (h->dfs2_ok && h->cfg.force_generic == 0) ? "k_tick_replica2" : "k_tick_replica";
+    if (h->S.C <= 3072 && h->cfg.force_generic != 1) {
+        if (h->dfs3_ok && h->cfg.force_generic == 4) return "k_tick_replica3";
+        return (h->dfs2_ok && (h->cfg.force_generic == 0 || h->cfg.force_generic == 3 || h->cfg.force_generic == 4)) ? "k_tick_replica2" : "k_tick_replica";
+    }
     return "k_match_dfs";
 }
 
@@ -435,9 +442,9 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         // byte copy of the whole (column-permuted) matrix for the neighbour search
         S.cost8 = nullptr;
         if (u8) {
-            std::vector<unsigned char> c8((size_t)N * N);
+            std::vector<unsigned char> c8((size_t)N * N + 16, 0);       // + padding: the staged-row copy of k_tick_replica3 reads whole dwords
             bool fits = true;
-            for (size_t i = 0; i < c8.size() && fits; ++i) { fits = costp_host[i] >= 0 && costp_host[i] <= 255; c8[i] = (unsigned char)costp_host[i]; }
+            for (size_t i = 0; i < (size_t)N * N && fits; ++i) { fits = costp_host[i] >= 0 && costp_host[i] <= 255; c8[i] = (unsigned char)costp_host[i]; }
             if (fits) { unsigned char *d8; if ((rc = upload(h, &d8, c8))) return rc; S.cost8 = d8; }
             else S.u8_ok = 0;
         }
@@ -450,6 +457,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         int cmin = 0x7FFFFFFF, cmax = -0x7FFFFFFF - 1;
         for (size_t i = 0; i < (size_t)N * N; ++i) { cmin = std::min(cmin, cost[i]); cmax = std::max(cmax, cost[i]); }
         S.fast_ok = (cmin >= 0 && cmax < (1 << 23) && (long long)cmax <= S.reject_threshold) ? 1 : 0;
+        S.window_live = ((long long)cmax > S.reject_threshold) ? 1 : 0;
         if (h->cfg.force_generic == 1) S.fast_ok = 0;
         h->cost_min = cmin; h->cost_max = cmax;
     }
@@ -646,6 +654,10 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->dfs2_ok = h->dfs_mode && Omax <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 15) &&
                      Z.V <= 20480 && Z.N <= 65534 && Z.C <= 3072 && h->blk_ints < (1ll << 29) && Z.idle_cap <= 32767 && Z.max_tick_orders < 32768 &&
                      lds2 <= 64 * 1024;
+        // k_tick_replica3: the same packing limits, 16-bit ranks inside a slot, and its (bigger) LDS footprint; byte costs
+        // need the byte copy of the matrix for the staged row
+        h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
+                     replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }
     h->have_orders = true;
     return VDS_OK;
@@ -721,7 +733,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     h->S.idle_cap = cap;
     h->idle_cap_grown = cap;
     // k_tick_replica2 addresses list positions with 15 bits
-    if (cap > 32767) h->dfs2_ok = false;
+    if (cap > 32767) { h->dfs2_ok = false; h->dfs3_ok = false; }
     return VDS_OK;
 }
 
@@ -815,7 +827,10 @@ static int step_impl(vds_handle *h) {
             HIPCHK(h, hipEventRecord(a, h->stream));
         }
         // neighbour search: lower-bound rounds, one workgroup per replica
-        if (h->dfs2_ok && h->cfg.force_generic == 0) launch_tick_replica2(h->S, h->D, h->t, h->stream);
+        // k_tick_replica3 (own-cluster pass once + dry-order walk) is exact but measured SLOWER than the lower-bound rounds of
+        // k_tick_replica2 at configs[3]: opt-in only
+        if (h->dfs3_ok && h->cfg.force_generic == 4) launch_tick_replica3(h->S, h->D, h->t, h->stream);
+        else if (h->dfs2_ok && (h->cfg.force_generic == 0 || h->cfg.force_generic == 3 || h->cfg.force_generic == 4)) launch_tick_replica2(h->S, h->D, h->t, h->stream);
         else launch_tick_replica(h->S, h->D, h->t, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
     } else {

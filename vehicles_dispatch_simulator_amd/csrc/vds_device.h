@@ -81,6 +81,7 @@ struct Static {
     int idle_cap, fl_cap, in_cap;    // fl_cap / in_cap: far list / far inbox
     int H, ring_cap;                 // arrival ring: H ticks (power of two) x ring_cap entries
     int fast_ok;                     // costs fit the packed (cost << 7 | pos) fast kernel and never exceed the reject threshold
+    int window_live;                 // some cost exceeds the reject threshold: `cost > PICKUPTIMEWINDOW` (:943) can really reject
     int max_nc;
     const int *cost;                 // [N*N] rows = node, COLUMNS cluster-contiguous: column cl_off[c] + loc_local
     const int *node2cluster;         // [N]

@@ -38,8 +38,10 @@ __device__ int g_ablate = 0;
 __device__ unsigned long long g_prof[PROF_WAVES * 8];   // bit7 of g_ablate: per-wave, per-section cycles of k_tick_rows
 #ifdef VDS_PROF
 #define PROF_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * 8 + (i)] += t_ - tprev; tprev = __builtin_amdgcn_s_memtime(); } } while (0)
+#define PROF_STAMP_NW(i) do { if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * 8 + (i)] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define PROF_STAMP(i) do { } while (0)
+#define PROF_STAMP_NW(i) do { } while (0)
 #endif
 void read_prof(unsigned long long *out, hipStream_t st) {
     (void)hipStreamSynchronize(st);
@@ -1949,6 +1951,680 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
 }
 
 // ---------------------------------------------------------------------------------------
+// k_tick_replica3: neighbour-search mode, third generation.  Same results as k_tick_replica2; what changed is WHEN the
+// own-cluster matching happens.  The lower-bound rounds of k_tick_replica2 advance every bucket a little in each of the
+// ~49 rounds of a replica-tick (one order per visited bucket per round: the list is re-read from LDS every time, 53
+// wave-instructions per matched order).  Here:
+//   phase 1  every bucket matches ALL its orders once, in id order, as if no vehicle were ever taken from outside
+//            (exactly what happens until the first steal), up to the order that finds the list exhausted; from there on
+//            the bucket's orders are "dry" (:936 - the list stays empty for the rest of the slot).  Every taken entry is
+//            STAMPED with the rank (position in id order inside the slot) of the order that took it.
+//   phase 2  the dry orders are walked in id order.  Order x scans its visit sequence for the vehicles ALIVE AT ITS TIME:
+//            entries not stolen before and with stamp > rank(x) (taken later, or never).  The winner is stolen (stamp =
+//            rank(x), column = DEAD).  If it had been taken later by an own-cluster order y of the victim cluster, that
+//            cluster's matching is redone from y on (rare: the stamps >= rank(y) are cleared and phase 1 reruns on the
+//            tail); this may move the victim's exhaustion point one order earlier, i.e. add a dry order with a rank > x.
+//            Nothing that happened before x is ever touched again, so walking by increasing rank is exact.
+//   evaluations (:928-933 / :986-991 bodies) follow from the final stamps: an own-cluster order of rank p looked at
+//            #{entries of its bucket with stamp >= p}; a dry order counts the alive entries it scanned.
+// One 512-thread workgroup per replica; LDS: u32 mirror (cost column | stamp << 16) of every idle entry, rank tables,
+// the dry bitset and - byte costs - a double-buffered copy of the dry order's cost-matrix row, so the candidate scan
+// reads LDS only.  Preconditions as k_tick_replica2 plus < 65535 orders per slot and the LDS footprint (vds_api dfs3_ok).
+#define R3_THREADS 512
+#define R3_WAVES (R3_THREADS / WAVE)
+#define ST_FREE 0xFFFFu
+
+__host__ __device__ inline size_t replica3_lds_bytes(int C, int V, int mto, int N, int u8) {
+    const size_t ids = (size_t)(mto > RCNT * C ? mto : RCNT * C);
+    const size_t half = (size_t)((mto + 1) & ~1);                 // u16 entries per table (pickup node, position of rank)
+    const size_t words = (size_t)(mto + 31) / 32 + 1;
+    const size_t row = u8 ? (size_t)2 * (((size_t)N + 7) / 4 + 1) : 0;
+    return ((size_t)9 * C + 2 + ids + half + words + (size_t)V + row) * sizeof(int);
+}
+
+template <bool U8>
+__global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D, int t) {
+    extern __shared__ int lds_dyn[];
+    const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
+    auto cost_at = [](const char *base, unsigned elem) -> int {
+        return U8 ? (int)*reinterpret_cast<const unsigned char *>(base + elem) : *reinterpret_cast<const int *>(base + (elem << 2));
+    };
+    const int C = S.C;
+    const int mto = S.max_tick_orders;
+    int *m_l = lds_dyn;                 // [C] list length after Update; after the walk: final length
+    int *qdry_l = lds_dyn + C;          // [C] first sorted position that is not matched inside its own cluster
+    int *qend_l = lds_dyn + 2 * C;      // [C]
+    int *moff_l = lds_dyn + 3 * C;      // [C+1] start of the cluster's segment in mirror
+    int *arr_l = lds_dyn + 4 * C + 1;   // [C] arrivals of this tick
+    int *ev_l = arr_l + C;              // [C] evaluations of this tick
+    int *cdA_l = ev_l + C;              // [C] n_c | first cost column << 11 | can search << 30
+    int *cdB_l = cdA_l + C;             // [C] start of the cluster's cost block
+    int *dfsoff_l = cdB_l + C;          // [C+1] visit-sequence offsets
+    int *ord_l = dfsoff_l + C + 1;      // [max(mto, RCNT*C)] by sorted position: rank in id order | pickup_local << 16; later the resolve counters
+    const int ids_n = mto > RCNT * C ? mto : RCNT * C;
+    unsigned short *pnode_l = reinterpret_cast<unsigned short *>(ord_l + ids_n);    // [mto] pickup node by sorted position
+    unsigned short *qofr_l = pnode_l + ((mto + 1) & ~1);                            // [mto] sorted position of rank
+    unsigned *dry_bits = reinterpret_cast<unsigned *>(qofr_l + ((mto + 1) & ~1));   // bit per rank: the order is dry
+    const int nwords = (mto + 31) / 32 + 1;
+    unsigned *mirror = dry_bits + nwords;                                           // [V] column | stamp << 16
+    unsigned short *mirror16 = reinterpret_cast<unsigned short *>(mirror);
+    unsigned char *row_l = reinterpret_cast<unsigned char *>(mirror + S.V);        // [2][row_bytes] (U8)
+    const int row_bytes = ((S.N + 7) / 4 + 1) * 4;
+    const int r = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const int p = t & 1;
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;                       // whole workgroup: this replica's day is over
+    const int now = dv.now0 + t * S.tick_minutes;
+    const int *bkt_off = dv.bkt_off;
+    const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
+    const int nord = tq1 - tq0;
+    const int o0 = dv.tick_off[t];
+#ifdef VDS_PROF
+    const bool prof = (g_ablate & 128) != 0;
+    unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int pwave = (int)((blockIdx.x * R3_WAVES + wave) & (PROF_WAVES - 1));
+#endif
+    for (int i = threadIdx.x; i < nord; i += R3_THREADS) ord_l[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nord; i += R3_THREADS) {
+        const int4 rec = S.so_rec[tq0 + i];
+        atomicOr(&ord_l[i], (rec.y & 0xFFFF) << 16);
+        pnode_l[i] = (unsigned short)S.so_pnode[tq0 + i];
+        const int q = S.ord_q[o0 + i] - tq0;          // i-th order of the slot in id order
+        atomicOr(&ord_l[q], i);
+        qofr_l[i] = (unsigned short)q;
+    }
+    for (int c = threadIdx.x; c < C; c += R3_THREADS) {
+        const int4 cd = S.cdesc[c];
+        ev_l[c] = 0; arr_l[c] = 0;
+        cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (S.dfs_off[c + 1] > S.dfs_off[c] ? CAPABLE : 0);
+        cdB_l[c] = U8 ? cd.z : cd.y;
+        dfsoff_l[c] = S.dfs_off[c];
+        if (c == 0) dfsoff_l[C] = S.dfs_off[C];
+    }
+    for (int w = threadIdx.x; w < nwords; w += R3_THREADS) dry_bits[w] = 0u;
+    __syncthreads();
+    // ---- UpdateFunction (:1006-1024), as in k_tick_replica2: four buckets per wavefront, one per 16-lane row
+    auto update_wave = [&](int c) {
+        const size_t b = (size_t)c * S.R + r;
+        int *hdr = D.hdr + b * HDR_WORDS;
+        int hv = lane < HDR_WORDS ? hdr[lane] : 0;
+        int m = rdlane(hv, HDR_IDLE);
+        const int f = rdlane(hv, HDR_FL), qin = rdlane(hv, HDR_INBOX0 + p);
+        int newf = f;
+        if (f + qin > 0) {
+            update_far(S, D, c, r, t, now, f, qin, D.fl + b * S.fl_cap, D.inbox + ((size_t)p * S.C * S.R + b) * S.in_cap, newf);
+            wave_fence();
+        }
+        const int A = drain_ring(S, D, b, t, m, D.idle + b * S.idle_cap);
+        const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
+        if (lane == 0) {
+            hdr[HDR_FL] = newf; hdr[HDR_INBOX0 + p] = 0; hdr[HDR_IDLE_PRE] = m; hdr[HDR_ORDERS] = q1 - q0;
+            m_l[c] = m; qdry_l[c] = q0; qend_l[c] = q1;
+            if (A > 0) arr_l[c] = A;
+        }
+    };
+    {
+        const int g16 = lane >> 4, l16 = lane & 15;
+        for (int c0 = 0; c0 < C; c0 += 4 * R3_WAVES) {
+            const int c = c0 + wave * 4 + g16;
+            const bool valid = c < C;
+            const size_t b = (size_t)(valid ? c : 0) * S.R + r;
+            int *hdr = D.hdr + b * HDR_WORDS;
+            const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
+            int m = 0, far = 0, A = 0, q0 = 0, q1 = 0;
+            if (valid) {
+                m = hdr[HDR_IDLE];
+                far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
+                A = D.ring_cnt[si] & 0xFFFF;
+                q0 = bkt_off[(size_t)t * C + c]; q1 = bkt_off[(size_t)t * C + c + 1];
+            }
+            const bool slow = valid && (far != 0 || A > 16 || A > S.ring_cap);
+            const bool fast = valid && !slow;
+            if (ballot(fast && A > 0) != 0) {
+                int4 e = make_int4(0, 0, 0, 0);
+                unsigned khi = 0xFFFFFFFFu, klo = 0xFFFFFFFFu;
+                const bool mine = fast && l16 < A;
+                if (mine) {
+                    e = D.ring[si * S.ring_cap + l16];
+                    const unsigned long long key = entry_key(e.y, e.w);
+                    khi = (unsigned)(key >> 32); klo = (unsigned)key;
+                }
+                int rank = 0;
+                RowRank<15>::run(khi, klo, rank);
+                if (mine) {
+                    const int pos = m + rank;
+                    if (pos < S.idle_cap) D.idle[b * S.idle_cap + pos] = make_uint2((unsigned)e.x, (unsigned)meta_dest(e.w));
+                    else atomicOr(&D.err[0], ERR_IDLE_CAP);
+                }
+            }
+            if (fast && l16 == 0) {
+                if (A > 0) D.ring_cnt[si] = 0;
+                const int mn = min(m + A, S.idle_cap);
+                hdr[HDR_IDLE_PRE] = mn; hdr[HDR_ORDERS] = q1 - q0;
+                m_l[c] = mn; qdry_l[c] = q0; qend_l[c] = q1;
+                if (mn > m) arr_l[c] = mn - m;
+            }
+            for (unsigned long long rest = ballot(slow && l16 == 0); rest; rest &= rest - 1)
+                update_wave(c0 + wave * 4 + ((__ffsll((long long)rest) - 1) >> 4));
+        }
+    }
+    __syncthreads();
+    PROF_STAMP(0);
+    if (wave == 0) {            // exclusive prefix of the list lengths
+        int run = 0;
+        for (int base = 0; base < C; base += WAVE) {
+            const int c = base + lane;
+            const int v = c < C ? m_l[c] : 0;
+            int inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            if (c < C) moff_l[c] = run + inc - v;
+            run += rdlane(inc, WAVE - 1);
+        }
+        if (lane == 0) moff_l[C] = run;
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4 * R3_WAVES) {       // four buckets' list loads in flight per wavefront
+        int m4[4], mo4[4], clo4[4];
+        unsigned loc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u * R3_WAVES;
+            m4[u] = cu < C ? m_l[cu] : 0;
+            mo4[u] = cu < C ? moff_l[cu] : 0;
+            clo4[u] = cu < C ? (cdA_l[cu] >> 11) & 0xFFFF : 0;
+            loc4[u] = 0;
+            if (lane < m4[u]) loc4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane].y;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (lane < m4[u]) mirror[mo4[u] + lane] = (unsigned)(clo4[u] + (int)loc4[u]) | (ST_FREE << 16);
+            if (m4[u] > WAVE) {
+                const uint2 *idle = D.idle + ((size_t)(c + u * R3_WAVES) * S.R + r) * S.idle_cap;
+                for (int i = WAVE + lane; i < m4[u]; i += WAVE) mirror[mo4[u] + i] = (unsigned)(clo4[u] + (int)idle[i].y) | (ST_FREE << 16);
+            }
+        }
+    }
+    __syncthreads();
+    PROF_STAMP(1);
+    int2 *out_r = D.out + (size_t)r * S.Oq - dv.q_base;
+    const int thr32 = S.reject_threshold > 0x7FFF ? 0x7FFF : (S.reject_threshold < 0 ? -1 : (int)S.reject_threshold);   // costs < 2^15 here
+    const int gl = lane & (GRP - 1);              // lane within its group
+    const int gw = lane / GRP;                    // group within the wavefront
+
+    // ---- own-cluster matching (:924-965) of bucket c from qdry_l[c] on, by the 8-lane group `gw` (act_all: the group
+    //      has a bucket).  Entries that are free (never taken, not stolen) take part; every match stamps its entry.
+    //      Stops at the first order that finds no free entry when the cluster can search its neighbours (that order and
+    //      all later ones of the bucket are dry), otherwise rejects on (:966-969).
+    auto own_pass = [&](int c, bool act_all) {
+        int qc = qdry_l[c];
+        const int qe = qend_l[c];
+        const int cda = cdA_l[c];
+        const int nc = cda & 2047;
+        const bool capable = (cda & CAPABLE) != 0;
+        const int boff = cdB_l[c] - ((cda >> 11) & 0xFFFF);
+        const int mo = moff_l[c], m0 = act_all ? moff_l[c + 1] - mo : 0;
+        const bool longlist = m0 > SLOTS * GRP;
+        bool act = act_all && !longlist && qc < qe;
+        int mx = (act_all && !longlist) ? m0 : 0;
+        mx = max(mx, dpp_mov<0x4E, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x141, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x140, 0xF>(mx, mx));
+        const int mmaxw = max(max(rdlane(mx, 0), rdlane(mx, 16)), max(rdlane(mx, 32), rdlane(mx, 48)));
+        if (ballot(act) != 0) {
+            int col[SLOTS];
+            unsigned amask = 0;
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                col[u] = DEAD;
+                if (u * GRP < mmaxw) {
+                    const int i = u * GRP + gl;
+                    const unsigned v = mirror[mo + min(i, max(m0, 1) - 1)];
+                    const bool fr = i < m0 && (v >> 16) == ST_FREE && (v & 0xFFFF) != DEAD;
+                    col[u] = (int)(v & 0xFFFF);
+                    amask |= (fr ? 1u : 0u) << u;
+                }
+            }
+            int navail = __popc(amask);
+            navail += dpp_mov<0xB1, 0xF>(navail, navail); navail += dpp_mov<0x4E, 0xF>(navail, navail); navail += dpp_mov<0x141, 0xF>(navail, navail);
+            while (ballot(act) != 0) {
+                const bool empty = act && navail == 0;
+                const bool stop = empty && capable;                  // dry from here on
+                const bool go = act && !empty;
+                const int idw = go ? ord_l[qc - tq0] : 0;
+                const int rowoff = boff + (int)((unsigned)idw >> 16) * nc;
+                const unsigned take = go ? amask : 0u;
+                int cst[SLOTS];
+                const bool any = ballot(go) != 0;
+#pragma unroll
+                for (int u = 0; u < SLOTS; ++u) {
+                    cst[u] = 0;
+                    if (any && u * GRP < mmaxw) cst[u] = cost_at(blk_b, (unsigned)(((take >> u) & 1u) ? rowoff + col[u] : 0));
+                }
+                int key = IMAX;
+#pragma unroll
+                for (int u = 0; u < SLOTS; ++u)
+                    if (u * GRP < mmaxw) key = min(key, ((take >> u) & 1u) ? (cst[u] << 16) | (u * GRP + gl) : IMAX);
+                key = grp_min_i32(key);
+                if (act && !stop) {
+                    int2 res = make_int2(-1, -1);
+                    if (go && key != IMAX && (key >> 16) <= thr32) {     // :943 (quirk Q3)
+                        const int pos = key & 0xFFFF;
+                        if ((pos & (GRP - 1)) == gl) amask &= ~(1u << (pos / GRP));
+                        if (gl == 0) mirror16[2 * (mo + pos) + 1] = (unsigned short)(idw & 0xFFFF);
+                        navail--;
+                        res = make_int2((int)(((unsigned)c << 16) | (unsigned)pos), key >> 16);
+                    }
+                    if (gl == 0) out_r[qc] = res;
+                    qc++;
+                }
+                act = act && !stop && qc < qe;
+            }
+        }
+        act = act_all && longlist && qc < qe;
+        if (ballot(act) != 0) {
+            // long lists: one order at a time, 64 candidates per pass, free entries counted on the way
+            while (ballot(act) != 0) {
+                int key = IMAX, nfree = 0;
+                const int idw = act ? ord_l[qc - tq0] : 0;
+                if (act) {
+                    const int rowoff = boff + (int)((unsigned)idw >> 16) * nc;
+                    for (int i0 = 0; i0 < m0; i0 += 8 * GRP) {
+                        int cl[8], cst[8], ok[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * GRP + gl;
+                            const unsigned v = mirror[mo + min(i, m0 - 1)];
+                            cl[u] = (int)(v & 0xFFFF);
+                            ok[u] = (i < m0 ? 1 : 0) & ((v >> 16) == ST_FREE ? 1 : 0) & (cl[u] != DEAD ? 1 : 0);
+                            nfree += ok[u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            cst[u] = cost_at(blk_b, (unsigned)(ok[u] ? rowoff + cl[u] : 0));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            key = min(key, ok[u] ? (cst[u] << 16) | (i0 + u * GRP + gl) : IMAX);
+                    }
+                }
+                key = grp_min_i32(key);
+                nfree += dpp_mov<0xB1, 0xF>(nfree, nfree); nfree += dpp_mov<0x4E, 0xF>(nfree, nfree); nfree += dpp_mov<0x141, 0xF>(nfree, nfree);
+                const bool stop = act && nfree == 0 && capable;
+                if (act && !stop) {
+                    int2 res = make_int2(-1, -1);
+                    if (key != IMAX && (long long)(key >> 16) <= S.reject_threshold) {     // :943 (quirk Q3)
+                        if (gl == 0) mirror16[2 * (mo + (key & 0xFFFF)) + 1] = (unsigned short)(idw & 0xFFFF);
+                        res = make_int2((int)(((unsigned)c << 16) | (unsigned)(key & 0xFFFF)), key >> 16);
+                    }
+                    if (gl == 0) out_r[qc] = res;
+                    qc++;
+                }
+                act = act && !stop && qc < qe;
+                wave_fence();
+            }
+        }
+        if (act_all && gl == 0) qdry_l[c] = qc;
+    };
+
+    // ---- phase 1: every bucket once
+    for (int c0 = wave * GRPS_WAVE; c0 < C; c0 += R3_WAVES * GRPS_WAVE) {
+        const int c = c0 + gw;
+        own_pass(c < C ? c : 0, c < C);
+    }
+    __syncthreads();
+    PROF_STAMP(2);
+    // dry orders: everything behind a searching cluster's exhaustion point
+    for (int c = threadIdx.x; c < C; c += R3_THREADS) {
+        if (!(cdA_l[c] & CAPABLE)) continue;
+        for (int q = qdry_l[c]; q < qend_l[c]; ++q) {
+            const int rk = (int)(ord_l[q - tq0] & 0xFFFF);
+            atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
+        }
+    }
+    __syncthreads();
+    PROF_STAMP(3);
+    // ---- phase 2: the dry orders in id order.  One barrier per order: while an order is scanned, everything the NEXT one
+    //      needs is fetched (its cost-matrix row into registers, then into the other LDS row buffer; its visit sequence);
+    //      after the barrier EVERY wavefront derives the winner from the eight candidates and moves on - wavefront 0 also
+    //      applies the steal.  Its write may not be visible to the next scan yet, so that scan skips the stolen entry by
+    //      index (two scans later a barrier lies in between).  Only a redo of the victim (rare) takes extra barriers.
+    auto next_dry = [&](int from) -> int {        // smallest dry rank >= from (every wavefront computes it), IMAX: none
+        int best = IMAX;
+        for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
+            unsigned bits = dry_bits[w];
+            if (w == (from >> 5)) bits &= 0xFFFFFFFFu << (from & 31);
+            if (bits != 0u) { best = w * 32 + __ffs((int)bits) - 1; break; }
+        }
+        return wave_min_i32(best);
+    };
+    auto cluster_of = [&](int q) -> int {         // the bucket whose range of sorted positions holds q
+        int pc = 0;
+        for (int base = 0; base < C; base += WAVE) {
+            const int c = base + lane;
+            const bool hit = c < C && q < qend_l[c] && (c == 0 || q >= qend_l[c - 1]);
+            const unsigned long long hb = ballot(hit);
+            if (hb) { pc = base + __ffsll((long long)hb) - 1; break; }
+        }
+        return pc;
+    };
+    const bool stage = U8 && S.N <= 8188;                          // the row fits four dwords per thread
+    const int ROWREGS = 4;
+    auto row_fetch = [&](int pnode, unsigned (&rr)[4]) {           // issue the loads of node pnode's cost row (dword aligned)
+        const size_t a0 = (size_t)pnode * S.N;
+        const int shift = (int)(a0 & 3);
+        const unsigned *src = reinterpret_cast<const unsigned *>(S.cost8 + (a0 - shift));
+        const int nw = (S.N + shift + 3) >> 2;
+#pragma unroll
+        for (int u = 0; u < ROWREGS; ++u) {
+            const int i = (int)threadIdx.x + u * R3_THREADS;
+            rr[u] = i < nw ? src[i] : 0u;
+        }
+    };
+    auto row_store = [&](int bufi, int pnode, const unsigned (&rr)[4]) {
+        const int shift = (int)(((size_t)pnode * S.N) & 3);
+        const int nw = (S.N + shift + 3) >> 2;
+        unsigned *dst = reinterpret_cast<unsigned *>(row_l + (size_t)bufi * row_bytes);
+#pragma unroll
+        for (int u = 0; u < ROWREGS; ++u) {
+            const int i = (int)threadIdx.x + u * R3_THREADS;
+            if (i < nw) dst[i] = rr[u];
+        }
+    };
+    __shared__ int s_cand3[2][R3_WAVES][4];
+    int rho = next_dry(0);
+    if (rho != IMAX) {
+        int q = tq0 + (int)qofr_l[rho];
+        int pc = cluster_of(q);
+        int pnode = (int)pnode_l[q - tq0];
+        int s0 = dfsoff_l[pc], s1 = dfsoff_l[pc + 1];
+        int cj = 0;
+        { const int sx = s0 + wave + lane * R3_WAVES; if (sx < s1) cj = S.dfs_seq[sx]; }
+        unsigned rr[4] = {0u, 0u, 0u, 0u};
+        if (stage) { row_fetch(pnode, rr); row_store(0, pnode, rr); }
+        __syncthreads();
+        int buf = 0, par = 0, prev_idx = -1;
+        for (;;) {
+            // ---- everything the next dry order needs, in flight during this order's scan
+            int rho_n = next_dry(rho + 1);
+            int q_n = 0, pc_n = 0, pnode_n = 0, s0_n = 0, s1_n = 0, cj_n = 0;
+            if (rho_n != IMAX) {
+                q_n = tq0 + (int)qofr_l[rho_n];
+                pc_n = cluster_of(q_n);
+                pnode_n = (int)pnode_l[q_n - tq0];
+                s0_n = dfsoff_l[pc_n]; s1_n = dfsoff_l[pc_n + 1];
+                const int sx = s0_n + wave + lane * R3_WAVES;
+                if (sx < s1_n) cj_n = S.dfs_seq[sx];
+                if (stage) row_fetch(pnode_n, rr);
+            }
+#ifdef R3DIAG
+            PROF_STAMP_NW(1);
+#endif
+            // ---- candidate scan of order rho (:978-996): this wavefront's share of the visit sequence
+            const int rowoff_l = buf * row_bytes + (int)(((size_t)pnode * S.N) & 3);
+            const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
+            int bhi = IMAX, blo = IMAX, bst = (int)ST_FREE, acnt = 0;
+            for (int jb = 0; s0 + wave + jb * R3_WAVES < s1; jb += WAVE) {
+                if (jb > 0) {                               // visit sequences longer than 64 clusters per wavefront
+                    const int sx = s0 + wave + (jb + lane) * R3_WAVES;
+                    cj = sx < s1 ? S.dfs_seq[sx] : 0;
+                }
+                const int nj = min(WAVE, (s1 - s0 - wave - jb * R3_WAVES + R3_WAVES - 1) / R3_WAVES);
+                int moj = 0, m0j = 0;
+                if (lane < nj) {
+                    moj = moff_l[cj];
+                    m0j = moff_l[cj + 1] - moj;
+                }
+                unsigned long long live = ballot(m0j > 0);
+                int b = 0, best = IMAX, bestv = 0;
+                while (live != 0) {
+                    int cl[8], cst[8], seq[8], in[8], stv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        in[k] = 0; cl[k] = DEAD; seq[k] = 0; stv[k] = 0;
+                        if (live != 0) {
+                            const int j = __ffsll((long long)live) - 1;
+                            const int m0c = rdlane(m0j, j), moc = rdlane(moj, j);
+                            const int i = b * WAVE + lane;
+                            const int at = moc + min(i, m0c - 1);
+                            const unsigned v = mirror[at];
+                            cl[k] = (int)(v & 0xFFFF);
+                            stv[k] = (int)(v >> 16);
+                            // alive at this order's time: not stolen (incl. by the previous order, whose write may be in
+                            // flight), and taken - if at all - by a LATER own-cluster order
+                            in[k] = (i < m0c ? 1 : 0) & (cl[k] != DEAD ? 1 : 0) & (stv[k] > rho ? 1 : 0) & (at != prev_idx ? 1 : 0);
+                            seq[k] = (j << 9) | b;
+                            ++b;
+                            if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (stage) cst[k] = (int)row_l[rowoff_l + (in[k] ? cl[k] : 0)];
+                        else cst[k] = cost_at(crow_b, (unsigned)(in[k] ? cl[k] : 0));
+                        acnt += in[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int key = in[k] ? (cst[k] << 16) | seq[k] : IMAX;
+                        if (key < best) { best = key; bestv = stv[k]; }
+                    }
+                }
+                const int wbest = wave_min_i32(best);
+                if (wbest != IMAX) {
+                    const int wl = __ffsll((long long)ballot(best == wbest)) - 1;       // lowest lane = lowest list position
+                    const int j = (wbest >> 9) & 63, bb = wbest & 511;
+                    const int hi = (wbest & ~0xFFFF) | ((jb + j) * R3_WAVES + wave);
+                    const int lo = ((bb * WAVE + wl) << 16) | rdlane(cj, j);
+                    if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; bst = rdlane(bestv, wl); }
+                }
+            }
+            {   // :986-991 runs for every visited cluster: its alive vehicles count as evaluations of this order
+                const int rs = row_sum_i32(acnt);
+                const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
+                if (lane == 0 && tot) atomicAdd(&ev_l[pc], tot);
+            }
+#ifdef R3DIAG
+            PROF_STAMP_NW(2);
+#endif
+            if (lane == 0) { s_cand3[par][wave][0] = bhi; s_cand3[par][wave][1] = blo; s_cand3[par][wave][2] = bst; }
+            if (stage && rho_n != IMAX) row_store(buf ^ 1, pnode_n, rr);
+#ifdef R3DIAG
+            PROF_STAMP_NW(3);
+            __syncthreads();
+            PROF_STAMP_NW(4);
+#else
+            PROF_STAMP(4);
+            __syncthreads();
+#endif
+            // ---- the winner, derived by every wavefront: lexicographic minimum of (hi, lo) over the eight candidates
+            int whi, wlo, wst;
+            {
+                const int h = lane < R3_WAVES ? s_cand3[par][lane][0] : IMAX;
+                const int l = lane < R3_WAVES ? s_cand3[par][lane][1] : IMAX;
+                const int st = lane < R3_WAVES ? s_cand3[par][lane][2] : 0;
+                whi = wave_min_i32(h);
+                wlo = wave_min_i32(h == whi ? l : IMAX);
+                const unsigned long long who = ballot(h == whi && l == wlo);
+                wst = rdlane(st, __ffsll((long long)who) - 1);
+            }
+            const int wc = whi >> 16;
+            const bool matched = whi != IMAX && (long long)wc <= S.reject_threshold;
+            const int wcl = wlo & 0xFFFF, wpos = wlo >> 16;
+            const int idx = matched ? moff_l[wcl] + wpos : -1;
+            if (wave == 0 && lane == 0) {
+                if (matched) mirror[idx] = (unsigned)DEAD | ((unsigned)rho << 16);     // stolen at rank rho
+                out_r[q] = matched ? make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc) : make_int2(-1, -1);
+            }
+            prev_idx = idx;
+            // Redo the victim's own-cluster matching from its first order after this one when the past it was built on
+            // changed: (a) the stolen vehicle had been taken later by an own-cluster order of the victim; (b) with a live
+            // pickup window (:943 really rejects) an own-cluster order may have been REJECTED while the list was not
+            // empty - if the steal empties the list before that order's time, it has to search the neighbours instead.
+            if (matched && (wst != (int)ST_FREE || S.window_live)) {       // workgroup-uniform
+                __syncthreads();
+                if (wave == 0) {
+                    const int victim = wcl;
+                    const int qa = victim == 0 ? tq0 : qend_l[victim - 1];
+                    const int old_dry = qdry_l[victim];
+                    int qy = old_dry;                              // first own-cluster position with rank > rho
+                    for (int base = qa; base < old_dry; base += WAVE) {
+                        const int qq = base + lane;
+                        const unsigned long long later = ballot(qq < old_dry && (int)(ord_l[(qq < old_dry ? qq : qa) - tq0] & 0xFFFF) > rho);
+                        if (later) { qy = base + __ffsll((long long)later) - 1; break; }
+                    }
+                    if (qy < old_dry) {
+                        const int mo = moff_l[victim], m0 = moff_l[victim + 1] - mo;
+                        for (int i = lane; i < m0; i += WAVE) {
+                            const unsigned v = mirror[mo + i];
+                            const int st = (int)(v >> 16);
+                            if ((v & 0xFFFF) != DEAD && st != (int)ST_FREE && st > rho) mirror[mo + i] = v | (ST_FREE << 16);
+                        }
+                        wave_fence();
+                        if (lane == 0) qdry_l[victim] = qy;
+                        wave_fence();
+                        own_pass(victim, gw == 0);
+                        wave_fence();
+                        const int new_dry = qdry_l[victim];
+                        if (cdA_l[victim] & CAPABLE)
+                            for (int qq = new_dry + lane; qq < old_dry; qq += WAVE) {
+                                const int rk = (int)(ord_l[qq - tq0] & 0xFFFF);
+                                atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
+                            }
+                    }
+                }
+                __syncthreads();
+                prev_idx = -1;                                     // the barriers made the steal visible
+                const int rho_2 = next_dry(rho + 1);               // the redo may have made an earlier order dry
+                if (rho_2 != rho_n) {
+                    rho_n = rho_2;
+                    q_n = tq0 + (int)qofr_l[rho_n];
+                    pc_n = cluster_of(q_n);
+                    pnode_n = (int)pnode_l[q_n - tq0];
+                    s0_n = dfsoff_l[pc_n]; s1_n = dfsoff_l[pc_n + 1];
+                    const int sx = s0_n + wave + lane * R3_WAVES;
+                    cj_n = sx < s1_n ? S.dfs_seq[sx] : 0;
+                    if (stage) { row_fetch(pnode_n, rr); row_store(buf ^ 1, pnode_n, rr); }
+                    __syncthreads();
+                }
+            }
+            PROF_STAMP(5);
+#ifdef VDS_PROF
+            if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+#endif
+            if (rho_n == IMAX) break;
+            rho = rho_n; q = q_n; pc = pc_n; pnode = pnode_n; s0 = s0_n; s1 = s1_n; cj = cj_n;
+            buf ^= 1; par ^= 1;
+        }
+    }
+    __syncthreads();
+    // ---- evaluations of the own-cluster orders and the final list lengths, from the final stamps: one 8-lane group per
+    //      bucket.  Order of rank p looked at the entries with stamp >= p (free = 0xFFFF; stolen entries carry the thief's rank).
+    for (int c0 = wave * GRPS_WAVE; c0 < C; c0 += R3_WAVES * GRPS_WAVE) {
+        const int c = c0 + gw;
+        const bool has = c < C;
+        const int cc = has ? c : 0;
+        const int mo = moff_l[cc], m0 = has ? moff_l[cc + 1] - mo : 0;
+        const int qa = has ? bkt_off[(size_t)t * C + cc] : 0;
+        const int qb2 = has ? qdry_l[cc] : 0;                       // own-cluster orders: [qa, qb2)
+        int ev = 0, fin = 0;
+        int mx = m0;
+        mx = max(mx, dpp_mov<0x4E, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x141, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x140, 0xF>(mx, mx));
+        const int mmaxw = max(max(rdlane(mx, 0), rdlane(mx, 16)), max(rdlane(mx, 32), rdlane(mx, 48)));
+        int nq = qb2 - qa;
+        nq = max(nq, dpp_mov<0x4E, 0xF>(nq, nq)); nq = max(nq, dpp_mov<0x141, 0xF>(nq, nq)); nq = max(nq, dpp_mov<0x140, 0xF>(nq, nq));
+        const int nqmax = max(max(rdlane(nq, 0), rdlane(nq, 16)), max(rdlane(nq, 32), rdlane(nq, 48)));
+        for (int i0 = 0; i0 < mmaxw; i0 += GRP) {
+            const int i = i0 + gl;
+            const bool ok = i < m0;
+            const unsigned v = ok ? mirror[mo + i] : 0u;
+            const int st = ok ? (int)(v >> 16) : -1;
+            fin += (ok && (v >> 16) == ST_FREE && (v & 0xFFFF) != DEAD) ? 1 : 0;
+            for (int j = 0; j < nqmax; ++j) {
+                const int qq = qa + j;
+                const int rk = qq < qb2 ? (int)(ord_l[qq - tq0] & 0xFFFF) : IMAX;
+                ev += st >= rk ? 1 : 0;
+            }
+        }
+        ev += dpp_mov<0xB1, 0xF>(ev, ev); ev += dpp_mov<0x4E, 0xF>(ev, ev); ev += dpp_mov<0x141, 0xF>(ev, ev);
+        fin += dpp_mov<0xB1, 0xF>(fin, fin); fin += dpp_mov<0x4E, 0xF>(fin, fin); fin += dpp_mov<0x141, 0xF>(fin, fin);
+        if (has && gl == 0) { if (ev) atomicAdd(&ev_l[c], ev); m_l[c] = fin; }
+    }
+    __syncthreads();
+    // ---- resolve the preliminary results: vehicle ids, arrivals (:954-960), counters (the id table is dead now)
+    int *rc_l = ord_l;
+    for (int i = threadIdx.x; i < RCNT * C; i += R3_THREADS) rc_l[i] = 0;
+    __syncthreads();
+    for (int q = tq0 + (int)threadIdx.x; q < tq1; q += R3_THREADS) {
+        const int4 rec = S.so_rec[q];
+        const int2 pr = out_r[q];
+        int *cl = rc_l + (int)((unsigned)rec.z >> 16) * RCNT;
+        atomicAdd(&cl[CNT_ORDERS], 1);
+        if (pr.x == -1) {
+            atomicAdd(&cl[CNT_REJECTS], 1);
+        } else {
+            const int vc = (int)((unsigned)pr.x >> 16), vpos = pr.x & 0xFFFF;
+            const int veh = (int)D.idle[((size_t)vc * S.R + r) * S.idle_cap + vpos].x;
+            out_r[q] = make_int2(veh, pr.y);
+            post_arrival(S, D, rec.z & 0xFFFF, r, t, now, veh, rec.x, now + pr.y + rec.w, 0, (int)((unsigned)rec.y >> 16));
+            atomicAdd(&cl[CNT_WAIT], pr.y);
+            atomicAdd(&cl[CNT_VALUE], rec.w);
+        }
+    }
+    __syncthreads();
+    // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = free entries)
+    for (int c = wave; c < C; c += 4 * R3_WAVES) {
+        uint2 e4[4];
+        bool keep4[4], small4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u * R3_WAVES;
+            const int mo = cu < C ? moff_l[cu] : 0, m0 = cu < C ? moff_l[cu + 1] - mo : 0;
+            small4[u] = cu < C && m0 <= WAVE && m_l[cu] != m0;
+            unsigned v = 0u;
+            if (small4[u] && lane < m0) v = mirror[mo + lane];
+            keep4[u] = small4[u] && lane < m0 && (v >> 16) == ST_FREE && (v & 0xFFFF) != DEAD;
+            e4[u] = make_uint2(0u, 0u);
+            if (keep4[u]) e4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long kb = ballot(keep4[u]);
+            if (keep4[u]) D.idle[((size_t)(c + u * R3_WAVES) * S.R + r) * S.idle_cap + popc64(kb & lanemask_lt())] = e4[u];
+        }
+    }
+    for (int c = wave; c < C; c += R3_WAVES) {
+        const int mo = moff_l[c], m0 = moff_l[c + 1] - mo;
+        if (m_l[c] == m0 || m0 <= WAVE) continue;
+        uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
+        int kept = 0;
+        for (int base = 0; base < m0; base += WAVE) {
+            const int i = base + lane;
+            uint2 e = make_uint2(0u, 0u);
+            bool keep = false;
+            if (i < m0) {
+                const unsigned v = mirror[mo + i];
+                keep = (v >> 16) == ST_FREE && (v & 0xFFFF) != DEAD;
+                if (keep) e = idle[i];
+            }
+            const unsigned long long kb = ballot(keep);
+            wave_fence();
+            if (keep) idle[kept + popc64(kb & lanemask_lt())] = e;
+            kept += popc64(kb);
+        }
+    }
+    PROF_STAMP(7);
+    // ---- flush: idle counts and this tick's counter deltas
+    for (int c = threadIdx.x; c < C; c += R3_THREADS) {
+        const size_t b = (size_t)c * S.R + r;
+        D.hdr[b * HDR_WORDS + HDR_IDLE] = m_l[c];
+        long long *cnt = D.cnt + b * CNT_WORDS;
+#pragma unroll
+        for (int w = 0; w < RCNT; ++w) { const int d = rc_l[c * RCNT + w]; if (d) cnt[w] += d; }
+        if (ev_l[c]) cnt[CNT_EVALS] += ev_l[c];
+        if (arr_l[c]) cnt[CNT_ARRIVALS] += arr_l[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_dispatch: one wavefront per (replica, from_cluster) group of actions (host-sorted).
 // grp_off[g]..grp_off[g+1] index the group's actions; positions refer to the idle list as it
 // stands at call time.
@@ -2223,6 +2899,20 @@ void launch_tick_replica2(const Static &S, const State &D, int t, hipStream_t st
     const size_t lds = replica2_lds_ints(S.C, S.V, S.max_tick_orders) * sizeof(int);
     if (S.u8_ok) hipLaunchKernelGGL(k_tick_replica2<true>, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
     else hipLaunchKernelGGL(k_tick_replica2<false>, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
+}
+
+size_t replica3_lds(const Static &S) { return replica3_lds_bytes(S.C, S.V, S.max_tick_orders, S.N, S.u8_ok); }
+
+void launch_tick_replica3(const Static &S, const State &D, int t, hipStream_t st) {
+    const size_t lds = replica3_lds(S);
+    if (S.u8_ok) hipLaunchKernelGGL(k_tick_replica3<true>, dim3(S.R), dim3(R3_THREADS), lds, st, S, D, t);
+    else hipLaunchKernelGGL(k_tick_replica3<false>, dim3(S.R), dim3(R3_THREADS), lds, st, S, D, t);
+}
+
+int replica3_prepare() {      // opt in to more than 64 KB of dynamic LDS per workgroup
+    hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tick_replica3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tick_replica3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    return (a == hipSuccess && b == hipSuccess) ? 0 : -1;
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
