@@ -644,6 +644,11 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
     { DayDesc *dd; if ((rc = upload(h, &dd, ddesc))) return rc; S.day = dd; }
     if ((rc = upload(h, &d, h->replica_day))) return rc; S.replica_day = d;
+    {
+        std::vector<int4> rdesc(S.R);
+        for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[h->replica_day[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
+        int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
+    }
     if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1)))) return rc;
     h->alloc_sink = nullptr;
     if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;

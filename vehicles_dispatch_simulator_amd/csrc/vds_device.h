@@ -74,6 +74,7 @@ struct Static {
     int n_days;                      // 1: one order stream shared by every replica (the fast path of k_tick_rows)
     const DayDesc *day;              // [n_days]
     const int *replica_day;          // [R]
+    const int4 *replica_desc;        // [R] {bkt_base, now0, T, q_base} of the replica's day: one load instead of replica_day -> day[]
     int tick_minutes, now0;          // RealExpTime at tick 0
     unsigned tick_magic;             // ceil(2^32 / tick_minutes): n / tick == mulhi(n, magic) for 0 <= n < tick_div_limit
     int tick_div_limit;              // (0: always divide)

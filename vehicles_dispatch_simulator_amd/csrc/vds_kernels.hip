@@ -773,12 +773,16 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #endif
 // U8: every cost fits a byte (Static.u8_ok): the cluster block is staged and read as bytes - a quarter of the L2 -> LDS
 // traffic, one 16-byte load per thread for blocks of up to 64 nodes
-// (the per-row variant holds its rows' pickup words and day descriptors: scheduled for 5 wavefronts per SIMD - at 7 it
+// (the per-row variant holds its rows' pickup words and day descriptors: scheduled for fewer wavefronts per SIMD - at 7 it
 // spills 198 VGPRs into the match loop)
+#ifndef ROWS_PD_MIN_WAVES
+#define ROWS_PD_MIN_WAVES 6
+#endif
 template <bool U8, bool PD>
-__global__ __launch_bounds__(ROWS_WAVES * WAVE, PD ? 5 : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+__global__ __launch_bounds__(ROWS_WAVES * WAVE, PD ? ROWS_PD_MIN_WAVES : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
+    if (!PD) S.n_days = 1;     // the shared-day instantiation: lets the compiler fold every per-day lookup of the inlined generic paths
     // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
     // the ranked arrivals) | cost block
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
@@ -811,13 +815,13 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, PD ? 5 : ROWS_MIN_WAVES) void k_
     if (PD) {
         q0 = 0; k = 0; now = 0;
         if (rowvalid) {
-            const DayDesc dd = S.day[S.replica_day[r]];
-            rowvalid = t < dd.T;                     // the row's day is over: its city stands still
+            const int4 dd = S.replica_desc[r];       // {bkt_base, now0, T, q_base}
+            rowvalid = t < dd.z;                     // the row's day is over: its city stands still
             if (rowvalid) {
-                const int *bo = S.bkt_off + dd.bkt_base + (size_t)t * S.C + c;
+                const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
                 q0 = bo[0]; k = bo[1] - q0;
-                now = dd.now0 + t * S.tick_minutes;
-                qb = dd.q_base;
+                now = dd.y + t * S.tick_minutes;
+                qb = dd.w;
             }
         }
     } else {
