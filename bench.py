@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify replica 0 against the oracle after the run")
+    ap.add_argument("--distinct-days", type=int, default=16, help="extra leg: the same workload with this many different order days (0/1 = skip)")
     a = ap.parse_args()
 
     import torch
@@ -231,6 +232,29 @@ def main():
                                        "cycles_per_valu_inst": lim["cycles_per_valu_inst"],
                                        "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source")}
 
+    # ---- per-replica order days (rank 0, N = 1): the headline replays ONE day in every replica, which lets 16 replicas
+    #      share staged order records and keeps per-order control flow wave-uniform.  The same workload with D distinct
+    #      days (replica r replays day r % D; vds_load_order_days, k_tick_rows' per-row variant) is timed next to it.
+    per_days = None
+    if rank == 0 and world == 1 and a.distinct_days > 1 and a.workload != "cfg5":
+        env2 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
+        env2.load_order_days(workloads.distinct_days(w, a.distinct_days))
+        env2.reset(init)
+        T2 = env2.T
+        env2.reset_again(); env2.run(T2)
+        torch.cuda.synchronize()
+        nd = max(2, min(a.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(nd):
+            env2.reset_again(); env2.run(T2)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        env2.sync()
+        per_days = {"distinct_days": a.distinct_days, "value": T2 * R * nd / dt2, "unit": "env-steps*replicas/s", "ms_per_step": dt2 / nd * 1e3,
+                    "steps": nd, "kernel": env2.main_kernel() + " (per-row order streams)",
+                    "note": "same city / vehicles / order count, replica r replays day r %% %d" % a.distinct_days}
+        env2.close()
+
     check = None
     if a.check and rank == 0:
         from oracle.oracle import Oracle
@@ -271,6 +295,8 @@ def main():
                                  "payload": "int64[8] aggregate counters per day"}
         if cpu_all is not None:
             out["cpu_baseline_all_cores"] = cpu_all
+        if per_days is not None:
+            out["per_replica_days"] = per_days
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))

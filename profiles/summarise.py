@@ -30,7 +30,11 @@ for name in ("fetch", "write", "sq", "sq2"):
     for n, row in g.iterrows():
         out[n] = {"mean_per_launch": float(row["mean"]), "launches": int(row["count"])}
     if len(k):
+        # as rocprofv3 prints them: on gfx950 VGPR_Count is HALF the allocated registers (the compiler's
+        # -Rpass-analysis=kernel-resource-usage says 72 for k_tick_rows<true, false>, this column 36) and
+        # LDS_Block_Size shows the static part only (the kernels use dynamic LDS: 18 KB per workgroup for k_tick_rows)
         out["_dispatch"] = {c: int(k[c].iloc[0]) for c in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size")}
-json.dump(out, open(os.path.join(dst, "pmc_%s.json" % kern), "w"), indent=1)
+import re
+json.dump(out, open(os.path.join(dst, "pmc_%s.json" % re.sub(r"[^A-Za-z0-9_]+", "_", kern).strip("_")), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_stats.csv")).read()[:1500])
 print(json.dumps(out, indent=1))

@@ -163,3 +163,88 @@ def run_case(seed, case, idle_cap=None):
         for k in ("idle_off", "idle_veh", "arr_off", "arr_veh", "arr_min"):
             np.testing.assert_array_equal(G[k], L[k], err_msg="seed %d replica %d %s" % (seed, r, k))
     env.close()
+
+
+def days_case(seed):
+    """random_case's city with 2-4 order days of different length / density (so different tick grids) and a random
+    replica -> day map; dispatches carry explicit arrival minutes and counted flags (vds_apply_dispatch_ex)."""
+    cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg = random_case(7000 + seed)
+    rng = np.random.default_rng(9000 + seed)
+    days = [(rel, pick, dele)]
+    for d in range(int(rng.integers(1, 4))):
+        O = int(rng.integers(2, 1200))
+        span = int(rng.integers(20, 1440))
+        r2 = (np.sort(rng.integers(0, span, size=O)) + int(rng.integers(0, 50))).astype(np.int32)
+        days.append((r2, rng.choice(valid_nodes, size=O).astype(np.int32), rng.choice(valid_nodes, size=O).astype(np.int32)))
+    cfg = dict(cfg, R=int(rng.integers(2, 9)))
+    rd = rng.integers(0, len(days), size=cfg["R"]).astype(np.int32)
+    return cost, n2c, nbr, V, days, rd, valid_nodes, cfg
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "40")))))
+def test_random_city_with_replica_days_matches_oracle(seed):
+    cost, n2c, nbr, V, days, rd, valid_nodes, cfg = days_case(seed)
+    off, idx = neighbors_to_csr(nbr)
+    R = cfg["R"]
+    rng = np.random.default_rng(2000 + seed)
+    init = rng.choice(valid_nodes, size=(R, V)).astype(np.int32) if V else np.zeros((R, 0), np.int32)
+    env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
+                             tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
+                             force_generic=cfg["force_generic"], idle_cap=max(64, V), ring_cap=max(16, V), far_cap=max(64, V))
+    env.load_order_days(days, rd)
+    env.reset(init)
+    oracles = []
+    for r in range(R):
+        d = days[rd[r]]
+        o = Oracle(cost, n2c, off, idx, cfg["depth"], cfg["neighbor"], d[0], d[1], d[2], V, tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"])
+        o.reset(init[r])
+        oracles.append(o)
+    Ts = [o.num_ticks for o in oracles]
+    assert env.T == max(Ts)
+    for t in range(env.T):
+        env.step()
+        live = [r for r in range(R) if t < Ts[r]]
+        for r in live:
+            oracles[r].begin_tick()
+        if cfg["dispatch"] and t % 3 == 1:
+            reps, cls, poss, tgts, arrs, cnts = [], [], [], [], [], []
+            for r in live:
+                o = oracles[r]
+                L = o.lists()
+                nidle = int(L["idle_off"][-1])
+                if nidle == 0:
+                    continue
+                pickn = rng.choice(nidle, size=min(nidle, int(rng.integers(1, 4))), replace=False)
+                vehs = L["idle_veh"][pickn]
+                tg = rng.choice(valid_nodes, size=vehs.size).astype(np.int32)
+                delay = rng.integers(0, 25, size=vehs.size)
+                loc = o.vehicles()["loc"][vehs]
+                arr = (o.now_min + cost[tg, loc] + delay).astype(np.int32)          # RoadCost(loc, target) = cost[target, loc]
+                counted = bool(rng.random() < 0.5)
+                for v, flat, tnode, am in zip(vehs, pickn, tg, arr):
+                    c = int(np.searchsorted(L["idle_off"], flat, side="right") - 1)
+                    reps.append(r); cls.append(c); poss.append(int(flat - L["idle_off"][c])); tgts.append(int(tnode)); arrs.append(int(am)); cnts.append(int(counted))
+                o.dispatch_at(vehs, tg, arrive_min=arr, counted=counted)
+            if reps:
+                env.apply_dispatch(reps, cls, poss, tgts, arrive_min=arrs, counted=cnts)
+        if t % 7 == 0:
+            ob = env.obs()
+            for r in live:
+                oo = oracles[r].obs()
+                np.testing.assert_array_equal(ob["supply"][r], oo["supply"])
+                np.testing.assert_array_equal(ob["idle_now"][r], oo["idle_now"])
+        env.advance()
+        for r in live:
+            oracles[r].end_tick()
+    got, cn = env.orders(), env.counters()
+    for r, o in enumerate(oracles):
+        exp, oc = o.orders(), o.counters()
+        n = exp["status"].size
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][r][:n], exp[k], err_msg="seed %d replica %d %s cfg %s" % (seed, r, k, cfg))
+        for i, k in enumerate(("order_num", "reject_num", "matched", "wait_sum", "dispatch_num", "dispatch_cost", "sum_order_value", "evals")):
+            assert cn[r, i] == oc[k], (seed, r, k, cfg)
+        L, G = o.lists(), env.lists(r)
+        for k in ("idle_off", "idle_veh", "arr_off", "arr_veh", "arr_min"):
+            np.testing.assert_array_equal(G[k], L[k], err_msg="seed %d replica %d %s" % (seed, r, k))
+    env.close()

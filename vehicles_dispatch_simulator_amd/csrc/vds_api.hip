@@ -629,6 +629,8 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         Tmax = std::max(Tmax, T); Oqmax = std::max(Oqmax, n_proc); Omax = std::max(Omax, O); mto = std::max(mto, day_mto);
         Ototal += O;
     }
+    Tmax = 0;                                   // the batch steps as long as its longest day that some replica replays
+    for (int r = 0; r < S.R; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
     S.now0 = h->days[0].now0; S.T = Tmax; S.Oq = Oqmax; h->O = Omax;
     S.n_days = n_days;
     S.max_tick_orders = mto;
