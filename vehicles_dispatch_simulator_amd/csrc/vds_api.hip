@@ -1126,7 +1126,9 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
         }
     }
     if (want_arr) {
-        const int np = (h->last_stepped + 1) & 1;   // parity holding far posts not yet drained
+        // parity holding far posts not yet drained; a replica whose day is over stopped at ITS last tick
+        const int last = std::min(h->last_stepped, h->days[h->replica_day[replica]].T - 1);
+        const int np = (last + 1) & 1;
         const int H = S.H;
         std::vector<int4> fl((size_t)C * S.fl_cap), inb((size_t)C * S.in_cap), ring((size_t)H * C * S.ring_cap);
         std::vector<int> rcnt((size_t)H * C);
@@ -1140,7 +1142,7 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
         for (int c = 0; c < C; ++c) {
             ent.clear();
             const int f = hdr[(size_t)c * HDR_WORDS + HDR_FL];
-            const int q = h->last_stepped < 0 ? 0 : hdr[(size_t)c * HDR_WORDS + HDR_INBOX0 + np];
+            const int q = last < 0 ? 0 : hdr[(size_t)c * HDR_WORDS + HDR_INBOX0 + np];
             for (int j = 0; j < f; ++j) ent.push_back(fl[(size_t)c * S.fl_cap + j]);
             for (int j = 0; j < q; ++j) ent.push_back(inb[(size_t)c * S.in_cap + j]);
             for (int sl = 0; sl < H; ++sl) {

@@ -2710,12 +2710,13 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
         if (r < S.R && c < S.C) {
             const size_t b = (size_t)c * S.R + r;
             const int *h = D.hdr + b * HDR_WORDS;
-            int infl = h[HDR_FL] + h[HDR_INBOX0 + ((t + 1) & 1)];
+            const int tr = S.n_days <= 1 ? t : min(t, day_view(S, r).T - 1);      // a replica whose day is over stopped at its own last tick
+            int infl = h[HDR_FL] + h[HDR_INBOX0 + ((tr + 1) & 1)];
             for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
             tile[0][ty][tx] = h[HDR_IDLE_PRE];
             tile[1][ty][tx] = h[HDR_IDLE];
             // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
-            tile[2][ty][tx] = (int)((unsigned)D.ring_cnt[(size_t)((t + 1) & (S.H - 1)) * RC + b] >> 16);
+            tile[2][ty][tx] = (int)((unsigned)D.ring_cnt[(size_t)((tr + 1) & (S.H - 1)) * RC + b] >> 16);
             tile[3][ty][tx] = h[HDR_ORDERS];
             tile[4][ty][tx] = infl;
         }
