@@ -237,23 +237,28 @@ def main():
     #      days (replica r replays day r % D; vds_load_order_days, k_tick_rows' per-row variant) is timed next to it.
     per_days = None
     if rank == 0 and world == 1 and a.distinct_days > 1 and a.workload != "cfg5":
-        env2 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
-        env2.load_order_days(workloads.distinct_days(w, a.distinct_days))
-        env2.reset(init)
-        T2 = env2.T
-        env2.reset_again(); env2.run(T2)
-        torch.cuda.synchronize()
-        nd = max(2, min(a.steps, 10))
-        t1 = time.perf_counter()
-        for _ in range(nd):
+        days = workloads.distinct_days(w, a.distinct_days)
+        per_days = {"distinct_days": a.distinct_days, "unit": "env-steps*replicas/s",
+                    "note": "same city / vehicles / order count; interleaved: replica r replays day r %% %d (every 16-lane row of a "
+                            "wavefront on another day: per-row order streams); blocked: day r // %d (the 16 replicas of a workgroup on "
+                            "one day: shared-day code, day looked up per workgroup)" % (a.distinct_days, max(1, R // a.distinct_days))}
+        for label, rmap in (("interleaved", np.arange(R) % a.distinct_days), ("blocked", np.minimum(np.arange(R) // max(1, R // a.distinct_days), a.distinct_days - 1))):
+            env2 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
+            env2.load_order_days(days, rmap.astype(np.int32))
+            env2.reset(init)
+            T2 = env2.T
             env2.reset_again(); env2.run(T2)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        env2.sync()
-        per_days = {"distinct_days": a.distinct_days, "value": T2 * R * nd / dt2, "unit": "env-steps*replicas/s", "ms_per_step": dt2 / nd * 1e3,
-                    "steps": nd, "kernel": env2.main_kernel() + " (per-row order streams)",
-                    "note": "same city / vehicles / order count, replica r replays day r %% %d" % a.distinct_days}
-        env2.close()
+            torch.cuda.synchronize()
+            nd = max(2, min(a.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(nd):
+                env2.reset_again(); env2.run(T2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            env2.sync()
+            per_days[label] = {"value": T2 * R * nd / dt2, "ms_per_step": dt2 / nd * 1e3, "steps": nd}
+            env2.close()
+        per_days["value"] = per_days["interleaved"]["value"]
 
     check = None
     if a.check and rank == 0:

@@ -167,3 +167,34 @@ def test_full_size_distinct_days_config2():
             np.testing.assert_array_equal(got[k][0][:n], exp[k], err_msg="replica %d %s" % (r, k))
         assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
     env.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_grid"])
+def test_days_in_blocks_of_sixteen_replicas_take_the_workgroup_uniform_path(name):
+    """A block-wise replica -> day map (every aligned group of 16 replicas on one day) runs the shared-day kernel code with
+    the day looked up once per workgroup (k_tick_rows day mode 1): every replica still equals its own oracle, incl. a
+    last, partially filled group and a day that ends early."""
+    g = load_golden(name)
+    V, N, R = int(g["V"]), int(g["N"]), 40
+    days = synth_days(g, 3, seed=333)
+    replica_day = np.array([0] * 16 + [2] * 16 + [1] * 8, dtype=np.int32)
+    valid = g["node2cluster"] >= 0
+    init = np.stack([synth.init_vehicle_nodes(random.Random(90 + r), N, V, valid) for r in range(R)]).astype(np.int32)
+    env = mk_env(g, R)
+    env.load_order_days(days, replica_day)
+    env.reset(init)
+    env.run(env.T)
+    env.sync()
+    got, cn = env.orders(), env.counters()
+    for r in range(R):
+        o = mk_oracle(g, days[replica_day[r]])
+        o.reset(init[r]); o.run_day()
+        exp, oc = o.orders(), o.counters()
+        n = exp["status"].size
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][r][:n], exp[k], err_msg="replica %d %s" % (r, k))
+        assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
+        L, G = o.lists(), env.lists(r)
+        for k in ("idle_off", "idle_veh", "arr_off", "arr_veh", "arr_min"):
+            np.testing.assert_array_equal(G[k], L[k], err_msg="replica %d %s" % (r, k))
+    env.close()

@@ -633,6 +633,9 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     for (int r = 0; r < S.R; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
     S.now0 = h->days[0].now0; S.T = Tmax; S.Oq = Oqmax; h->O = Omax;
     S.n_days = n_days;
+    S.chunk_days = n_days > 1 ? 1 : 0;
+    for (int r = 0; r < S.R && S.chunk_days; ++r)
+        if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
     S.max_tick_orders = mto;
     int rc;
     int *d;

@@ -639,7 +639,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             const int got = __builtin_amdgcn_ds_bpermute(src, (int)veh[s]);
             vid = (matched && (wpos % J) == s) ? got : vid;
         }
-        if (has && !(abl & 8)) D.out[(size_t)r * S.Oq + (PD ? q0 - qb : q0) + j] = make_int2(vid, matched ? wait : -1);
+        if (has && !(abl & 8)) D.out[(size_t)r * S.Oq + (q0 - qb) + j] = make_int2(vid, matched ? wait : -1);
         if (matched && !(abl & 1)) {
             if (abl & 96) {   // timing-only: bit5 = atomic without the entry store, bit6 = entry store without the atomic
                 const int rel = wait + rr.w;
@@ -778,11 +778,15 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #ifndef ROWS_PD_MIN_WAVES
 #define ROWS_PD_MIN_WAVES 6
 #endif
-template <bool U8, bool PD>
-__global__ __launch_bounds__(ROWS_WAVES * WAVE, PD ? ROWS_PD_MIN_WAVES : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+// DM (day mode): 0 = one order day shared by every replica; 1 = several days, but the 16 replicas of every workgroup replay
+// the same one (vds_load_order_days with a block-wise replica -> day map): the shared-day code with the day looked up once
+// per workgroup through scalar loads; 2 = per-row order streams (PD below).
+template <bool U8, int DM>
+__global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+    constexpr bool PD = DM == 2;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
-    if (!PD) S.n_days = 1;     // the shared-day instantiation: lets the compiler fold every per-day lookup of the inlined generic paths
+    if (DM == 0) S.n_days = 1; // the shared-day instantiation: lets the compiler fold every per-day lookup of the inlined generic paths
     // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
     // the ranked arrivals) | cost block
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
@@ -824,6 +828,15 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, PD ? ROWS_PD_MIN_WAVES : ROWS_MI
                 qb = dd.w;
             }
         }
+    } else if (DM == 1) {
+        // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
+        const int4 dd = S.replica_desc[min((int)((blockIdx.x % nchunks) * ROWS_WAVES * 4), S.R - 1)];
+        rowvalid = rowvalid && t < dd.z;             // (workgroup-uniform apart from r < R)
+        const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
+        q0 = bo[0]; k = bo[1] - q0;
+        now = dd.y + t * S.tick_minutes;
+        qb = dd.w;
+        if (t >= dd.z) { q0 = 0; k = 0; }
     } else {
         q0 = S.bkt_off[(size_t)t * S.C + c];
         k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
@@ -2872,14 +2885,17 @@ static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int chunks = (S.R + 15) / 16;
     const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
-    const bool pd = S.n_days > 1;
+    const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
+    const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
     if (S.fast_ok && S.u8_ok) {
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);      // byte blocks: a quarter of the LDS
-        if (pd) hipLaunchKernelGGL((k_tick_rows<true, true>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(li), st, S, D, t, li);
-        else hipLaunchKernelGGL((k_tick_rows<true, false>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(li), st, S, D, t, li);
+        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<true, 2>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        else hipLaunchKernelGGL((k_tick_rows<true, 0>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
     } else if (S.fast_ok) {
-        if (pd) hipLaunchKernelGGL((k_tick_rows<false, true>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        else hipLaunchKernelGGL((k_tick_rows<false, false>), dim3(S.C * rchunks), dim3(ROWS_WAVES * WAVE), rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<false, 2>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        else hipLaunchKernelGGL((k_tick_rows<false, 0>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
     }
     else hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * 4, st, S, D, t, lds_ints);
 }
