@@ -447,6 +447,20 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
             for (size_t i = 0; i < (size_t)N * N && fits; ++i) { fits = costp_host[i] >= 0 && costp_host[i] <= 255; c8[i] = (unsigned char)costp_host[i]; }
             if (fits) { unsigned char *d8; if ((rc = upload(h, &d8, c8))) return rc; S.cost8 = d8; }
             else S.u8_ok = 0;
+            S.lbc = nullptr;
+            if (fits && any_seq && (long long)N * C <= (256ll << 20)) {
+                // per (pickup node, cluster): the cheapest way from any node of the cluster - prunes the neighbour search
+                std::vector<unsigned char> lb((size_t)N * C, 255);
+                for (int pn = 0; pn < N; ++pn) {
+                    const unsigned char *row = c8.data() + (size_t)pn * N;
+                    for (int c = 0; c < C; ++c) {
+                        unsigned char m = 255;
+                        for (int col = h->cl_off[c]; col < h->cl_off[c + 1]; ++col) m = std::min(m, row[col]);
+                        lb[(size_t)pn * C + c] = m;
+                    }
+                }
+                unsigned char *dlb; if ((rc = upload(h, &dlb, lb))) return rc; S.lbc = dlb;
+            }
         }
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
     }

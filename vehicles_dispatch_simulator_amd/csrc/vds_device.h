@@ -98,6 +98,8 @@ struct Static {
     const unsigned char *blk8;       // the same cost blocks as bytes (16-byte aligned starts) when every cost is <= 255
     const unsigned char *cost8;      // byte copy of `cost` (same column order) under the same condition
     int u8_ok;
+    const unsigned char *lbc;        // [N][C] min over the nodes n of cluster c of cost8[p*N + col(n)]: lower bound of RoadCost(vehicle in c, pickup p)
+                                     // (neighbour-search mode with byte costs; nullptr otherwise)
     const int *dfs_off;              // [C+1]
     const int *dfs_seq;              // visit sequence excluding the start cluster
     const int4 *so_rec;              // [Oq]

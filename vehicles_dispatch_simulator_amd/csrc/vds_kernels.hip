@@ -1415,6 +1415,9 @@ struct RowRank<0> {
 #endif
 #define DEAD 0xFFFF
 #define CAPABLE (1 << 30)
+#ifndef PRUNE_DELTA
+#define PRUNE_DELTA 2                       // first scan pass: candidate clusters whose cost bound is within this of the smallest
+#endif
 #ifndef SLOTS
 #define SLOTS 12                            // candidates per lane of an 8-lane group held in registers
 #endif
@@ -1788,6 +1791,10 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
             }
             wave_fence();
         }
+        // lower bound of the cost from any node of candidate cluster cj to the dry order's pickup node (byte costs only):
+        // lets the scan skip clusters that cannot beat the best vehicle found in the most promising ones
+        int lbj = 0;
+        if (U8 && S.lbc != nullptr && LB != IMAX && s0 + wave + lane * REPL_WAVES < s1) lbj = (int)S.lbc[(size_t)pnode * C + cj];
         __syncthreads();
         PROF_STAMP(3);
         if (LB == IMAX) break;
@@ -1808,6 +1815,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
             if (jb > 0) {                               // visit sequences longer than 64 clusters per wavefront
                 const int sx = s0 + wave + (jb + lane) * REPL_WAVES;
                 cj = sx < s1 ? S.dfs_seq[sx] : 0;
+                lbj = (U8 && S.lbc != nullptr && sx < s1) ? (int)S.lbc[(size_t)pnode * C + cj] : 0;
             }
             const int nj = min(WAVE, (s1 - s0 - wave - jb * REPL_WAVES + REPL_WAVES - 1) / REPL_WAVES);
             int mj = 0, moj = 0, m0j = 0;
@@ -1824,8 +1832,21 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
             // slots = (cluster j of this wavefront, 64-entry chunk b of its list), walked in (j, b) order, eight cost
             // gathers in flight per lane.  key = cost << 16 | j << 9 | b: with the lane as the last tie-break this
             // is (cost, visit position, list position)
-            unsigned long long live = ballot(m0j > 0);
+            // Two passes over the candidate clusters: first those whose cost bound is within PRUNE_DELTA of the smallest
+            // bound - the nearest vehicle is almost always there -, then only the clusters whose bound does not exceed the
+            // best cost found (<=: an equal cost in an earlier visit position still wins).  A skipped cluster holds no
+            // vehicle that could be the first strict minimum, so the result is unchanged; evaluations were counted above.
+            const unsigned long long cand = ballot(m0j > 0);
+            const int lbmin = wave_min_i32(m0j > 0 ? lbj : IMAX);
+            unsigned long long live = ballot(m0j > 0 && lbj <= lbmin + PRUNE_DELTA);
+            const unsigned long long first_pass = live;
             int b = 0, best = IMAX;
+            for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                const int bc = wave_min_i32(best) >> 16;            // 32767 when nothing was found
+                live = cand & ~first_pass & ballot(lbj <= bc);
+                b = 0;
+            }
             while (live != 0) {
                 // branch-free in three passes, so that the eight LDS reads and then the eight gathers are issued
                 // back to back instead of one dependent chain per slot (integer flags and byte offsets on purpose:
@@ -1853,6 +1874,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     best = min(best, in[k] ? (cst[k] << 16) | seq[k] : IMAX);
+            }
             }
             // this batch's winner in global terms
             const int wbest = wave_min_i32(best);
