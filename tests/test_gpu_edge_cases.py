@@ -9,6 +9,7 @@ import pytest
 from helpers import load_golden
 from oracle.oracle import Oracle
 from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth
+from vehicles_dispatch_simulator_amd import _lib as _lib_mod
 
 pytestmark = pytest.mark.gpu
 
@@ -191,3 +192,47 @@ def test_another_day_on_the_same_handle():
             first = got["vehicle"].copy()
     np.testing.assert_array_equal(got["vehicle"], first)      # day 1 again after day 2: identical
     env.close()
+
+
+def test_round2_entry_points_refuse_bad_arguments():
+    """vds_load_order_days / vds_load_orders_strided / vds_apply_dispatch_ex / vds_set_idle_cap / vds_cluster_cost_sums:
+    status code + message, nothing aborts, the handle stays usable."""
+    import ctypes as C
+    g = load_golden("tiny_kmeans")
+    R, V, N = 4, int(g["V"]), int(g["N"])
+    day = (g["o_release_min"], g["o_pickup"], g["o_delivery"])
+    env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=V)
+    with pytest.raises(Exception, match="load static tables and orders first"):
+        env.set_idle_cap(256)
+    with pytest.raises(Exception, match="mapped to day"):
+        env.load_order_days([day, day], replica_day=[0, 1, 2, 0])
+    with pytest.raises(Exception, match="replica_day needs"):
+        env.load_order_days([day, day], replica_day=[0, 1])
+    with pytest.raises(Exception, match="no orders"):
+        env.load_order_days([day, (day[0][:0], day[1][:0], day[2][:0])])
+    bad = (day[0], day[1].copy(), day[2]); bad[1][5] = N + 3
+    with pytest.raises(Exception, match="node outside"):
+        env.load_order_days([day, bad])
+    with pytest.raises(Exception, match="replica_stride"):
+        env.load_orders_strided(np.tile(day[0], R), np.tile(day[1], R), np.tile(day[2], R), day[0].size, 5)
+    with pytest.raises(Exception, match="call vds_reset first|vds_reset"):
+        env.load_order_days([day, day]); env.apply_dispatch([0], [0], [0], [0], arrive_min=[5], counted=[0])
+    # the handle is still usable
+    init = np.stack([synth.init_vehicle_nodes(random.Random(3 + r), N, V) for r in range(R)])
+    env.reset(init)
+    env.step()
+    with pytest.raises(Exception, match="target node"):
+        env.apply_dispatch([0], [0], [0], [N + 1], arrive_min=[5], counted=[1])
+    with pytest.raises(Exception, match="bad capacity"):
+        env.set_idle_cap(0)
+    env.advance()
+    env.run(env.T - 1); env.sync()
+    assert env.counters()[0, 0] == day[0].size - 1
+    env.close()
+    lib = _lib_mod.load()
+    sums = np.zeros((3, 3), np.int64)
+    cost = np.zeros((4, 4), np.int32); n2c = np.zeros(4, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.vds_cluster_cost_sums(0, None, 4, p(n2c), 3, p(sums), None) == -1
+    assert lib.vds_cluster_cost_sums(99, p(cost), 4, p(n2c), 3, p(sums), None) == -1
+    assert b"bad device" in lib.vds_cluster_cost_sums_error()
