@@ -1919,20 +1919,39 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
     int *rc_l = ids_l;
     for (int i = threadIdx.x; i < RCNT * C; i += REPL_THREADS) rc_l[i] = 0;
     __syncthreads();
-    for (int q = tq0 + (int)threadIdx.x; q < tq1; q += REPL_THREADS) {
-        const int4 rec = S.so_rec[q];
-        const int2 pr = out_r[q];
-        int *cl = rc_l + (int)((unsigned)rec.z >> 16) * RCNT;
-        atomicAdd(&cl[CNT_ORDERS], 1);
-        if (pr.x == -1) {
-            atomicAdd(&cl[CNT_REJECTS], 1);
-        } else {
-            const int vc = (int)((unsigned)pr.x >> 16), vpos = pr.x & 0xFFFF;
-            const int veh = (int)D.idle[((size_t)vc * S.R + r) * S.idle_cap + vpos].x;
-            out_r[q] = make_int2(veh, pr.y);
-            post_arrival(S, D, rec.z & 0xFFFF, r, t, now, veh, rec.x, now + pr.y + rec.w, 0, (int)((unsigned)rec.y >> 16));
-            atomicAdd(&cl[CNT_WAIT], pr.y);
-            atomicAdd(&cl[CNT_VALUE], rec.w);
+    for (int qq = tq0 + (int)threadIdx.x; qq < tq1; qq += 3 * REPL_THREADS) {
+        // three orders per thread at a time: their records, then their vehicle-id gathers, then their posts travel together
+        int4 rec[3];
+        int2 pr[3];
+        int veh[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = qq + u * REPL_THREADS;
+            rec[u] = make_int4(0, 0, 0, 0); pr[u] = make_int2(-1, -1);
+            if (q < tq1) { rec[u] = S.so_rec[q]; pr[u] = out_r[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            veh[u] = -1;
+            if (pr[u].x != -1) {
+                const int vc = (int)((unsigned)pr[u].x >> 16), vpos = pr[u].x & 0xFFFF;
+                veh[u] = (int)D.idle[((size_t)vc * S.R + r) * S.idle_cap + vpos].x;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = qq + u * REPL_THREADS;
+            if (q >= tq1) continue;
+            int *cl = rc_l + (int)((unsigned)rec[u].z >> 16) * RCNT;
+            atomicAdd(&cl[CNT_ORDERS], 1);
+            if (pr[u].x == -1) {
+                atomicAdd(&cl[CNT_REJECTS], 1);
+            } else {
+                out_r[q] = make_int2(veh[u], pr[u].y);
+                post_arrival(S, D, rec[u].z & 0xFFFF, r, t, now, veh[u], rec[u].x, now + pr[u].y + rec[u].w, 0, (int)((unsigned)rec[u].y >> 16));
+                atomicAdd(&cl[CNT_WAIT], pr[u].y);
+                atomicAdd(&cl[CNT_VALUE], rec[u].w);
+            }
         }
     }
     __syncthreads();
