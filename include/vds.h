@@ -110,10 +110,12 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
 /* Per-replica order days.  In the reference one Simulation is one city with its own self.Orders (:325-342); a batch of R
  * replicas can therefore replay R different days.  n_days days are passed back to back: day d owns elements
  * [day_off[d], day_off[d+1]) of release_min / pickup / delivery (each day sorted by release like self.Orders, ids = index
- * inside the day); replica r replays day replica_day[r] (NULL: r % n_days).  Every day has its own tick grid (:1037-1040):
+ * inside the day); replica r replays day replica_day[r] (NULL: contiguous blocks, day r * n_days / R).  Every day has its own tick grid (:1037-1040):
  * vds_num_ticks reports the longest; a replica whose day is over is left untouched by further vds_step calls, exactly as
  * if its SimCity loop had ended (:1048).  vds_read_orders rows are strided by the longest day.  n_days == 1 is
- * vds_load_orders.  With more than one day the fast kernel runs its per-row order-stream variant (k_tick_rows<.., PD>). */
+ * vds_load_orders.  With more than one day the fast kernel (k_tick_rows) runs the shared-day code with one day lookup per
+ * workgroup when every aligned group of 16 replicas replays one day (e.g. the default block map with R / n_days a multiple
+ * of 16; ~0.9x the shared-day rate), otherwise its per-row order-stream variant (~0.6x). */
 int vds_load_order_days(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min,
                         const int32_t *pickup, const int32_t *delivery, const int32_t *replica_day);
 

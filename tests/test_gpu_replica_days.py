@@ -152,7 +152,7 @@ def test_full_size_distinct_days_config2():
     days = workloads.distinct_days(w, D)
     init = w.vehicle_nodes(R)
     env = w.make_env(R, load=False)
-    env.load_order_days(days)
+    env.load_order_days(days, np.arange(R) % D)         # interleaved: every row of a wavefront on another day
     env.reset(init)
     env.run(env.T)
     env.sync()
@@ -166,6 +166,21 @@ def test_full_size_distinct_days_config2():
         for k in ("status", "vehicle", "wait"):
             np.testing.assert_array_equal(got[k][0][:n], exp[k], err_msg="replica %d %s" % (r, k))
         assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
+    # the default map (contiguous blocks of R / D = 128 replicas per day: one day per workgroup): same days, other replicas
+    env.load_order_days(days)
+    env.reset(init)
+    env.run(env.T)
+    env.sync()
+    cn = env.counters()
+    for r in (0, 127, 128, 600, 1023):
+        d = days[r * D // R]
+        o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, d[0], d[1], d[2], w.vehicles)
+        o.reset(init[r]); o.run_day()
+        exp, oc, got = o.orders(), o.counters(), env.orders(r, 1)
+        n = exp["status"].size
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][0][:n], exp[k], err_msg="block map: replica %d %s" % (r, k))
+        assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["evals"])
     env.close()
 
 

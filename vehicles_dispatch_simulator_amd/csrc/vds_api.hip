@@ -557,7 +557,9 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     const int N = S.N, C = S.C, tick = S.tick_minutes;
     h->replica_day.assign(S.R, 0);
     for (int r = 0; r < S.R; ++r) {
-        const int d = replica_day ? replica_day[r] : r % n_days;
+        // default map: contiguous blocks of replicas per day - when the blocks are multiples of 16 replicas every workgroup of
+        // the fast kernel sees one day (day mode 1, the shared-day code); an interleaved map costs the per-row variant
+        const int d = replica_day ? replica_day[r] : (int)((long long)r * n_days / S.R);
         if (d < 0 || d >= n_days) return fail(h, VDS_EINVAL, "vds_load_order_days: replica %d is mapped to day %d of %d", r, d, n_days);
         h->replica_day[r] = d;
     }

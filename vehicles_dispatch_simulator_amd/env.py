@@ -99,7 +99,8 @@ class BatchedDispatchEnv:
 
     def load_order_days(self, days, replica_day=None):
         """Per-replica order days (``vds_load_order_days``): ``days`` is a sequence of ``(release_min, pickup,
-        delivery)`` triples, replica ``r`` replays ``days[replica_day[r]]`` (default ``r % len(days)``) - one
+        delivery)`` triples, replica ``r`` replays ``days[replica_day[r]]`` (default: contiguous blocks, ``r * len(days) // R``;
+        keep every aligned group of 16 replicas on one day for the fast path) - one
         ``Simulation`` = one city = its own ``Orders`` in the reference (``simulator.py:325-342``).  ``T`` is the
         longest day; a replica whose day is over stands still."""
         rel = np.concatenate([_i32(d[0]).reshape(-1) for d in days])
