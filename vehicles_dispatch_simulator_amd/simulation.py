@@ -535,7 +535,8 @@ class Simulation(object):
         cl, ps, tg, am, ct, seen = [], [], [], [], [], set()
         # one action list in hook-body order (it is the insertion order of the targets' arrival dicts): DispatchVehicle
         # calls are counted by the engine and timed RealExpTime + RoadCost; container edits carry the body's own time
-        todo = sorted([(q, v, t, -1, 1) for q, v, t in self._pending] + [(q, v, t, m, 0) for q, v, t, m in edits])
+        todo = sorted([(q, v, t, None, 1) for q, v, t in self._pending] + [(q, v, t, m, 0) for q, v, t, m in edits],
+                      key=lambda a: a[0])
         self._pending = []
         for _, v, t, minute, counted in todo:
             if v not in pos_of:
@@ -545,10 +546,11 @@ class Simulation(object):
             seen.add(v)
             cl.append(pos_of[v][0]); ps.append(pos_of[v][1]); tg.append(t); am.append(minute); ct.append(counted)
         if edits:
-            # DispatchVehicle entries carry -1: the device computes RealExpTime + RoadCost for them
+            # DispatchVehicle entries carry None: RealExpTime + RoadCost(LocationNode, target), as the engine would compute
+            # (minutes on the day clock may be negative in the first slot: RealExpTime starts one slot before the first order)
             now = self.env.clock[1]
             W = self._world
-            am = [m if m >= 0 else now + int(W.cost[t, int(L["idle_node"][L["idle_off"][c] + p])]) for m, t, c, p in zip(am, tg, cl, ps)]
+            am = [m if m is not None else now + int(W.cost[t, int(L["idle_node"][L["idle_off"][c] + p])]) for m, t, c, p in zip(am, tg, cl, ps)]
             self.env.apply_dispatch([self.Replica] * len(cl), cl, ps, tg, arrive_min=am, counted=ct)
         else:
             self.env.apply_dispatch([self.Replica] * len(cl), cl, ps, tg)
