@@ -1,5 +1,5 @@
 """Full-scale parity: EVERY replica of the bench workload against the CPU oracle (per-order status / vehicle / wait
-and counters, bit-exact).   python profiles/full_check.py [cfg2|cfg4] [replicas]"""
+and counters, bit-exact).   python profiles/full_check.py [cfg2|cfg4] [replicas] [distinct days] [interleaved|blocked]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -9,21 +9,32 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 w = workloads.didi_day("cfg2") if wl == "cfg2" else workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
 init = w.vehicle_nodes(R)
-env = w.make_env(R)
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+mapping = sys.argv[4] if len(sys.argv) > 4 else "interleaved"
+days = workloads.distinct_days(w, D)
+rd = (np.arange(R) % D) if mapping == "interleaved" else (np.arange(R) * D // R)
+if D > 1:
+    env = w.make_env(R, load=False)
+    env.load_order_days(days, rd.astype(np.int32))
+else:
+    env = w.make_env(R)
 env.reset(init)
 env.run(env.T)
 cn = env.counters()
-o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, w.release_min, w.pickup, w.delivery, w.vehicles)
+oracles = [Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, d[0], d[1], d[2], w.vehicles) for d in days]
 t0 = time.time()
 bad = 0
 for r0 in range(0, R, 64):
     got = env.orders(r0, min(64, R - r0))
     for i in range(got["status"].shape[0]):
         r = r0 + i
+        o = oracles[int(rd[r])]
         o.reset(init[r]); o.run_day()
         exp, oc = o.orders(), o.counters()
-        ok = all(np.array_equal(got[k][i], exp[k]) for k in ("status", "vehicle", "wait")) and \
+        n = exp["status"].size
+        ok = all(np.array_equal(got[k][i][:n], exp[k]) for k in ("status", "vehicle", "wait")) and \
             (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
         bad += 0 if ok else 1
-print("%s: %d replicas checked against the oracle in %.0f s, mismatching replicas: %d" % (wl, R, time.time() - t0, bad))
+print("%s (%d order day%s%s, %s): %d replicas checked against the oracle in %.0f s, mismatching replicas: %d" % (
+    wl, D, "s" if D > 1 else "", ", %s map" % mapping if D > 1 else "", env.main_kernel(), R, time.time() - t0, bad))
 assert bad == 0
