@@ -1695,6 +1695,9 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                             amask |= (col[u] != DEAD ? 1u : 0u) << u;
                         }
                     }
+#ifdef R2DIAG
+                    PROF_STAMP_NW(3);
+#endif
                     while (ballot(act) != 0) {
                         // up to OB pending orders of the bucket: their cost gathers are in flight together
                         int idw[OB], cst[OB][SLOTS];
@@ -1742,6 +1745,9 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                         }
                         if (act) act = qc < qe && (ids_l[qc - tq0] & ID_MASK) < LB;
                     }
+#ifdef R2DIAG
+                    PROF_STAMP_NW(1);
+#endif
                 }
                 act = act_all && longlist;
                 if (ballot(act) != 0) {
