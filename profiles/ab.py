@@ -20,7 +20,7 @@ name, R, days, distinct = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(s
 w = workloads.didi_day("cfg2") if name == "cfg2" else (workloads.didi_day("cfg4", neighbor=True, service_m=2000.0) if name == "cfg4" else workloads.stress())
 env = w.make_env(R, load=(distinct <= 1)) if distinct <= 1 else w.make_env(R, load=False)
 if distinct > 1:
-    env.load_order_days(workloads.distinct_days(w, distinct), list(range(R)) if distinct >= R else [r % distinct for r in range(R)])
+    env.load_order_days(workloads.distinct_days(w, distinct), list(range(R)) if distinct >= R else [r %% distinct for r in range(R)])
 env.reset(w.vehicle_nodes(R))
 T = env.T
 for _ in range(2):
