@@ -73,7 +73,8 @@ typedef struct vds_config {
     int32_t far_cap;                  /* slots per (replica, cluster) far table; 0 = auto */
     int32_t force_generic;            /* testing: 1 = generic one-wavefront-per-bucket / serial neighbour-search kernels,
                                          2 = first-generation neighbour-search kernel (k_tick_replica), 3 = second
-                                         generation (k_tick_replica2, lower-bound rounds: what 0 selects), 4 = third
+                                         generation (k_tick_replica2, lower-bound rounds: what 0 falls back to when the hybrid tick's
+                                         preconditions do not hold), 4 = third
                                          generation (k_tick_replica3: own-cluster pass once + dry-order walk; exact,
                                          measured slower at configs[3]); 0 = fastest */
 } vds_config;
@@ -289,8 +290,8 @@ int vds_cluster_cost_sums(int32_t device, const int32_t *cost, int32_t N, const 
 const char *vds_cluster_cost_sums_error(void);
 
 /* Name of the kernel that vds_step launches for the main part of a tick with the handle's current tables (the one
- * vds_profile_enable brackets with events): "k_tick_rows", "k_tick", "k_tick_replica3", "k_tick_replica2", "k_tick_replica" or
- * "k_match_dfs".  Valid after vds_load_orders; static string. */
+ * vds_profile_enable brackets with events): "k_tick_rows", "k_tick", "k_dfs_hybrid" (k_tick_rows in stamp mode + k_dfs_walk), "k_tick_replica3",
+ * "k_tick_replica2", "k_tick_replica" or "k_match_dfs".  Valid after vds_load_orders; static string. */
 const char *vds_main_kernel(const vds_handle *h);
 
 /* Library/ABI version: (major << 16) | minor. */

@@ -47,7 +47,7 @@ def random_case(seed):
     dele = rng.choice(valid_nodes, size=O).astype(np.int32)
     cfg = dict(neighbor=bool(rng.random() < 0.5), depth=int(rng.integers(-1, 4)),
                threshold=int(rng.choice([600_000_000_000, 600_000_000_000, 40, 8, 0])),
-               ring_ticks=int(rng.choice([32, 32, 8, 2])), force_generic=int(rng.choice([0, 0, 0, 1, 2, 4])),
+               ring_ticks=int(rng.choice([32, 32, 8, 2])), force_generic=int(rng.choice([0, 0, 0, 1, 2, 3, 4])),
                tick=int(rng.choice([10, 10, 5, 15])), R=int(rng.integers(1, 9)), dispatch=bool(rng.random() < 0.4))
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 
@@ -79,7 +79,7 @@ def medium_case(seed):
         dele[sel] = rng.choice(hot_nodes, size=int(sel.sum()))
     cfg = dict(neighbor=bool(rng.random() < 0.8), depth=int(rng.integers(0, 5)),
                threshold=int(rng.choice([600_000_000_000, 600_000_000_000, 30])),
-               ring_ticks=int(rng.choice([32, 32, 4])), force_generic=int(rng.choice([0, 0, 0, 2, 4])),
+               ring_ticks=int(rng.choice([32, 32, 4])), force_generic=int(rng.choice([0, 0, 0, 2, 3, 4])),
                tick=int(rng.choice([10, 10, 5])), R=int(rng.integers(1, 4)), dispatch=bool(rng.random() < 0.3))
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 

@@ -149,6 +149,7 @@ MODES = {
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
     "dfs_v1": {"force_generic": 2},          # neighbour search by the first-generation kernel (lists edited in place)
+    "dfs_v2": {"force_generic": 3},          # ... by the second-generation kernel (lower-bound rounds); default = hybrid tick
     "dfs_v3": {"force_generic": 4},          # ... by the third-generation kernel (own-cluster pass once + dry-order walk); default = second
 }
 

@@ -15,7 +15,7 @@ from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth, workloads
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"fast": dict(), "generic": dict(force_generic=1), "gen1": dict(force_generic=2), "gen3": dict(force_generic=4)}
+MODES = {"fast": dict(), "generic": dict(force_generic=1), "gen1": dict(force_generic=2), "gen2": dict(force_generic=3), "gen3": dict(force_generic=4)}
 
 
 def synth_days(g, n_days, seed):
@@ -48,7 +48,7 @@ def mk_oracle(g, day):
 
 
 @pytest.mark.parametrize("name,mode", [("tiny_kmeans", "fast"), ("tiny_kmeans", "generic"), ("tiny_grid", "fast"),
-                                       ("tiny_kmeans_dfs2", "fast"), ("tiny_kmeans_dfs2", "gen1"), ("tiny_kmeans_dfs2", "gen3"), ("tiny_kmeans_dfs2", "generic"),
+                                       ("tiny_kmeans_dfs2", "fast"), ("tiny_kmeans_dfs2", "gen1"), ("tiny_kmeans_dfs2", "gen2"), ("tiny_kmeans_dfs2", "gen3"), ("tiny_kmeans_dfs2", "generic"),
                                        ("tiny_window6", "fast"), ("tiny_empty_clusters_dfs2", "fast")])
 def test_every_replica_replays_its_own_day(name, mode):
     g = load_golden(name)

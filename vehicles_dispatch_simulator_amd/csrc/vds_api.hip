@@ -21,6 +21,8 @@ void launch_match_dfs(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
+void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
+size_t dfs_walk_lds(const Static &);
 size_t replica3_lds(const Static &);
 int replica3_prepare();
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
@@ -57,6 +59,7 @@ struct vds_handle {
     bool dfs_mode = false;
     bool dfs2_ok = false;   // k_tick_replica2 preconditions hold (see vds_kernels.hip)
     bool dfs3_ok = false;   // k_tick_replica3 preconditions hold
+    bool hybrid_ok = false; // hybrid neighbour-search tick (k_tick_rows in stamp mode + k_dfs_walk) preconditions hold
     long long blk_ints = 0; // total size of the per-cluster cost blocks
     int cost_min = 0, cost_max = 0;
     int depth_limit = 0;
@@ -216,6 +219,7 @@ void vds_config_init(vds_config *cfg) {
 const char *vds_main_kernel(const vds_handle *h) {
     if (!h || !h->have_orders) return "";
     if (!h->dfs_mode) return h->S.fast_ok ? "k_tick_rows" : "k_tick";
+    if (h->hybrid_ok && h->cfg.force_generic == 0) return "k_dfs_hybrid";
     if (h->S.C <= 3072 && h->cfg.force_generic != 1) {
         if (h->dfs3_ok && h->cfg.force_generic == 4) return "k_tick_replica3";
         return (h->dfs2_ok && (h->cfg.force_generic == 0 || h->cfg.force_generic == 3 || h->cfg.force_generic == 4)) ? "k_tick_replica2" : "k_tick_replica";
@@ -663,6 +667,19 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;
     if ((rc = upload(h, &d, so_pnode))) return rc; S.so_pnode = d;
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
+    {   // rank of every sorted position inside its slot (tick_off / ord_q hold absolute positions)
+        std::vector<int> so_rank(so_rec.size(), 0);
+        size_t tbase = 0;
+        for (int dd = 0; dd < n_days; ++dd) {
+            const DayDesc &de = ddesc[dd];
+            for (int t = 0; t < de.T; ++t) {
+                const int a = tick_off[de.tick_base + t], b = tick_off[de.tick_base + t + 1];
+                for (int i = a; i < b; ++i) so_rank[ord_q[i]] = i - a;
+            }
+        }
+        (void)tbase;
+        if ((rc = upload(h, &d, so_rank))) return rc; S.so_rank = d;
+    }
     { DayDesc *dd; if ((rc = upload(h, &dd, ddesc))) return rc; S.day = dd; }
     if ((rc = upload(h, &d, h->replica_day))) return rc; S.replica_day = d;
     {
@@ -682,6 +699,11 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                      lds2 <= 64 * 1024;
         // k_tick_replica3: the same packing limits, 16-bit ranks inside a slot, and its (bigger) LDS footprint; byte costs
         // need the byte copy of the matrix for the staged row
+        // hybrid tick: the fast kernel's preconditions (packed keys, no live pickup window, every cost block in LDS), one
+        // order day per workgroup, 16-bit ranks / positions / columns, the walk's LDS footprint
+        h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
+                       (Z.n_days <= 1 || Z.chunk_days) && Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
+                       Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 65535 && dfs_walk_lds(Z) + 1024 <= 64 * 1024;
         h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
                      replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }
@@ -760,6 +782,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     h->idle_cap_grown = cap;
     // k_tick_replica2 addresses list positions with 15 bits
     if (cap > 32767) { h->dfs2_ok = false; h->dfs3_ok = false; }
+    if (cap > 65535) h->hybrid_ok = false;
     return VDS_OK;
 }
 
@@ -845,6 +868,17 @@ static int step_impl(vds_handle *h) {
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
         // the fast kernel only defers buckets whose cluster cost block does not fit LDS
         if (!h->S.fast_ok || h->S.max_nc * h->S.max_nc > h->lds_ints) launch_tick_work(h->S, h->D, h->t, h->stream);
+    } else if (h->hybrid_ok && h->cfg.force_generic == 0) {
+        // neighbour search, hybrid: Update + own-cluster matching cluster-major (k_tick_rows, stamp mode), then one
+        // workgroup per replica walks the dry orders and commits the slot (k_dfs_walk)
+        hipEvent_t a = nullptr, b = nullptr;
+        if (h->profiling) {
+            a = next_event(h); b = next_event(h);
+            if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
+            HIPCHK(h, hipEventRecord(a, h->stream));
+        }
+        launch_tick_hybrid(h->S, h->D, h->t, h->lds_ints, h->stream);
+        if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
     } else if (h->S.C <= 3072 && h->cfg.force_generic != 1) {   // 11 ints of LDS per cluster
         hipEvent_t a = nullptr, b = nullptr;
         if (h->profiling) {

@@ -328,13 +328,18 @@ __device__ int drain_ring(const Static &S, const State &D, size_t b, int t, int 
 // ---------------------------------------------------------------------------------------
 // Generic match phase of one bucket (own-cluster scan, :924-965).  Lane l holds idle positions
 // l*J .. l*J+J-1, so "lowest position" == "lowest lane, then lowest slot".
-template <int J, bool LDSBLK, typename CT = int>
+// ST: stamp mode (see rows_match) - taken entries stay in the list and get rank + 1 into the high half of their node word,
+// results are {cl << 16 | list position, wait}, nothing is posted and m keeps the list length.
+template <int J, bool LDSBLK, typename CT = int, bool ST = false>
 __device__ void match_bucket(const Static &S, const State &D, int r, int t, int now, int &m, int q0, int k,
                              const CT *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
-                             long long &evals, int &rejects, unsigned short *mir = nullptr) {
+                             long long &evals, int &rejects, unsigned short *mir = nullptr, int cl = 0) {
     const int lane = lane_id();
     unsigned veh[J], loc[J];
     bool av[J];
+    unsigned stp[J];
+#pragma unroll
+    for (int s = 0; s < J; ++s) stp[s] = 0u;
 #pragma unroll
     for (int s = 0; s < J; ++s) {
         int pos = lane * J + s;
@@ -348,6 +353,7 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
     for (int base = 0; base < k; base += WAVE) {
         const int kk = min(WAVE, k - base);
         int4 rec = lane < kk ? S.so_rec[q0 + base + lane] : make_int4(0, 0, 0, 0);
+        const int rk = (ST && lane < kk) ? S.so_rank[q0 + base + lane] : 0;
         int res_veh = -1, res_wait = -1;
         for (int j = 0; j < kk; ++j) {
             evals += navail;
@@ -376,7 +382,12 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
 #pragma unroll
                 for (int s = 0; s < J; ++s) av[s] = (s == ws) ? false : av[s];
             }
-            if (lane == j) { res_veh = wveh; res_wait = minc; }
+            if (ST) {
+                const unsigned mark = (unsigned)rdlane(rk, j) + 1u;
+#pragma unroll
+                for (int s = 0; s < J; ++s) stp[s] = (lane == w && s == ws) ? mark : stp[s];
+            }
+            if (lane == j) { res_veh = ST ? (int)(((unsigned)cl << 16) | (unsigned)(w * J + ws)) : wveh; res_wait = minc; }
             wait_sum += minc;                                      // :952
             value_sum += rdlane(rec.w, j);
             navail--;
@@ -384,9 +395,15 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
         }
         if (lane < kk) {
             out_row(S, D, r)[q0 + base + lane] = make_int2(res_veh, res_wait);
-            if (res_veh >= 0)   // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery)
+            if (!ST && res_veh >= 0)   // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery)
                 post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
+    }
+    if (ST) {
+#pragma unroll
+        for (int s = 0; s < J; ++s)
+            if (stp[s] != 0u) idle[lane * J + s] = make_uint2(veh[s], loc[s] | (stp[s] << 16));
+        return;
     }
     if (changed) {                                                 // :963 IdleVehicles.remove, order preserved
         int before = 0;
@@ -417,11 +434,11 @@ __device__ __forceinline__ void add_counters(long long *cnt, long long k, long l
 
 __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t, int now, int &m, int qs, int n,
                                   const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
-                                  long long &evals, int &rejects, unsigned short *mir = nullptr);
+                                  long long &evals, int &rejects, unsigned short *mir = nullptr, int stamp_cl = -1);
 
 // Whole generic tick of one bucket by one wavefront.  MAXJ = 4: tables up to 256 idle entries are
 // matched here, bigger ones are pushed to the worklist (match only).  MAXJ = 16: everything here.
-template <bool DO_MATCH, bool LDSBLK, int MAXJ, bool ONLY_J4 = false, typename CT = int>
+template <bool DO_MATCH, bool LDSBLK, int MAXJ, bool ONLY_J4 = false, typename CT = int, bool ST = false>
 __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t, const CT *blk, int nc) {
     const int lane = lane_id();
     const int p = t & 1;
@@ -450,7 +467,7 @@ __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t
     bool deferred = false;
     if (DO_MATCH && k > 0) {
         if (MAXJ < 16 && m > 256 && ONLY_J4) {
-            match_bucket_slow(S, D, r, t, now, m, q0, k, S.blk + S.blk_off[c], nc, idle, wait_sum, value_sum, evals, rejects);   // any size, in place (int block from L2)
+            match_bucket_slow(S, D, r, t, now, m, q0, k, S.blk + S.blk_off[c], nc, idle, wait_sum, value_sum, evals, rejects, nullptr, ST ? c : -1);   // any size, in place (int block from L2)
         } else if (MAXJ < 16 && m > 256) {
             deferred = true;
             if (lane == 0) {
@@ -461,17 +478,18 @@ __device__ void bucket_tick(const Static &S, const State &D, int c, int r, int t
             match_bucket_slow(S, D, r, t, now, m, q0, k, S.blk + S.blk_off[c], nc, idle, wait_sum, value_sum, evals, rejects);   // beyond the register tables
         } else if (!ONLY_J4 && m <= 64) match_bucket<1, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
         else if (!ONLY_J4 && m <= 128) match_bucket<2, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
-        else if (MAXJ < 16 || m <= 256) match_bucket<4, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
+        else if (MAXJ < 16 || m <= 256) match_bucket<4, LDSBLK, CT, ST>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects, nullptr, c);
         else match_bucket<MAXJ, LDSBLK, CT>(S, D, r, t, now, m, q0, k, blk, nc, idle, wait_sum, value_sum, evals, rejects);
     }
     if (lane == 0) {
-        hdr[HDR_IDLE] = m;
+        hdr[HDR_IDLE] = ST ? m_pre : m;               // stamp mode: the list keeps its length until the walk commits
         hdr[HDR_FL] = newf;
         hdr[HDR_INBOX0 + p] = 0;
         hdr[HDR_IDLE_PRE] = m_pre;
         hdr[HDR_ORDERS] = k;
     }
-    if (k > 0 || A > 0) add_counters(D.cnt + b * CNT_WORDS, deferred ? 0 : k, rejects, wait_sum, value_sum, evals, A);
+    if (ST) { if (A > 0) add_counters(D.cnt + b * CNT_WORDS, 0, 0, 0, 0, 0, A); }
+    else if (k > 0 || A > 0) add_counters(D.cnt + b * CNT_WORDS, deferred ? 0 : k, rejects, wait_sum, value_sum, evals, A);
 }
 
 // k_tick: all buckets, generic form.  grid = C * ceil(R/16); block b -> cluster b % C.
@@ -556,7 +574,13 @@ __device__ __forceinline__ void rows_load_idle(const uint2 *idle, int l16, int m
 // PD (per-replica order days, Static.n_days > 1): q0 / k / now / out_r differ per 16-lane row; the rows fetch their own
 // order records from HBM (lane l of a row holds order jj*16 + l) and the pickup of order j reaches the row's lanes
 // through the LDS crossbar (ds_bpermute) instead of a scalar readlane; the loop runs to the longest row of the wavefront.
-template <int J, typename CT, bool PD>
+// ST ("stamp mode", first half of the hybrid neighbour-search tick): own-cluster matching exactly as
+// below, but nothing is committed - no arrival posts, no compaction, no order counters.  A taken entry stays in the list and
+// gets the RANK of its order (position in id order inside the slot) + 1 into the high half of its node word; the result of an
+// order is {cluster << 16 | list position, wait}.  k_dfs_walk then serves the orders that found their cluster empty from the
+// neighbours (:936-940) against the vehicles alive at their time (stamp > rank) and commits the whole slot.
+#define ST_TAKEN 0x40000000
+template <int J, typename CT, bool PD, bool ST>
 __device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, const uint2 *arr_row, int qb, int r, bool rowvalid, size_t b, int m, int A,
                                            uint2 *idle, long long cntv, unsigned (&veh)[J], int (&loc)[J], bool prof, unsigned long long tprev, int pwave) {
@@ -580,9 +604,11 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (pos >= mnew) loc[s] = 0;
         dead[s] = pos < mnew ? 0 : IMAX;
     }
-    int recy = 0;
+    static_assert(!(PD && ST), "stamp mode: shared or workgroup-uniform order day");
+    int recy = 0, recx = 0;
     int recy4[4] = {0, 0, 0, 0};
     int kmax = k;
+    if (ST && lane < k) recx = lds_rec[lane].x;            // stamp mode stages the order's rank in .x
     if (PD) {
         kmax = max(max(rdlane(k, 0), rdlane(k, 16)), max(rdlane(k, 32), rdlane(k, 48)));
 #pragma unroll
@@ -609,16 +635,39 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
                 best = min(best, v);
             }
             const int rmin = live ? row_min_i32(best) : IMAX;
-            const bool hit = rmin != IMAX;
+            const bool hit = ST ? rmin < ST_TAKEN : rmin != IMAX;
             const int wpos = rmin & 127;
+            const int mark = ST ? (ST_TAKEN | rdlane(recx, jj * 16 + ji)) : IMAX;       // stamp mode: the taker's rank rides in the dead mask
 #pragma unroll
-            for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? IMAX : dead[s];
+            for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? mark : dead[s];
             res[jj] = (l16 == ji) ? rmin : res[jj];
             evals += live ? navail : 0;
             navail -= hit ? 1 : 0;
         }
     }
     PROF_STAMP(4);
+    if (ST) {
+        const int c = (int)(b / (size_t)S.R);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (jj * 16 >= kmax) break;
+            const int j = jj * 16 + l16;
+            const int rv = res[jj];
+            if (rowvalid && j < k) D.out[(size_t)r * S.Oq + (q0 - qb) + j] = rv < ST_TAKEN ? make_int2((int)(((unsigned)c << 16) | (unsigned)(rv & 127)), rv >> 7) : make_int2(-1, -1);
+        }
+        if (rowvalid) {
+#pragma unroll
+            for (int s = 0; s < J; ++s) {
+                const int pos = l16 * J + s;
+                const bool taken = dead[s] != IMAX && dead[s] >= ST_TAKEN;
+                if (pos < mnew && (pos >= m || taken))
+                    idle[pos] = make_uint2(veh[s], (unsigned)loc[s] | (taken ? (unsigned)((dead[s] & 0xFFFF) + 1) << 16 : 0u));
+            }
+            if (l16 < 3) D.hdr[b * HDR_WORDS + l16] = l16 == HDR_ORDERS ? k : mnew;          // the list keeps its length until the walk commits
+            if (l16 == CNT_ARRIVALS && A > 0) D.cnt[b * CNT_WORDS + l16] = cntv + A;
+        }
+        return;
+    }
     // results; the ring-slot atomics of the matched orders are issued here, their dependent entry
     // stores only after the compaction / header traffic below (hides the atomic round trip)
     int wsum = 0, vsum = 0, rej = 0;
@@ -690,7 +739,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     PROF_STAMP(6);
 }
 
-template <int J, typename CT, bool PD>
+template <int J, typename CT, bool PD, bool ST>
 __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
                                           const int4 *lds_rec, unsigned long long *key_row, int qb, int r, bool rowvalid, size_t b, size_t si,
                                           int m, int A, long long cntv, bool prof, unsigned long long tprev, int pwave) {
@@ -761,7 +810,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
         }
         return;
     }
-    rows_match<J, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, qb, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
+    rows_match<J, CT, PD, ST>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, arr_row, qb, r, rowvalid, b, m, A, idle, cntv, veh, loc, prof, tprev, pwave);
 }
 
 #ifndef ROWS_WAVES
@@ -781,7 +830,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 // DM (day mode): 0 = one order day shared by every replica; 1 = several days, but the 16 replicas of every workgroup replay
 // the same one (vds_load_order_days with a block-wise replica -> day map): the shared-day code with the day looked up once
 // per workgroup through scalar loads; 2 = per-row order streams (PD below).
-template <bool U8, int DM>
+template <bool U8, int DM, bool ST = false>
 __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     constexpr bool PD = DM == 2;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
@@ -879,7 +928,10 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
         const int n4 = U8 ? (nc * nc + 15) >> 4 : (nc * nc + 3) >> 2;
         int4 rec = make_int4(0, 0, 0, 0);
-        if (!PD && (int)threadIdx.x < min(k, 64)) rec = S.so_rec[q0 + threadIdx.x];
+        if (!PD && (int)threadIdx.x < min(k, 64)) {
+            rec = S.so_rec[q0 + threadIdx.x];
+            if (ST) rec.x = S.so_rank[q0 + threadIdx.x];        // the order id is only needed by the commit (k_dfs_walk)
+        }
         if (U8) {
             for (int i = threadIdx.x; i < n4; i += ROWS_WAVES * WAVE) lds4[i] = blk4[i];
         } else {
@@ -902,15 +954,15 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
         // 3.-5. idle list + arrivals + match, specialised on the table depth
         unsigned long long *key_row = scr_all + (wave * 4 + g) * ROW_KEYS;
         PROF_STAMP(0);
-        if (big && !big96) rows_body<6, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (big) rows_body<8, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else if (small32) rows_body<2, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
-        else rows_body<4, CT, PD>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        if (big && !big96) rows_body<6, CT, PD, ST>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (big) rows_body<8, CT, PD, ST>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else if (small32) rows_body<2, CT, PD, ST>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
+        else rows_body<4, CT, PD, ST>(S, D, t, now, q0, k, lds_blk, nc, lds_rec, key_row, qb, r, rowvalid, b, si, m, A, cntv, prof, tprev, pwave);
     }
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int gg = (__ffsll((long long)rest) - 1) >> 4;
-        bucket_tick<true, true, 4, true, CT>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, lds_blk, nc);
+        bucket_tick<true, true, 4, true, CT, ST>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, lds_blk, nc);
     }
 }
 
@@ -1039,8 +1091,42 @@ __global__ __launch_bounds__(64) void k_match_dfs(Static S, State D, int t) {
 // own-cluster match of orders [qs, qs+n) for tables of any size (slow path: > 256 idle entries)
 __device__ void match_bucket_slow(const Static &S, const State &D, int r, int t, int now, int &m, int qs, int n,
                                   const int *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
-                                  long long &evals, int &rejects, unsigned short *mir) {
+                                  long long &evals, int &rejects, unsigned short *mir, int stamp_cl) {
     const int lane = lane_id();
+    if (stamp_cl >= 0) {
+        // stamp mode (see rows_match): the list is not edited; a taken entry gets rank + 1 into the high half of its node
+        // word and is skipped from then on.  On entry every entry is free (the previous commit left a clean list).
+        int nfree = m;
+        for (int j = 0; j < n; ++j) {
+            const int4 rec = S.so_rec[qs + j];
+            int2 res = make_int2(-1, -1);
+            if (nfree > 0) {
+                const int *row = blk + (size_t)(rec.y & 0xFFFF) * nc;
+                int lc = IMAX, lp = -1;
+                for (int base = 0; base < m; base += WAVE) {
+                    const int i = base + lane;
+                    if (i < m) {
+                        const unsigned y = idle[i].y;
+                        if ((y >> 16) == 0u) {
+                            const int cst = row[y];
+                            if (lp < 0 || cst < lc) { lc = cst; lp = i; }
+                        }
+                    }
+                }
+                const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
+                const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
+                if ((long long)minc <= S.reject_threshold) {
+                    wave_fence();
+                    if (lane == 0) idle[minp].y |= (unsigned)(S.so_rank[qs + j] + 1) << 16;
+                    nfree--;
+                    res = make_int2((int)(((unsigned)stamp_cl << 16) | (unsigned)minp), minc);
+                }
+            }
+            if (lane == 0) out_row(S, D, r)[qs + j] = res;
+            wave_fence();
+        }
+        return;
+    }
     for (int j = 0; j < n; ++j) {
         const int4 rec = S.so_rec[qs + j];
         evals += m;
@@ -2689,6 +2775,464 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 }
 
 // ---------------------------------------------------------------------------------------
+// k_dfs_walk: second half of the HYBRID neighbour-search tick.  The first half is k_tick_rows in stamp mode:
+// cluster-major, four replicas per wavefront, cost block in LDS - UpdateFunction and the own-cluster matching (:924-933) of
+// every bucket up to the order that finds the list exhausted, nothing committed, every taken entry stamped with the rank of
+// its order.  This kernel, one 256-thread workgroup per replica, then
+//   1. loads the stamps of the replica's ~V idle entries into LDS (u16 each: 0xFFFF free, else the rank that took it);
+//   2. walks the DRY orders (own cluster exhausted, :936) in id order with ONE wavefront: the visit sequence of
+//      FindServerVehicleFunction (:978-996), lane j = j-th visited cluster; the vehicles alive at the order's time are the
+//      entries with stamp > rank; evaluations = sum over the visited clusters of the alive count, derived without a scan
+//      (list length - own matches before the order - steals so far; own matches are a prefix of the bucket's orders);
+//      candidate clusters are pruned by the cost lower bound (Static.lbc); the winner (first strict minimum in visit, then
+//      list order) is stolen: stamp = the dry order's rank.  If it had been taken later by an own-cluster order, that
+//      bucket's matching is redone from its first order after this one (rare), which may add a dry order with a later rank;
+//   3. commits the slot: evaluations of the own-cluster orders from the final stamps, vehicle ids and arrival posts
+//      (:954-960) for every order, counters, order-preserving compaction of the lists (:963), headers.
+// Preconditions (vds_api dfs_hybrid_ok): the fast kernel's (fast_ok: costs < 2^23 and never above the pickup window, blocks fit
+// LDS), one order day per workgroup chunk, < 65535 orders per slot, V < 65536, C <= 2047 nodes per cluster, LDS footprint.
+#define WK_THREADS 256
+#define WK_WAVES (WK_THREADS / WAVE)
+#define WK_FREE 0xFFFFu
+#ifdef WKDEBUG
+#define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
+#else
+#define WKCHK(cond, code, a, b2) do { } while (0)
+#endif
+
+__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto) {
+    const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
+    const size_t words = (size_t)(mto + 31) / 32 + 1;
+    return ((size_t)10 * C + 2 + ids + words + ((size_t)V + 1) / 2) * sizeof(int);
+}
+
+template <bool U8>
+__global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int t) {
+    extern __shared__ int lds_dyn[];
+    const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
+    auto cost_at = [](const char *base, unsigned elem) -> int {
+        return U8 ? (int)*reinterpret_cast<const unsigned char *>(base + elem) : *reinterpret_cast<const int *>(base + (elem << 2));
+    };
+    const int C = S.C;
+    const int mto = S.max_tick_orders;
+    int *m0_l = lds_dyn;                  // [C] list length after Update (taken entries still inside); later the final length
+    int *moff_l = lds_dyn + C;            // [C+1] start of the cluster's stamps
+    int *qdry_l = moff_l + C + 1;         // [C] first sorted position that is not an own-cluster order (dry from here / end)
+    int *qend_l = qdry_l + C;             // [C]
+    int *lm_l = qend_l + C;               // [C] own-cluster matches of the bucket (a prefix of its orders)
+    int *sc_l = lm_l + C;                 // [C] vehicles stolen from the cluster so far
+    int *cur_l = sc_l + C;                // [C] cursor: first sorted position of the bucket whose rank is >= the dry order being served
+    int *cdA_l = cur_l + C;               // [C] n_c | first cost column << 11 | can search << 30
+    int *cdB_l = cdA_l + C;               // [C] start of the cluster's cost block
+    int *dfsoff_l = cdB_l + C;            // [C+1]
+    int *tab_l = dfsoff_l + C + 1;        // rank tables (u16), later the resolve counters
+    const int ids_n = mto + 2 > RCNT * C ? mto + 2 : RCNT * C;
+    unsigned short *rq_l = reinterpret_cast<unsigned short *>(tab_l);                 // [mto] rank of sorted position
+    unsigned short *qr_l = rq_l + ((mto + 1) & ~1);                                   // [mto] sorted position of rank
+    unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
+    const int nwords = (mto + 31) / 32 + 1;
+    unsigned short *st_l = reinterpret_cast<unsigned short *>(dry_bits + nwords);     // [V] stamps
+    __shared__ int s_ev;                  // evaluations of the dry orders
+    const int r = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;
+    const int now = dv.now0 + t * S.tick_minutes;
+    const int *bkt_off = dv.bkt_off;
+    const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
+    const int nord = tq1 - tq0;
+    int2 *out_r = D.out + (size_t)r * S.Oq - dv.q_base;
+#ifdef VDS_PROF
+    const bool prof = (g_ablate & 128) != 0;
+    unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int pwave = (int)((blockIdx.x * WK_WAVES + wave) & (PROF_WAVES - 1));
+#endif
+    // ---- tables
+    for (int i = threadIdx.x; i < nord; i += WK_THREADS) {
+        const int rk = S.so_rank[tq0 + i];
+        rq_l[i] = (unsigned short)rk;
+        qr_l[rk] = (unsigned short)i;
+    }
+    for (int c = threadIdx.x; c < C; c += WK_THREADS) {
+        const int4 cd = S.cdesc[c];
+        const bool capable = S.dfs_off[c + 1] > S.dfs_off[c];
+        cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (capable ? CAPABLE : 0);
+        cdB_l[c] = U8 ? cd.z : cd.y;
+        dfsoff_l[c] = S.dfs_off[c];
+        if (c == 0) dfsoff_l[C] = S.dfs_off[C];
+        const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
+        const int m0 = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
+        const int own = min(q1 - q0, m0);                 // the fast kernel matched while vehicles remained
+        m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; cur_l[c] = q0;
+        qdry_l[c] = capable ? q0 + own : q1;
+    }
+    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) dry_bits[w] = 0u;
+    if (threadIdx.x == 0) s_ev = 0;
+    __syncthreads();
+    if (wave == 0) {            // exclusive prefix of the list lengths
+        int run = 0;
+        for (int base = 0; base < C; base += WAVE) {
+            const int c = base + lane;
+            const int v = c < C ? m0_l[c] : 0;
+            int inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            if (c < C) moff_l[c] = run + inc - v;
+            run += rdlane(inc, WAVE - 1);
+        }
+        if (lane == 0) moff_l[C] = run;
+    }
+    __syncthreads();
+    // ---- stamps of every idle entry (the fast kernel wrote rank + 1 into the high half of the node word of a taken entry)
+    for (int c = wave; c < C; c += 4 * WK_WAVES) {
+        int m4[4], mo4[4];
+        unsigned y4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u * WK_WAVES;
+            m4[u] = cu < C ? m0_l[cu] : 0;
+            mo4[u] = cu < C ? moff_l[cu] : 0;
+            y4[u] = 0u;
+            if (lane < m4[u]) y4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane].y;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (lane < m4[u]) st_l[mo4[u] + lane] = (unsigned short)((y4[u] >> 16) ? (y4[u] >> 16) - 1u : WK_FREE);
+            if (m4[u] > WAVE) {
+                const uint2 *idle = D.idle + ((size_t)(c + u * WK_WAVES) * S.R + r) * S.idle_cap;
+                for (int i = WAVE + lane; i < m4[u]; i += WAVE) { const unsigned y = idle[i].y; st_l[mo4[u] + i] = (unsigned short)((y >> 16) ? (y >> 16) - 1u : WK_FREE); }
+            }
+        }
+    }
+    // dry orders: everything behind a searching cluster's exhaustion point
+    for (int c = threadIdx.x; c < C; c += WK_THREADS) {
+        if (!(cdA_l[c] & CAPABLE)) continue;
+        for (int q = qdry_l[c]; q < qend_l[c]; ++q) {
+            const int rk = rq_l[q - tq0];
+            atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
+        }
+    }
+    __syncthreads();
+    PROF_STAMP(0);
+    // ---- the walk: wavefront 0 alone (a chain of dependent steps - more wavefronts would only add barriers)
+    if (wave == 0) {
+        auto next_dry = [&](int from) -> int {
+            int best = IMAX;
+            for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
+                unsigned bits = dry_bits[w];
+                if (w == (from >> 5)) bits &= 0xFFFFFFFFu << (from & 31);
+                if (bits != 0u) { best = w * 32 + __ffs((int)bits) - 1; break; }
+            }
+            return wave_min_i32(best);
+        };
+        auto cluster_of = [&](int q) -> int {
+            int pc = 0;
+            for (int base = 0; base < C; base += WAVE) {
+                const int c = base + lane;
+                const bool hit = c < C && q < qend_l[c] && (c == 0 || q >= qend_l[c - 1]);
+                const unsigned long long hb = ballot(hit);
+                if (hb) { pc = base + __ffsll((long long)hb) - 1; break; }
+            }
+            return pc;
+        };
+        int ev_acc = 0;
+        int rho = next_dry(0);
+        int q = 0, pc = 0, pnode = 0;
+        if (rho != IMAX) { q = tq0 + (int)qr_l[rho]; pc = cluster_of(q); pnode = S.so_pnode[q]; }
+        while (rho != IMAX) {
+            WKCHK(rho < nord && q >= tq0 && q < tq1 && pc >= 0 && pc < C && pnode >= 0 && pnode < S.N, 1, rho, q);
+            const int s0 = dfsoff_l[pc], s1 = dfsoff_l[pc + 1];
+            const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
+            // the next dry order (as known now; a redo below may insert an earlier one): its pickup node travels meanwhile
+            int rho_n = next_dry(rho + 1);
+            int q_n = 0, pc_n = 0, pnode_n = 0;
+            if (rho_n != IMAX) { q_n = tq0 + (int)qr_l[rho_n]; pc_n = cluster_of(q_n); pnode_n = S.so_pnode[q_n]; }
+            int bhi = IMAX, blo = IMAX;
+            for (int jb = 0; s0 + jb < s1; jb += WAVE) {
+                const int sx = s0 + jb + lane;
+                const bool inseq = sx < s1;
+                const int cj = inseq ? S.dfs_seq[sx] : 0;
+                WKCHK(cj >= 0 && cj < C, 2, cj, sx);
+                int lbj = 0;
+                if (U8 && S.lbc != nullptr && inseq) lbj = (int)S.lbc[(size_t)pnode * C + cj];
+                // vehicles of cj alive at this order's time, without looking at them
+                int alive = 0, moj = 0, m0j = 0;
+                if (inseq) {
+                    const int qe = qend_l[cj];
+                    const int qa = cj == 0 ? tq0 : qend_l[cj - 1];
+                    int cur = cur_l[cj];
+                    while (cur < qe && (int)rq_l[cur - tq0] < rho) ++cur;
+                    cur_l[cj] = cur;
+                    m0j = m0_l[cj];
+                    moj = moff_l[cj];
+                    alive = m0j - min(cur - qa, lm_l[cj]) - sc_l[cj];
+                }
+                {   // :986-991 runs for every visited cluster
+                    const int rs = row_sum_i32(alive);
+                    ev_acc += rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
+                }
+                const bool cand_l = alive > 0;
+                const unsigned long long cand = ballot(cand_l);
+                const int lbmin = wave_min_i32(cand_l ? lbj : IMAX);
+                unsigned long long live = ballot(cand_l && lbj <= lbmin + PRUNE_DELTA);
+                const unsigned long long first_pass = live;
+                int b = 0, best = IMAX;
+                for (int pass = 0; pass < 2; ++pass) {
+                    if (pass == 1) {
+                        const int bc = wave_min_i32(best) >> 16;
+                        live = cand & ~first_pass & ballot(lbj <= bc);
+                        b = 0;
+                    }
+                    while (live != 0) {
+                        // eight (cluster, 64-entry chunk) slots at a time: their stamps (LDS), then the node words of the alive
+                        // entries (HBM), then the cost gathers, then the minima
+                        int in[8], seq[8], cst[8];
+                        unsigned yv[8];
+                        int cof[8];
+#pragma unroll
+                        for (int k8 = 0; k8 < 8; ++k8) {
+                            in[k8] = 0; seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0;
+                            if (live != 0) {
+                                const int j = __ffsll((long long)live) - 1;
+                                const int m0c = rdlane(m0j, j), moc = rdlane(moj, j), cc = rdlane(cj, j);
+                                const int i = b * WAVE + lane;
+                                WKCHK(m0c > 0 && cc >= 0 && cc < C && moc + m0c <= S.V, 3, m0c, cc);
+                                in[k8] = (i < m0c ? 1 : 0) & ((int)st_l[moc + min(i, m0c - 1)] > rho ? 1 : 0);
+                                if (in[k8]) yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
+                                cof[k8] = (cdA_l[cc] >> 11) & 0xFFFF;
+                                seq[k8] = (j << 9) | b;
+                                ++b;
+                                if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
+                            }
+                        }
+#pragma unroll
+                        for (int k8 = 0; k8 < 8; ++k8)
+                            cst[k8] = cost_at(crow_b, (unsigned)(in[k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
+#pragma unroll
+                        for (int k8 = 0; k8 < 8; ++k8)
+                            best = min(best, in[k8] ? (cst[k8] << 16) | seq[k8] : IMAX);
+                    }
+                }
+                const int wbest = wave_min_i32(best);
+                if (wbest != IMAX) {
+                    const int wl = __ffsll((long long)ballot(best == wbest)) - 1;       // lowest lane = lowest list position
+                    const int j = (wbest >> 9) & 63, bb = wbest & 511;
+                    const int hi = (wbest & ~0xFFFF) | (jb + j);
+                    const int lo = ((bb * WAVE + wl) << 16) | rdlane(cj, j);
+                    if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; }
+                }
+            }
+            // ---- the winner
+            const int wc = bhi >> 16;
+            int2 res = make_int2(-1, -1);
+            if (bhi != IMAX && (long long)wc <= S.reject_threshold) {
+                const int wcl = blo & 0xFFFF, wpos = blo >> 16;
+                WKCHK(wcl < C && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
+                const int idx = moff_l[wcl] + wpos;
+                const int vst = (int)st_l[idx];
+                wave_fence();
+                if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] += 1; }
+                res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
+                wave_fence();
+                if (vst != (int)WK_FREE) {
+                    // the stolen vehicle had been taken later by an own-cluster order of wcl: redo that bucket from its first
+                    // order after this one, in sequence, against the entries that are free now
+                    const int cda = cdA_l[wcl];
+                    const int nc = cda & 2047, clo = (cda >> 11) & 0xFFFF;
+                    const bool capable = (cda & CAPABLE) != 0;
+                    const int boff = cdB_l[wcl];
+                    const int mo = moff_l[wcl], m0 = m0_l[wcl];
+                    const int qa = wcl == 0 ? tq0 : qend_l[wcl - 1];
+                    const int qy = cur_l[wcl];                          // first own position with rank > rho (cursor of this round)
+                    const int old_dry = qdry_l[wcl];
+                    WKCHK(qy >= qa && qy <= qend_l[wcl] && old_dry <= qend_l[wcl] && old_dry >= qa, 5, qy, old_dry);
+                    const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
+                    for (int i = lane; i < m0; i += WAVE) {
+                        const int st = (int)st_l[mo + i];
+                        if (st != (int)WK_FREE && st > rho) st_l[mo + i] = (unsigned short)WK_FREE;
+                    }
+                    wave_fence();
+                    int qq = qy;
+                    for (; qq < old_dry; ++qq) {
+                        const int pick = S.so_rec[qq].y & 0xFFFF;
+                        int lc = IMAX, lp = -1;
+                        for (int base = 0; base < m0; base += WAVE) {
+                            const int i = base + lane;
+                            if (i < m0 && (unsigned)st_l[mo + i] == WK_FREE) {
+                                const int loc = (int)(idle[i].y & 0xFFFF);
+                                const int cst = cost_at(blk_b, (unsigned)(boff + pick * nc + loc));
+                                if (lp < 0 || cst < lc) { lc = cst; lp = i; }
+                            }
+                        }
+                        const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
+                        if (minc == IMAX) {
+                            if (capable) break;                         // exhausted: this order and the rest are dry
+                            if (lane == 0) out_r[qq] = make_int2(-1, -1);
+                            continue;
+                        }
+                        const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
+                        if (lane == 0) {
+                            st_l[mo + minp] = rq_l[qq - tq0];
+                            out_r[qq] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
+                        }
+                        wave_fence();
+                    }
+                    // own matches now: those before qy plus the re-matched ones (a prefix again)
+                    int nmatch = 0;
+                    for (int base = 0; base < m0; base += WAVE) {
+                        const int i = base + lane;
+                        const int st = i < m0 ? (int)st_l[mo + i] : (int)WK_FREE;
+                        nmatch += popc64(ballot(st != (int)WK_FREE && i < m0));
+                    }
+                    if (lane == 0) { lm_l[wcl] = nmatch - sc_l[wcl]; if (capable) qdry_l[wcl] = qq; }
+                    if (capable)
+                        for (int q2 = qq + lane; q2 < old_dry; q2 += WAVE) {
+                            const int rk = rq_l[q2 - tq0];
+                            atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
+                        }
+                    wave_fence();
+                    const int rho_2 = next_dry(rho + 1);
+                    if (rho_2 != rho_n) { rho_n = rho_2; q_n = tq0 + (int)qr_l[rho_n]; pc_n = cluster_of(q_n); pnode_n = S.so_pnode[q_n]; }
+                }
+            }
+            if (lane == 0) out_r[q] = res;
+#ifdef VDS_PROF
+            if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+#endif
+            rho = rho_n; q = q_n; pc = pc_n; pnode = pnode_n;
+        }
+        if (lane == 0) s_ev = ev_acc;
+    }
+    __syncthreads();
+    PROF_STAMP(1);
+    // ---- evaluations of the own-cluster orders and the final list lengths, from the final stamps: one 8-lane group per
+    //      bucket.  Order of rank p looked at the entries with stamp >= p (free = 0xFFFF; stolen entries carry the thief's rank).
+    {
+        const int gl = lane & (GRP - 1), gw = lane / GRP;
+        for (int c0 = wave * GRPS_WAVE; c0 < C; c0 += WK_WAVES * GRPS_WAVE) {
+            const int c = c0 + gw;
+            const bool has = c < C;
+            const int cc = has ? c : 0;
+            const int mo = moff_l[cc], m0 = has ? m0_l[cc] : 0;
+            const int qa = has ? (cc == 0 ? tq0 : qend_l[cc - 1]) : 0;
+            const int qb2 = has ? qdry_l[cc] : 0;                       // own-cluster orders: [qa, qb2)
+            int ev = 0, fin = 0;
+            int mx = m0;
+            mx = max(mx, dpp_mov<0x4E, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x141, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x140, 0xF>(mx, mx));
+            const int mmaxw = max(max(rdlane(mx, 0), rdlane(mx, 16)), max(rdlane(mx, 32), rdlane(mx, 48)));
+            int nq = qb2 - qa;
+            nq = max(nq, dpp_mov<0x4E, 0xF>(nq, nq)); nq = max(nq, dpp_mov<0x141, 0xF>(nq, nq)); nq = max(nq, dpp_mov<0x140, 0xF>(nq, nq));
+            const int nqmax = max(max(rdlane(nq, 0), rdlane(nq, 16)), max(rdlane(nq, 32), rdlane(nq, 48)));
+            for (int i0 = 0; i0 < mmaxw; i0 += GRP) {
+                const int i = i0 + gl;
+                const bool ok = i < m0;
+                const int st = ok ? (int)st_l[mo + i] : -1;
+                fin += (ok && st == (int)WK_FREE) ? 1 : 0;
+                for (int j = 0; j < nqmax; ++j) {
+                    const int qq = qa + j;
+                    const int rk = qq < qb2 ? (int)rq_l[qq - tq0] : IMAX;
+                    ev += st >= rk ? 1 : 0;
+                }
+            }
+            ev += dpp_mov<0xB1, 0xF>(ev, ev); ev += dpp_mov<0x4E, 0xF>(ev, ev); ev += dpp_mov<0x141, 0xF>(ev, ev);
+            fin += dpp_mov<0xB1, 0xF>(fin, fin); fin += dpp_mov<0x4E, 0xF>(fin, fin); fin += dpp_mov<0x141, 0xF>(fin, fin);
+            if (has && gl == 0) { lm_l[c] = ev; sc_l[c] = fin; }       // (lm / sc are dead now: reused as evaluations / final length)
+        }
+    }
+    __syncthreads();
+    // ---- commit: vehicle ids, arrivals (:954-960), counters (the rank tables are dead now)
+    int *rc_l = tab_l;
+    for (int i = threadIdx.x; i < RCNT * C; i += WK_THREADS) rc_l[i] = 0;
+    __syncthreads();
+    for (int qq = tq0 + (int)threadIdx.x; qq < tq1; qq += 3 * WK_THREADS) {
+        int4 rec[3];
+        int2 pr[3];
+        int veh[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = qq + u * WK_THREADS;
+            rec[u] = make_int4(0, 0, 0, 0); pr[u] = make_int2(-1, -1);
+            if (q < tq1) { rec[u] = S.so_rec[q]; pr[u] = out_r[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            veh[u] = -1;
+            if (pr[u].x != -1) {
+                const int vc = (int)((unsigned)pr[u].x >> 16), vpos = pr[u].x & 0xFFFF;
+#ifdef WKDEBUG
+                if (vc >= C || vpos >= m0_l[vc < C ? vc : 0]) { printf("walk resolve: r %d t %d q %d (rank %d) pr %x %d vc %d vpos %d\n", r, t, qq + u * WK_THREADS - tq0, (int)S.so_rank[qq + u * WK_THREADS], pr[u].x, pr[u].y, vc, vpos); pr[u].x = -1; continue; }
+#endif
+                veh[u] = (int)D.idle[((size_t)vc * S.R + r) * S.idle_cap + vpos].x;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = qq + u * WK_THREADS;
+            if (q >= tq1) continue;
+            int *cl = rc_l + (int)((unsigned)rec[u].z >> 16) * RCNT;
+            atomicAdd(&cl[CNT_ORDERS], 1);
+            if (pr[u].x == -1) {
+                atomicAdd(&cl[CNT_REJECTS], 1);
+            } else {
+                out_r[q] = make_int2(veh[u], pr[u].y);
+                post_arrival(S, D, rec[u].z & 0xFFFF, r, t, now, veh[u], rec[u].x, now + pr[u].y + rec[u].w, 0, (int)((unsigned)rec[u].y >> 16));
+                atomicAdd(&cl[CNT_WAIT], pr[u].y);
+                atomicAdd(&cl[CNT_VALUE], rec[u].w);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = free entries, node words clean)
+    for (int c = wave; c < C; c += 4 * WK_WAVES) {
+        uint2 e4[4];
+        bool keep4[4], small4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u * WK_WAVES;
+            const int mo = cu < C ? moff_l[cu] : 0, m0 = cu < C ? m0_l[cu] : 0;
+            small4[u] = cu < C && m0 <= WAVE && sc_l[cu] != m0;
+            keep4[u] = small4[u] && lane < m0 && (unsigned)st_l[mo + min(lane, max(m0, 1) - 1)] == WK_FREE;
+            e4[u] = make_uint2(0u, 0u);
+            if (keep4[u]) e4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long kb = ballot(keep4[u]);
+            if (keep4[u]) D.idle[((size_t)(c + u * WK_WAVES) * S.R + r) * S.idle_cap + popc64(kb & lanemask_lt())] = e4[u];
+        }
+    }
+    for (int c = wave; c < C; c += WK_WAVES) {
+        const int mo = moff_l[c], m0 = m0_l[c];
+        if (sc_l[c] == m0 || m0 <= WAVE) continue;
+        uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
+        int kept = 0;
+        for (int base = 0; base < m0; base += WAVE) {
+            const int i = base + lane;
+            uint2 e = make_uint2(0u, 0u);
+            bool keep = false;
+            if (i < m0) {
+                keep = (unsigned)st_l[mo + i] == WK_FREE;
+                if (keep) e = idle[i];
+            }
+            const unsigned long long kb = ballot(keep);
+            wave_fence();
+            if (keep) idle[kept + popc64(kb & lanemask_lt())] = e;
+            kept += popc64(kb);
+        }
+    }
+    PROF_STAMP(7);
+    // ---- flush: list lengths and this tick's counter deltas (arrivals were counted by the fast kernel)
+    for (int c = threadIdx.x; c < C; c += WK_THREADS) {
+        const size_t b = (size_t)c * S.R + r;
+        D.hdr[b * HDR_WORDS + HDR_IDLE] = sc_l[c];
+        long long *cnt = D.cnt + b * CNT_WORDS;
+#pragma unroll
+        for (int w = 0; w < RCNT; ++w) { const int d = rc_l[c * RCNT + w]; if (d) cnt[w] += d; }
+        const int ev = lm_l[c] + (c == 0 ? s_ev : 0);
+        if (ev) cnt[CNT_EVALS] += ev;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_dispatch: one wavefront per (replica, from_cluster) group of actions (host-sorted).
 // grp_off[g]..grp_off[g+1] index the group's actions; positions refer to the idle list as it
 // stands at call time.
@@ -2981,6 +3525,25 @@ int replica3_prepare() {      // opt in to more than 64 KB of dynamic LDS per wo
     hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tick_replica3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tick_replica3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     return (a == hipSuccess && b == hipSuccess) ? 0 : -1;
+}
+
+size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders); }
+
+// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
+void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
+    const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+    const int dm = S.n_days <= 1 ? 0 : 1;
+    const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
+    if (S.u8_ok) {
+        const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);
+        if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        else hipLaunchKernelGGL((k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        hipLaunchKernelGGL(k_dfs_walk<true>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+    } else {
+        if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        else hipLaunchKernelGGL((k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        hipLaunchKernelGGL(k_dfs_walk<false>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+    }
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
