@@ -21,6 +21,12 @@ if env.main_kernel() == "k_tick_replica3":
     names = ["0 update (drain + hdr)", "1 mirror build", "2 phase 1: own-cluster pass, every bucket once", "3 dry bitset", "4 per dry order: pick + row + candidate scan",
              "5 per dry order: barrier + winner (+ redo) + barrier", None, "7 evaluations + resolve + compaction + flush"]
     nw = R * 8
+if env.main_kernel() == "k_dfs_hybrid":
+    names = ["0 k_dfs_walk: tables + stamps into LDS + dry bits", "1 k_dfs_walk: the walk (wavefront 0)", None, None, None, "5 k_dfs_walk: evaluations from the stamps", None, "7 k_dfs_walk: resolve + compaction"]
+    nw = R * 4
+    print("dry orders per replica-tick %.1f, served by a neighbour %.1f, with a redo chain %.2f, scanned again by the walk %.2f" % (
+        buf[6] / R / T, buf[2] / R / T, buf[3] / R / T, buf[4] / R / T))
+    buf[2] = buf[3] = buf[4] = 0
 print(env.main_kernel())
 tot = float(buf[:6].sum() + buf[7])
 print("instrumented: %.2f ms/launch; DFS rounds per replica-tick: %.1f" % (ms.mean(), buf[6] / nw / T))

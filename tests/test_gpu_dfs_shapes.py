@@ -15,7 +15,7 @@ from vehicles_dispatch_simulator_amd.env import neighbors_to_csr
 pytestmark = pytest.mark.gpu
 
 
-def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, **kw):
+def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_dfs_hybrid", **kw):
     start, p0, d0 = synth.make_orders(oseed, city.N, O)
     pick = p0 if pick is None else pick
     dele = d0 if dele is None else dele
@@ -26,7 +26,7 @@ def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, **kw):
         env = BatchedDispatchEnv(city.cost, city.node2cluster, off, idx, replicas=R, vehicles=V, depth_limit=depth,
                                  neighbor_can_server=True, force_generic=mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
         env.load_orders(rel, pick, dele)
-        assert env.main_kernel() == {0: "k_dfs_hybrid", 3: "k_tick_replica2", 4: "k_tick_replica3", 2: "k_tick_replica"}[mode]
+        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 4: "k_tick_replica3", 2: "k_tick_replica"}[mode]
         env.reset(init)
         env.run(env.T)
         results[mode] = (env.orders(), env.counters(), env.obs(), [env.lists(r) for r in range(R)])
@@ -54,8 +54,17 @@ def test_long_visit_sequences_many_clusters():
     assert max(len(s) for s in seqs) > 4 * 64            # more than one 64-cluster batch for some wavefront
     V, R = 500, 3
     init = np.stack([synth.init_vehicle_nodes(random.Random(31 + r), city.N, V) for r in range(R)])
-    cn = check(city, 5, V, 9000, 77, R, init)
+    cn = check(city, 5, V, 9000, 77, R, init, kernel0="k_tick_replica2")      # beyond the hybrid tick's 256 visited clusters
     assert cn[:, 1].min() >= 0
+
+
+def test_visit_sequences_of_several_batches_hybrid():
+    city = synth.make_city(seed=905, N=1500, C=260)
+    seqs = synth.dfs_sequences(city.neighbors, 3)
+    assert 2 * 64 < max(len(s) for s in seqs) <= 256     # three or four 64-cluster batches per dry order, still the hybrid tick
+    V, R = 500, 3
+    init = np.stack([synth.init_vehicle_nodes(random.Random(41 + r), city.N, V) for r in range(R)])
+    check(city, 3, V, 9000, 83, R, init)
 
 
 def test_all_vehicles_start_in_a_few_clusters_long_lists():

@@ -23,6 +23,8 @@ void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
 size_t dfs_walk_lds(const Static &);
+size_t dfs_spec_lds(const Static &);
+size_t dfs_spec_ints(const Static &);
 size_t replica3_lds(const Static &);
 int replica3_prepare();
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
@@ -62,6 +64,7 @@ struct vds_handle {
     bool hybrid_ok = false; // hybrid neighbour-search tick (k_tick_rows in stamp mode + k_dfs_walk) preconditions hold
     long long blk_ints = 0; // total size of the per-cluster cost blocks
     int cost_min = 0, cost_max = 0;
+    int max_seq = 0;        // longest visit sequence of FindServerVehicleFunction over the clusters
     int depth_limit = 0;
     int t = 0;              // self.step
     int last_stepped = -1;  // tick of the last vds_step
@@ -468,6 +471,9 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         }
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
     }
+    h->max_seq = 0;
+    for (int c = 0; c < C; ++c) h->max_seq = std::max(h->max_seq, dfs_off[c + 1] - dfs_off[c]);
+    S.seq_pad = std::max(64, (h->max_seq + 63) / 64 * 64);
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;
     if ((rc = upload(h, &d, dfs_seq))) return rc; S.dfs_seq = d;
     // fast-kernel preconditions: packed (cost << 7 | position) keys, no window rejects
@@ -703,7 +709,17 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         // order day per workgroup, 16-bit ranks / positions / columns, the walk's LDS footprint
         h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
                        (Z.n_days <= 1 || Z.chunk_days) && Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
-                       Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 65535 && dfs_walk_lds(Z) + 1024 <= 64 * 1024;
+                       Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
+                       dfs_walk_lds(Z) + 1024 <= 64 * 1024 && dfs_spec_lds(Z) + 1024 <= 64 * 1024 &&
+                       dfs_spec_ints(Z) * sizeof(int) <= ((size_t)16 << 30);
+        if (h->hybrid_ok) {         // speculation records, one per (replica, order of a slot)
+            h->alloc_sink = &h->order_allocs;
+            unsigned *sp = nullptr;
+            rc = dev_alloc(h, &sp, dfs_spec_ints(Z));
+            h->alloc_sink = nullptr;
+            if (rc) return rc;
+            h->S.spec = sp;
+        }
         h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
                      replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }
@@ -782,7 +798,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     h->idle_cap_grown = cap;
     // k_tick_replica2 addresses list positions with 15 bits
     if (cap > 32767) { h->dfs2_ok = false; h->dfs3_ok = false; }
-    if (cap > 65535) h->hybrid_ok = false;
+    if (cap > 16384) h->hybrid_ok = false;
     return VDS_OK;
 }
 

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
     const int g = lane >> 4, l16 = lane & 15;
     const int p = t & 1;
 #ifdef VDS_PROF
-    const bool prof = (g_ablate & 128) != 0;
+    const bool prof = (g_ablate & 128) != 0 && !ST;       // in the hybrid tick the sections of k_dfs_walk are the ones recorded
     unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 #else
     const bool prof = false;
@@ -2794,44 +2794,273 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_THREADS 256
 #define WK_WAVES (WK_THREADS / WAVE)
 #define WK_FREE 0xFFFFu
+#define WK_K 8                              // candidates kept per speculated dry order
+#define WK_JB 4                             // visit sequences of up to WK_JB * 64 clusters
+#define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
+#define SP_THREADS 1024
+#define SP_WAVES (SP_THREADS / WAVE)
 #ifdef WKDEBUG
 #define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
 #else
 #define WKCHK(cond, code, a, b2) do { } while (0)
 #endif
 
-__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto) {
+// one speculation record (ints): [seq_pad] visited cluster | orders of it before the dry order << 16 (0xFFFFFFFF past the end of
+// the sequence), [WK_K] candidates {cost << 16 | visit index << 8 | 64-entry chunk of the list, cluster << 16 | list position},
+// the number of candidates, pad
+__host__ __device__ inline int dfs_rec_ints(int seq_pad) { return seq_pad + 2 * WK_K + 2; }
+
+__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int seq_pad) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
-    return ((size_t)10 * C + 2 + ids + words + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)9 * C + 2 + ids + 2 * words + dfs_rec_ints(seq_pad) + ((size_t)V + 1) / 2) * sizeof(int);
+}
+__host__ __device__ inline size_t dfs_spec_lds_bytes(int C, int mto) { return ((size_t)3 * C + 1 + (size_t)(mto + 2) / 2 + mto) * sizeof(int); }
+
+template <bool U8>
+__device__ __forceinline__ int cost_elem(const char *base, unsigned elem) {
+    return U8 ? (int)*reinterpret_cast<const unsigned char *>(base + elem) : *reinterpret_cast<const int *>(base + (elem << 2));
+}
+__device__ __forceinline__ unsigned long long pick_mask(const unsigned long long (&m)[WK_JB], int jb) {
+    unsigned long long v = m[0];
+#pragma unroll
+    for (int x = 1; x < WK_JB; ++x) v = jb == x ? m[x] : v;
+    return v;
+}
+__device__ __forceinline__ int pick_lane(const int (&a)[WK_JB], int jb, int l) {
+    int v = rdlane(a[0], l);
+#pragma unroll
+    for (int x = 1; x < WK_JB; ++x) { const int u = rdlane(a[x], l); v = jb == x ? u : v; }
+    return v;
+}
+
+// dfs_scan: what one dry order (rank rho, pickup cluster pc / node pnode) would be served with, by ONE wavefront: the visit
+// sequence of FindServerVehicleFunction (:978-996), lane (j & 63) of batch (j >> 6) = j-th visited cluster; candidate clusters
+// (alive count > 0, derived from the list length, the own matches before the order and the steals so far) pruned by the cost
+// lower bound (Static.lbc) in two passes; eight (cluster, 64-entry chunk) gathers in flight; the WK_K best candidates in the
+// exact order of the reference (cost, visit order, list position: first strict minimum), as far as they are KNOWN to be the
+// best (each lane keeps its two smallest keys; clusters never scanned cost at least their bound).  The first is always exact.
+// LIVE: stamps / own matches / steals from the walk's LDS tables (state as it stands); else the state k_tick_rows left in
+// HBM (stamp = high half of the node word, own matches = min(orders, list length), no steals).
+template <bool U8, bool LIVE>
+__device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int tq0, int rho, int pc, int pnode,
+                                         const int *m0_l, const int *moff_l, const int *qend_l, const int *lm_l, const int *sc_l,
+                                         const int *cof_l, const unsigned short *rq_l, const unsigned short *st_l,
+                                         unsigned *cjk_out, int2 *list_out, int *nl_out) {
+    const int lane = lane_id();
+    const int C = S.C;
+    const int s0 = S.dfs_off[pc], n = S.dfs_off[pc + 1] - s0;
+    const int nb = (n + WAVE - 1) >> 6;
+    const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
+    int cj[WK_JB], lbj[WK_JB];
+    unsigned long long cand[WK_JB], scanned[WK_JB], live[WK_JB];
+#pragma unroll
+    for (int jb = 0; jb < WK_JB; ++jb) {
+        const int jx = jb * WAVE + lane;
+        cj[jb] = (jb < nb && jx < n) ? S.dfs_seq[s0 + jx] : 0;
+    }
+#pragma unroll
+    for (int jb = 0; jb < WK_JB; ++jb) {
+        const int jx = jb * WAVE + lane;
+        lbj[jb] = 0;
+        if (U8 && S.lbc != nullptr && jb < nb && jx < n) lbj[jb] = (int)S.lbc[(size_t)pnode * C + cj[jb]];
+    }
+    int lbmin = IMAX;
+#pragma unroll
+    for (int jb = 0; jb < WK_JB; ++jb) {
+        const int jx = jb * WAVE + lane;
+        cand[jb] = 0ull; scanned[jb] = 0ull; live[jb] = 0ull;
+        if (jb * WAVE < S.seq_pad) {
+            unsigned ck = 0xFFFFFFFFu;
+            int alive = 0;
+            if (jb < nb && jx < n) {
+                const int c = cj[jb];
+                const int qa = c == 0 ? tq0 : qend_l[c - 1];
+                const int qe = qend_l[c];
+                int lo = qa, hi = qe;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)rq_l[mid - tq0] < rho) lo = mid + 1; else hi = mid; }
+                const int kj = lo - qa;                     // orders of the cluster before this one
+                const int m0c = m0_l[c];
+                alive = LIVE ? m0c - min(kj, lm_l[c]) - sc_l[c] : m0c - min(kj, min(qe - qa, m0c));
+                ck = (unsigned)c | ((unsigned)kj << 16);
+            }
+            cjk_out[jx] = ck;
+            cand[jb] = ballot(alive > 0);
+            lbmin = min(lbmin, alive > 0 ? lbj[jb] : IMAX);
+        }
+    }
+    lbmin = wave_min_i32(lbmin);
+    int b1 = IMAX, b2 = IMAX, nval = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int bound = pass == 0 ? lbmin + PRUNE_DELTA : (wave_min_i32(b1) >> 16) + WK_SLACK;
+#pragma unroll
+        for (int jb = 0; jb < WK_JB; ++jb) {
+            live[jb] = cand[jb] & ~scanned[jb] & ballot(lbj[jb] <= bound);
+            scanned[jb] |= live[jb];
+        }
+        int jbc = -1, b = 0;
+        unsigned long long cl = 0ull;
+        while (true) {
+            // eight (cluster, 64-entry chunk) slots at a time: their stamps, the node words of the entries (HBM), then the
+            // cost gathers, then the two smallest keys of the lane
+            int in[8], seq[8], cst[8];
+            unsigned yv[8];
+            int cof[8];
+            bool any = false;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                in[k8] = 0; seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0;
+                while (cl == 0ull && jbc + 1 < nb) { ++jbc; cl = pick_mask(live, jbc); b = 0; }
+                if (cl != 0ull) {
+                    any = true;
+                    const int j = __ffsll((long long)cl) - 1;
+                    const int cc = pick_lane(cj, jbc, j);
+                    const int m0c = m0_l[cc];
+                    const int i = b * WAVE + lane;
+                    if (LIVE) {
+                        in[k8] = (i < m0c ? 1 : 0) & ((int)st_l[moff_l[cc] + min(i, m0c - 1)] > rho ? 1 : 0);
+                        if (in[k8]) yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
+                    } else if (i < m0c) {
+                        yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
+                        in[k8] = -1;                       // stamp still to be looked at
+                    }
+                    cof[k8] = cof_l[cc] & 0xFFFF;
+                    seq[k8] = (((jbc << 6) | j) << 8) | b;
+                    ++b;
+                    if (b * WAVE >= m0c) { b = 0; cl &= cl - 1ull; }
+                }
+            }
+            if (!any) break;
+            if (!LIVE) {
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const unsigned hi = yv[k8] >> 16;
+                    in[k8] = (in[k8] != 0 && (hi == 0u || (int)hi - 1 > rho)) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8)
+                cst[k8] = cost_elem<U8>(crow_b, (unsigned)(in[k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int v = in[k8] ? (cst[k8] << 16) | seq[k8] : IMAX;
+                nval += in[k8];
+                b2 = min(b2, max(b1, v));
+                b1 = min(b1, v);
+            }
+        }
+    }
+    // candidates of clusters never scanned cost at least their bound (and could win a tie on visit order)
+    int ulb = IMAX;
+#pragma unroll
+    for (int jb = 0; jb < WK_JB; ++jb) ulb = min(ulb, (((cand[jb] & ~scanned[jb]) >> lane) & 1ull) ? lbj[jb] : IMAX);
+    ulb = wave_min_i32(ulb);
+    int nl = 0, npop = 0;
+    for (int kk = 0; kk < WK_K; ++kk) {
+        const int m = wave_min_i32(b1);
+        if (m == IMAX) break;
+        if (kk > 0 && (m >> 16) >= ulb) break;
+        const int wl = __ffsll((long long)ballot(b1 == m)) - 1;       // lowest lane = lowest list position
+        const int j = (m >> 8) & 255, bb = m & 255;
+        const int cc = pick_lane(cj, j >> 6, j & 63);
+        if (lane == 0) list_out[kk] = make_int2(m, (int)(((unsigned)cc << 16) | (unsigned)(bb * WAVE + wl)));
+        ++nl;
+        bool stop = false;
+        if (lane == wl) { b1 = b2; b2 = IMAX; ++npop; stop = npop == 2 && nval > 2; }   // the lane's third smallest is unknown
+        if (ballot(stop)) break;
+    }
+    if (lane == 0) *nl_out = nl;
+}
+
+// k_dfs_spec: speculation for every order k_tick_rows left dry - one 1024-thread workgroup per replica, one wavefront per dry
+// order at a time - against the state k_tick_rows left.  Stamps only ever decrease during the walk (a steal or a re-pick of a
+// redo chain lowers the stamp of the entry it takes), so the vehicles alive for a dry order only become fewer between this
+// kernel and the order's turn in the walk: the candidate list stays a sorted prefix of a superset of them, and its first
+// entry still alive at that time IS the winner.
+template <bool U8>
+__global__ __launch_bounds__(SP_THREADS, 8) void k_dfs_spec(Static S, State D, int t) {
+    extern __shared__ int lds_dyn[];
+    const int C = S.C;
+    const int mto = S.max_tick_orders;
+    int *m0_l = lds_dyn;                  // [C]
+    int *qend_l = m0_l + C;               // [C]
+    int *cof_l = qend_l + C;              // [C+1] first cost column; during the set-up also the prefix of the dry counts
+    unsigned short *rq_l = reinterpret_cast<unsigned short *>(cof_l + C + 1);         // [mto] rank of sorted position
+    int *dq_l = cof_l + C + 1 + (mto + 2) / 2;                                         // [mto] dry orders: position - tq0 | cluster << 16
+    __shared__ int s_nd;
+    const int r = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const DayView dv = day_view(S, r);
+    if (t >= dv.T) return;
+    const int *bkt_off = dv.bkt_off;
+    const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
+    const int nord = tq1 - tq0;
+    for (int i = threadIdx.x; i < nord; i += SP_THREADS) rq_l[i] = (unsigned short)S.so_rank[tq0 + i];
+    for (int c = threadIdx.x; c < C; c += SP_THREADS) {
+        m0_l[c] = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
+        qend_l[c] = bkt_off[(size_t)t * C + c + 1];
+    }
+    __syncthreads();
+    if (wave == 0) {            // dry orders per cluster (everything behind a searching cluster's exhaustion point): exclusive prefix
+        int run = 0;
+        for (int base = 0; base < C; base += WAVE) {
+            const int c = base + lane;
+            int v = 0;
+            if (c < C && S.dfs_off[c + 1] > S.dfs_off[c]) {
+                const int no = qend_l[c] - (c == 0 ? tq0 : qend_l[c - 1]);
+                v = no - min(no, m0_l[c]);
+            }
+            int inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            if (c < C) cof_l[c] = run + inc - v;
+            run += rdlane(inc, WAVE - 1);
+        }
+        if (lane == 0) { cof_l[C] = run; s_nd = run; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += SP_THREADS) {
+        const int d0 = cof_l[c], d1 = cof_l[c + 1];
+        const int qe = qend_l[c];
+        for (int i = 0; i < d1 - d0; ++i) dq_l[d0 + i] = (qe - (d1 - d0) + i - tq0) | (c << 16);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += SP_THREADS) cof_l[c] = S.cl_off[c];
+    __syncthreads();
+    const int nd = s_nd;
+    const int stride = dfs_rec_ints(S.seq_pad);
+    for (int i = wave; i < nd; i += SP_WAVES) {
+        const int dq = dq_l[i];
+        const int qi = dq & 0xFFFF, pc = (int)((unsigned)dq >> 16);
+        unsigned *rec = S.spec + ((size_t)r * mto + qi) * stride;
+        dfs_scan<U8, false>(S, D, r, tq0, (int)rq_l[qi], pc, S.so_pnode[tq0 + qi], m0_l, nullptr, qend_l, nullptr, nullptr, cof_l, rq_l, nullptr,
+                            rec, reinterpret_cast<int2 *>(rec + S.seq_pad), reinterpret_cast<int *>(rec + S.seq_pad + 2 * WK_K));
+    }
 }
 
 template <bool U8>
 __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
-    auto cost_at = [](const char *base, unsigned elem) -> int {
-        return U8 ? (int)*reinterpret_cast<const unsigned char *>(base + elem) : *reinterpret_cast<const int *>(base + (elem << 2));
-    };
     const int C = S.C;
     const int mto = S.max_tick_orders;
     int *m0_l = lds_dyn;                  // [C] list length after Update (taken entries still inside); later the final length
     int *moff_l = lds_dyn + C;            // [C+1] start of the cluster's stamps
-    int *qdry_l = moff_l + C + 1;         // [C] first sorted position that is not an own-cluster order (dry from here / end)
-    int *qend_l = qdry_l + C;             // [C]
+    int *qend_l = moff_l + C + 1;         // [C]
     int *lm_l = qend_l + C;               // [C] own-cluster matches of the bucket (a prefix of its orders)
     int *sc_l = lm_l + C;                 // [C] vehicles stolen from the cluster so far
-    int *cur_l = sc_l + C;                // [C] cursor: first sorted position of the bucket whose rank is >= the dry order being served
-    int *cdA_l = cur_l + C;               // [C] n_c | first cost column << 11 | can search << 30
+    int *tk_l = sc_l + C;                 // [C] sum over the cluster's steals of min(orders of the bucket before the thief, own matches)
+    int *cdA_l = tk_l + C;                // [C] n_c | first cost column << 11 | can search << 30
     int *cdB_l = cdA_l + C;               // [C] start of the cluster's cost block
-    int *dfsoff_l = cdB_l + C;            // [C+1]
-    int *tab_l = dfsoff_l + C + 1;        // rank tables (u16), later the resolve counters
+    int *cof_l = cdB_l + C;               // [C+1] first cost column
+    int *tab_l = cof_l + C + 1;           // rank tables (u16), later the resolve counters
     const int ids_n = mto + 2 > RCNT * C ? mto + 2 : RCNT * C;
     unsigned short *rq_l = reinterpret_cast<unsigned short *>(tab_l);                 // [mto] rank of sorted position
     unsigned short *qr_l = rq_l + ((mto + 1) & ~1);                                   // [mto] sorted position of rank
     unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
     const int nwords = (mto + 31) / 32 + 1;
-    unsigned short *st_l = reinterpret_cast<unsigned short *>(dry_bits + nwords);     // [V] stamps
+    unsigned *spec_bits = dry_bits + nwords;                                          // dry orders k_dfs_spec has a record for
+    unsigned *slot_l = spec_bits + nwords;                                            // one record, for the scans done here
+    unsigned short *st_l = reinterpret_cast<unsigned short *>(slot_l + dfs_rec_ints(S.seq_pad));      // [V] stamps
     __shared__ int s_ev;                  // evaluations of the dry orders
     const int r = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
@@ -2858,13 +3087,10 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         const bool capable = S.dfs_off[c + 1] > S.dfs_off[c];
         cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (capable ? CAPABLE : 0);
         cdB_l[c] = U8 ? cd.z : cd.y;
-        dfsoff_l[c] = S.dfs_off[c];
-        if (c == 0) dfsoff_l[C] = S.dfs_off[C];
+        cof_l[c] = S.cl_off[c];
         const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
         const int m0 = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
-        const int own = min(q1 - q0, m0);                 // the fast kernel matched while vehicles remained
-        m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; cur_l[c] = q0;
-        qdry_l[c] = capable ? q0 + own : q1;
+        m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = min(q1 - q0, m0); sc_l[c] = 0; tk_l[c] = 0;   // the fast kernel matched while vehicles remained
     }
     for (int w = threadIdx.x; w < nwords; w += WK_THREADS) dry_bits[w] = 0u;
     if (threadIdx.x == 0) s_ev = 0;
@@ -2906,15 +3132,23 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     // dry orders: everything behind a searching cluster's exhaustion point
     for (int c = threadIdx.x; c < C; c += WK_THREADS) {
         if (!(cdA_l[c] & CAPABLE)) continue;
-        for (int q = qdry_l[c]; q < qend_l[c]; ++q) {
+        const int qa = c == 0 ? tq0 : qend_l[c - 1];
+        for (int q = qa + lm_l[c]; q < qend_l[c]; ++q) {
             const int rk = rq_l[q - tq0];
             atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
         }
     }
     __syncthreads();
+    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) spec_bits[w] = dry_bits[w];
+    __syncthreads();
     PROF_STAMP(0);
-    // ---- the walk: wavefront 0 alone (a chain of dependent steps - more wavefronts would only add barriers)
+    // ---- the walk: wavefront 0 serves the dry orders in id (rank) order from the records k_dfs_spec left - evaluations (the
+    //      alive counts of the visited clusters as they stand now, closed form), the first candidate still alive, the steal,
+    //      the redo chain - and scans itself only for an order whose kept candidates have all died, or that a redo made dry
     if (wave == 0) {
+        const int nbp = S.seq_pad >> 6;
+        const int stride = dfs_rec_ints(S.seq_pad);
+        const unsigned *spec_r = S.spec + (size_t)r * mto * stride;
         auto next_dry = [&](int from) -> int {
             int best = IMAX;
             for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
@@ -2924,221 +3158,165 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             }
             return wave_min_i32(best);
         };
-        auto cluster_of = [&](int q) -> int {
-            int pc = 0;
-            for (int base = 0; base < C; base += WAVE) {
-                const int c = base + lane;
-                const bool hit = c < C && q < qend_l[c] && (c == 0 || q >= qend_l[c - 1]);
-                const unsigned long long hb = ballot(hit);
-                if (hb) { pc = base + __ffsll((long long)hb) - 1; break; }
-            }
-            return pc;
+        auto cluster_of = [&](int q) -> int {       // first cluster whose bucket ends behind q
+            int lo = 0, hi = C - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (qend_l[mid] <= q) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        unsigned ck[WK_JB], ck_n[WK_JB];
+        int2 e = make_int2(IMAX, 0), e_n = make_int2(IMAX, 0);
+        int nl = 0, nl_n = 0;
+        auto load_rec = [&](int rho_x, unsigned (&ckx)[WK_JB], int2 &ex, int &nlx) {
+            // (records of orders a redo made dry do not exist: nlx = -1, scanned below)
+            const int qi = (int)qr_l[rho_x];
+            const bool has = (spec_bits[rho_x >> 5] >> (rho_x & 31)) & 1u;
+            const unsigned *rec = spec_r + (size_t)qi * stride;
+#pragma unroll
+            for (int jb = 0; jb < WK_JB; ++jb) ckx[jb] = (has && jb < nbp) ? rec[jb * WAVE + lane] : 0xFFFFFFFFu;
+            ex = make_int2(IMAX, 0);
+            if (has && lane < WK_K) ex = reinterpret_cast<const int2 *>(rec + S.seq_pad)[lane];
+            nlx = has ? (int)rec[S.seq_pad + 2 * WK_K] : -1;
         };
         int ev_acc = 0;
         int rho = next_dry(0);
-        int q = 0, pc = 0, pnode = 0;
-        if (rho != IMAX) { q = tq0 + (int)qr_l[rho]; pc = cluster_of(q); pnode = S.so_pnode[q]; }
+        if (rho != IMAX) load_rec(rho, ck, e, nl);
         while (rho != IMAX) {
-            WKCHK(rho < nord && q >= tq0 && q < tq1 && pc >= 0 && pc < C && pnode >= 0 && pnode < S.N, 1, rho, q);
-            const int s0 = dfsoff_l[pc], s1 = dfsoff_l[pc + 1];
-            const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
-            // the next dry order (as known now; a redo below may insert an earlier one): its pickup node travels meanwhile
+            const int q = tq0 + (int)qr_l[rho];
             int rho_n = next_dry(rho + 1);
-            int q_n = 0, pc_n = 0, pnode_n = 0;
-            if (rho_n != IMAX) { q_n = tq0 + (int)qr_l[rho_n]; pc_n = cluster_of(q_n); pnode_n = S.so_pnode[q_n]; }
-            int bhi = IMAX, blo = IMAX;
-            for (int jb = 0; s0 + jb < s1; jb += WAVE) {
-                const int sx = s0 + jb + lane;
-                const bool inseq = sx < s1;
-                const int cj = inseq ? S.dfs_seq[sx] : 0;
-                WKCHK(cj >= 0 && cj < C, 2, cj, sx);
-                int lbj = 0;
-                if (U8 && S.lbc != nullptr && inseq) lbj = (int)S.lbc[(size_t)pnode * C + cj];
-                // vehicles of cj alive at this order's time, without looking at them
-                int alive = 0, moj = 0, m0j = 0;
-                if (inseq) {
-                    const int qe = qend_l[cj];
-                    const int qa = cj == 0 ? tq0 : qend_l[cj - 1];
-                    int cur = cur_l[cj];
-                    while (cur < qe && (int)rq_l[cur - tq0] < rho) ++cur;
-                    cur_l[cj] = cur;
-                    m0j = m0_l[cj];
-                    moj = moff_l[cj];
-                    alive = m0j - min(cur - qa, lm_l[cj]) - sc_l[cj];
-                }
-                {   // :986-991 runs for every visited cluster
-                    const int rs = row_sum_i32(alive);
-                    ev_acc += rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
-                }
-                const bool cand_l = alive > 0;
-                const unsigned long long cand = ballot(cand_l);
-                const int lbmin = wave_min_i32(cand_l ? lbj : IMAX);
-                unsigned long long live = ballot(cand_l && lbj <= lbmin + PRUNE_DELTA);
-                const unsigned long long first_pass = live;
-                int b = 0, best = IMAX;
-                for (int pass = 0; pass < 2; ++pass) {
-                    if (pass == 1) {
-                        const int bc = wave_min_i32(best) >> 16;
-                        live = cand & ~first_pass & ballot(lbj <= bc);
-                        b = 0;
-                    }
-                    while (live != 0) {
-                        // eight (cluster, 64-entry chunk) slots at a time: their stamps (LDS), then the node words of the alive
-                        // entries (HBM), then the cost gathers, then the minima
-                        int in[8], seq[8], cst[8];
-                        unsigned yv[8];
-                        int cof[8];
+            if (rho_n != IMAX) load_rec(rho_n, ck_n, e_n, nl_n);        // travels while this order is served
+            if (nl < 0) {
+                dfs_scan<U8, true>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, lm_l, sc_l, cof_l, rq_l, st_l,
+                                   slot_l, reinterpret_cast<int2 *>(slot_l + S.seq_pad), reinterpret_cast<int *>(slot_l + S.seq_pad + 2 * WK_K));
+                wave_fence();
 #pragma unroll
-                        for (int k8 = 0; k8 < 8; ++k8) {
-                            in[k8] = 0; seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0;
-                            if (live != 0) {
-                                const int j = __ffsll((long long)live) - 1;
-                                const int m0c = rdlane(m0j, j), moc = rdlane(moj, j), cc = rdlane(cj, j);
-                                const int i = b * WAVE + lane;
-                                WKCHK(m0c > 0 && cc >= 0 && cc < C && moc + m0c <= S.V, 3, m0c, cc);
-                                in[k8] = (i < m0c ? 1 : 0) & ((int)st_l[moc + min(i, m0c - 1)] > rho ? 1 : 0);
-                                if (in[k8]) yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
-                                cof[k8] = (cdA_l[cc] >> 11) & 0xFFFF;
-                                seq[k8] = (j << 9) | b;
-                                ++b;
-                                if (b * WAVE >= m0c) { b = 0; live &= live - 1; }
-                            }
-                        }
-#pragma unroll
-                        for (int k8 = 0; k8 < 8; ++k8)
-                            cst[k8] = cost_at(crow_b, (unsigned)(in[k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
-#pragma unroll
-                        for (int k8 = 0; k8 < 8; ++k8)
-                            best = min(best, in[k8] ? (cst[k8] << 16) | seq[k8] : IMAX);
-                    }
-                }
-                const int wbest = wave_min_i32(best);
-                if (wbest != IMAX) {
-                    const int wl = __ffsll((long long)ballot(best == wbest)) - 1;       // lowest lane = lowest list position
-                    const int j = (wbest >> 9) & 63, bb = wbest & 511;
-                    const int hi = (wbest & ~0xFFFF) | (jb + j);
-                    const int lo = ((bb * WAVE + wl) << 16) | rdlane(cj, j);
-                    if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; }
-                }
+                for (int jb = 0; jb < WK_JB; ++jb) ck[jb] = jb < nbp ? slot_l[jb * WAVE + lane] : 0xFFFFFFFFu;
+                e = make_int2(IMAX, 0);
+                if (lane < WK_K) e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[lane];
+                nl = (int)slot_l[S.seq_pad + 2 * WK_K];
+#ifdef VDS_PROF
+                if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 4] += 1;
+#endif
             }
-            // ---- the winner
-            const int wc = bhi >> 16;
+            // :986-991 runs for every visited cluster: the alive counts as they stand NOW
+            int alive = 0;
+#pragma unroll
+            for (int jb = 0; jb < WK_JB; ++jb)
+                if (jb < nbp && ck[jb] != 0xFFFFFFFFu) {
+                    const int cjv = (int)(ck[jb] & 0xFFFFu), kv = (int)(ck[jb] >> 16);
+                    alive += m0_l[cjv] - min(kv, lm_l[cjv]) - sc_l[cjv];
+                }
+            const int rs = row_sum_i32(alive);
+            const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
+            ev_acc += tot;
             int2 res = make_int2(-1, -1);
-            if (bhi != IMAX && (long long)wc <= S.reject_threshold) {
-                const int wcl = blo & 0xFFFF, wpos = blo >> 16;
-                WKCHK(wcl < C && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
-                const int idx = moff_l[wcl] + wpos;
-                const int vst = (int)st_l[idx];
-                wave_fence();
-                if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] += 1; }
-                res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
-                wave_fence();
-                if (vst != (int)WK_FREE) {
-                    // the stolen vehicle had been taken later by an own-cluster order of wcl: redo that bucket from its first
-                    // order after this one, in sequence, against the entries that are free now
-                    const int cda = cdA_l[wcl];
-                    const int nc = cda & 2047, clo = (cda >> 11) & 0xFFFF;
-                    const bool capable = (cda & CAPABLE) != 0;
-                    const int boff = cdB_l[wcl];
-                    const int mo = moff_l[wcl], m0 = m0_l[wcl];
-                    const int qa = wcl == 0 ? tq0 : qend_l[wcl - 1];
-                    const int qy = cur_l[wcl];                          // first own position with rank > rho (cursor of this round)
-                    const int old_dry = qdry_l[wcl];
-                    WKCHK(qy >= qa && qy <= qend_l[wcl] && old_dry <= qend_l[wcl] && old_dry >= qa, 5, qy, old_dry);
-                    const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
-                    for (int i = lane; i < m0; i += WAVE) {
-                        const int st = (int)st_l[mo + i];
-                        if (st != (int)WK_FREE && st > rho) st_l[mo + i] = (unsigned short)WK_FREE;
-                    }
+            if (tot > 0) {
+                bool ok = lane < nl && (int)st_l[moff_l[(unsigned)e.y >> 16] + (e.y & 0xFFFF)] > rho;
+                unsigned long long okb = ballot(ok);
+                if (okb == 0ull) {             // every kept candidate has been taken since: scan again, on the state as it is
+                    dfs_scan<U8, true>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, lm_l, sc_l, cof_l, rq_l, st_l,
+                                       slot_l, reinterpret_cast<int2 *>(slot_l + S.seq_pad), reinterpret_cast<int *>(slot_l + S.seq_pad + 2 * WK_K));
                     wave_fence();
-                    int qq = qy;
-                    for (; qq < old_dry; ++qq) {
-                        const int pick = S.so_rec[qq].y & 0xFFFF;
-                        int lc = IMAX, lp = -1;
-                        for (int base = 0; base < m0; base += WAVE) {
-                            const int i = base + lane;
-                            if (i < m0 && (unsigned)st_l[mo + i] == WK_FREE) {
-                                const int loc = (int)(idle[i].y & 0xFFFF);
-                                const int cst = cost_at(blk_b, (unsigned)(boff + pick * nc + loc));
-                                if (lp < 0 || cst < lc) { lc = cst; lp = i; }
+                    e = make_int2(IMAX, 0);
+                    if (lane == 0) e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[0];
+                    okb = 1ull;
+#ifdef VDS_PROF
+                    if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 4] += 1;
+#endif
+                }
+                const int first = __ffsll((long long)okb) - 1;
+                const int key = rdlane(e.x, first), loc = rdlane(e.y, first);
+                const int wc = key >> 16;
+                if ((long long)wc <= S.reject_threshold) {
+                    const int wcl = (int)((unsigned)loc >> 16), wpos = loc & 0xFFFF;
+                    const int jw = (key >> 8) & 255;
+                    int kw = 0;
+#pragma unroll
+                    for (int jb = 0; jb < WK_JB; ++jb) { const int u = rdlane((int)(ck[jb] >> 16), jw & 63); kw = (jw >> 6) == jb ? u : kw; }
+                    WKCHK(wcl < C && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
+                    const int idx = moff_l[wcl] + wpos;
+                    int a = (int)st_l[idx];
+                    wave_fence();
+                    if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] += 1; tk_l[wcl] += min(kw, lm_l[wcl]); }
+                    res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
+                    wave_fence();
+#ifdef VDS_PROF
+                    if (prof && lane == 0) { g_prof[(size_t)pwave * 8 + 2] += 1; if (a != (int)WK_FREE) g_prof[(size_t)pwave * 8 + 3] += 1; }
+#endif
+                    if (a != (int)WK_FREE) {
+                        // the stolen vehicle had been taken later by own-cluster order a of wcl: that order picks again among the
+                        // entries alive at ITS time (stamp > a); if its new pick had been taken by a later order, that one picks
+                        // again, ... until a free entry is taken or the list is exhausted - then the last own match of the bucket
+                        // (only it can find nothing) turns dry.  Nobody else's choice changes.
+                        const int cda = cdA_l[wcl];
+                        const int nc = cda & 2047;
+                        const bool capable = (cda & CAPABLE) != 0;
+                        const int boff = cdB_l[wcl];
+                        const int mo = moff_l[wcl], m0 = m0_l[wcl];
+                        const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
+                        bool inserted = false;
+                        while (true) {
+                            const int y = tq0 + (int)qr_l[a];
+                            const int pick = S.so_rec[y].y & 0xFFFF;
+                            int lc = IMAX, lp = -1;
+                            for (int base = 0; base < m0; base += WAVE) {
+                                const int ii = base + lane;
+                                if (ii < m0 && (int)st_l[mo + ii] > a) {
+                                    const int lo2 = (int)(idle[ii].y & 0xFFFF);
+                                    const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
+                                    if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
+                                }
                             }
+                            const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
+                            if (minc == IMAX) {
+                                if (lane == 0) {
+                                    lm_l[wcl] -= 1;
+                                    if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
+                                    else out_r[y] = make_int2(-1, -1);
+                                }
+                                inserted = capable;
+                                break;
+                            }
+                            const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
+                            const int bst = (int)st_l[mo + minp];
+                            wave_fence();
+                            if (lane == 0) {
+                                st_l[mo + minp] = (unsigned short)a;
+                                out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
+                            }
+                            wave_fence();
+                            if (bst == (int)WK_FREE) break;
+                            a = bst;
                         }
-                        const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
-                        if (minc == IMAX) {
-                            if (capable) break;                         // exhausted: this order and the rest are dry
-                            if (lane == 0) out_r[qq] = make_int2(-1, -1);
-                            continue;
+                        if (inserted) {         // an order turned dry: it may come before the one already fetched
+                            wave_fence();
+                            const int rho_2 = next_dry(rho + 1);
+                            if (rho_2 != rho_n) { rho_n = rho_2; load_rec(rho_n, ck_n, e_n, nl_n); }
                         }
-                        const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
-                        if (lane == 0) {
-                            st_l[mo + minp] = rq_l[qq - tq0];
-                            out_r[qq] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
-                        }
-                        wave_fence();
                     }
-                    // own matches now: those before qy plus the re-matched ones (a prefix again)
-                    int nmatch = 0;
-                    for (int base = 0; base < m0; base += WAVE) {
-                        const int i = base + lane;
-                        const int st = i < m0 ? (int)st_l[mo + i] : (int)WK_FREE;
-                        nmatch += popc64(ballot(st != (int)WK_FREE && i < m0));
-                    }
-                    if (lane == 0) { lm_l[wcl] = nmatch - sc_l[wcl]; if (capable) qdry_l[wcl] = qq; }
-                    if (capable)
-                        for (int q2 = qq + lane; q2 < old_dry; q2 += WAVE) {
-                            const int rk = rq_l[q2 - tq0];
-                            atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
-                        }
-                    wave_fence();
-                    const int rho_2 = next_dry(rho + 1);
-                    if (rho_2 != rho_n) { rho_n = rho_2; q_n = tq0 + (int)qr_l[rho_n]; pc_n = cluster_of(q_n); pnode_n = S.so_pnode[q_n]; }
                 }
             }
             if (lane == 0) out_r[q] = res;
 #ifdef VDS_PROF
             if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
 #endif
-            rho = rho_n; q = q_n; pc = pc_n; pnode = pnode_n;
+            rho = rho_n; e = e_n; nl = nl_n;
+#pragma unroll
+            for (int jb = 0; jb < WK_JB; ++jb) ck[jb] = ck_n[jb];
         }
         if (lane == 0) s_ev = ev_acc;
     }
     __syncthreads();
     PROF_STAMP(1);
-    // ---- evaluations of the own-cluster orders and the final list lengths, from the final stamps: one 8-lane group per
-    //      bucket.  Order of rank p looked at the entries with stamp >= p (free = 0xFFFF; stolen entries carry the thief's rank).
-    {
-        const int gl = lane & (GRP - 1), gw = lane / GRP;
-        for (int c0 = wave * GRPS_WAVE; c0 < C; c0 += WK_WAVES * GRPS_WAVE) {
-            const int c = c0 + gw;
-            const bool has = c < C;
-            const int cc = has ? c : 0;
-            const int mo = moff_l[cc], m0 = has ? m0_l[cc] : 0;
-            const int qa = has ? (cc == 0 ? tq0 : qend_l[cc - 1]) : 0;
-            const int qb2 = has ? qdry_l[cc] : 0;                       // own-cluster orders: [qa, qb2)
-            int ev = 0, fin = 0;
-            int mx = m0;
-            mx = max(mx, dpp_mov<0x4E, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x141, 0xF>(mx, mx)); mx = max(mx, dpp_mov<0x140, 0xF>(mx, mx));
-            const int mmaxw = max(max(rdlane(mx, 0), rdlane(mx, 16)), max(rdlane(mx, 32), rdlane(mx, 48)));
-            int nq = qb2 - qa;
-            nq = max(nq, dpp_mov<0x4E, 0xF>(nq, nq)); nq = max(nq, dpp_mov<0x141, 0xF>(nq, nq)); nq = max(nq, dpp_mov<0x140, 0xF>(nq, nq));
-            const int nqmax = max(max(rdlane(nq, 0), rdlane(nq, 16)), max(rdlane(nq, 32), rdlane(nq, 48)));
-            for (int i0 = 0; i0 < mmaxw; i0 += GRP) {
-                const int i = i0 + gl;
-                const bool ok = i < m0;
-                const int st = ok ? (int)st_l[mo + i] : -1;
-                fin += (ok && st == (int)WK_FREE) ? 1 : 0;
-                for (int j = 0; j < nqmax; ++j) {
-                    const int qq = qa + j;
-                    const int rk = qq < qb2 ? (int)rq_l[qq - tq0] : IMAX;
-                    ev += st >= rk ? 1 : 0;
-                }
-            }
-            ev += dpp_mov<0xB1, 0xF>(ev, ev); ev += dpp_mov<0x4E, 0xF>(ev, ev); ev += dpp_mov<0x141, 0xF>(ev, ev);
-            fin += dpp_mov<0xB1, 0xF>(fin, fin); fin += dpp_mov<0x4E, 0xF>(fin, fin); fin += dpp_mov<0x141, 0xF>(fin, fin);
-            if (has && gl == 0) { lm_l[c] = ev; sc_l[c] = fin; }       // (lm / sc are dead now: reused as evaluations / final length)
-        }
+    // ---- evaluations of the own-cluster orders and the final list lengths, closed form: the own matches of a bucket are its
+    //      first n orders; the i-th looked at m0 - i - (steals before it) entries, and a steal that came after k of the
+    //      bucket's orders is seen by the n - min(k, n) own matches behind it (tk = sum of min(k, n) over the steals)
+    for (int c = threadIdx.x; c < C; c += WK_THREADS) {
+        const int nm = lm_l[c], m0 = m0_l[c], sc = sc_l[c];
+        const int ev = nm * m0 - (nm * (nm - 1)) / 2 - (sc * nm - tk_l[c]);
+        lm_l[c] = ev; sc_l[c] = m0 - nm - sc;                          // (lm / sc are dead now: reused as evaluations / final length)
     }
     __syncthreads();
+    PROF_STAMP(5);
     // ---- commit: vehicle ids, arrivals (:954-960), counters (the rank tables are dead now)
     int *rc_l = tab_l;
     for (int i = threadIdx.x; i < RCNT * C; i += WK_THREADS) rc_l[i] = 0;
@@ -3527,9 +3705,12 @@ int replica3_prepare() {      // opt in to more than 64 KB of dynamic LDS per wo
     return (a == hipSuccess && b == hipSuccess) ? 0 : -1;
 }
 
-size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders); }
+size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, S.seq_pad); }
+size_t dfs_spec_lds(const Static &S) { return dfs_spec_lds_bytes(S.C, S.max_tick_orders); }
+size_t dfs_spec_ints(const Static &S) { return (size_t)S.R * S.max_tick_orders * dfs_rec_ints(S.seq_pad); }
 
-// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
+// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), the
+// speculation for the orders it left dry, then the walk
 void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : 1;
@@ -3538,10 +3719,12 @@ void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hi
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);
         if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
         else hipLaunchKernelGGL((k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        hipLaunchKernelGGL(k_dfs_spec<true>, dim3(S.R), dim3(SP_THREADS), dfs_spec_lds(S), st, S, D, t);
         hipLaunchKernelGGL(k_dfs_walk<true>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     } else {
         if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
         else hipLaunchKernelGGL((k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        hipLaunchKernelGGL(k_dfs_spec<false>, dim3(S.R), dim3(SP_THREADS), dfs_spec_lds(S), st, S, D, t);
         hipLaunchKernelGGL(k_dfs_walk<false>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     }
 }
