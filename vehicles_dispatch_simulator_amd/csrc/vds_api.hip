@@ -23,8 +23,6 @@ void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
 size_t dfs_walk_lds(const Static &);
-size_t dfs_spec_lds(const Static &);
-size_t dfs_spec_ints(const Static &);
 size_t replica3_lds(const Static &);
 int replica3_prepare();
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
@@ -710,16 +708,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
                        (Z.n_days <= 1 || Z.chunk_days) && Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
-                       dfs_walk_lds(Z) + 1024 <= 64 * 1024 && dfs_spec_lds(Z) + 1024 <= 64 * 1024 &&
-                       dfs_spec_ints(Z) * sizeof(int) <= ((size_t)16 << 30);
-        if (h->hybrid_ok) {         // speculation records, one per (replica, order of a slot)
-            h->alloc_sink = &h->order_allocs;
-            unsigned *sp = nullptr;
-            rc = dev_alloc(h, &sp, dfs_spec_ints(Z));
-            h->alloc_sink = nullptr;
-            if (rc) return rc;
-            h->S.spec = sp;
-        }
+                       dfs_walk_lds(Z) + 1024 <= 64 * 1024;
         h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
                      replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }

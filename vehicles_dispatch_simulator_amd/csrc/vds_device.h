@@ -107,7 +107,6 @@ struct Static {
     const int *tick_off;             // [T+1] into ord_q
     const int *ord_q;                // [Oq] processed orders in id order -> q
     const int *so_pnode;             // [Oq] pickup NODE of each sorted order (row of the cost matrix the DFS scans)
-    unsigned *spec;                  // [R][max_tick_orders] speculation records of the hybrid neighbour-search tick (dfs_rec_ints each)
     int seq_pad;                     // longest visit sequence, rounded up to a multiple of 64
     const int *so_rank;              // [Oq] rank of the sorted position inside its slot, in id order (= cursor order of :912-973)
     int max_tick_orders;             // most orders processed in one tick

@@ -2794,28 +2794,26 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_THREADS 256
 #define WK_WAVES (WK_THREADS / WAVE)
 #define WK_FREE 0xFFFFu
-#define WK_K 8                              // candidates kept per speculated dry order
+#define WK_K 8                              // candidates kept per scanned dry order
 #define WK_JB 4                             // visit sequences of up to WK_JB * 64 clusters
+#define WK_NS 4                             // records the scanning wavefronts may be ahead of the walk
 #define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
-#define SP_THREADS 1024
-#define SP_WAVES (SP_THREADS / WAVE)
 #ifdef WKDEBUG
 #define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
 #else
 #define WKCHK(cond, code, a, b2) do { } while (0)
 #endif
 
-// one speculation record (ints): [seq_pad] visited cluster | orders of it before the dry order << 16 (0xFFFFFFFF past the end of
-// the sequence), [WK_K] candidates {cost << 16 | visit index << 8 | 64-entry chunk of the list, cluster << 16 | list position},
+// one scan record (ints): [seq_pad] visited cluster | orders of it before the dry order << 16 (0xFFFFFFFF past the end of the
+// sequence), [WK_K] candidates {cost << 16 | visit index << 8 | 64-entry chunk of the list, cluster << 16 | list position},
 // the number of candidates, pad
 __host__ __device__ inline int dfs_rec_ints(int seq_pad) { return seq_pad + 2 * WK_K + 2; }
 
 __host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int seq_pad) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
-    return ((size_t)9 * C + 2 + ids + 2 * words + dfs_rec_ints(seq_pad) + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)8 * C + 1 + ids + words + (1 + WK_NS) * dfs_rec_ints(seq_pad) + ((size_t)V + 1) / 2) * sizeof(int);
 }
-__host__ __device__ inline size_t dfs_spec_lds_bytes(int C, int mto) { return ((size_t)3 * C + 1 + (size_t)(mto + 2) / 2 + mto) * sizeof(int); }
 
 template <bool U8>
 __device__ __forceinline__ int cost_elem(const char *base, unsigned elem) {
@@ -2833,25 +2831,31 @@ __device__ __forceinline__ int pick_lane(const int (&a)[WK_JB], int jb, int l) {
     for (int x = 1; x < WK_JB; ++x) { const int u = rdlane(a[x], l); v = jb == x ? u : v; }
     return v;
 }
+__device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_acquire(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_release(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // dfs_scan: what one dry order (rank rho, pickup cluster pc / node pnode) would be served with, by ONE wavefront: the visit
 // sequence of FindServerVehicleFunction (:978-996), lane (j & 63) of batch (j >> 6) = j-th visited cluster; candidate clusters
-// (alive count > 0, derived from the list length, the own matches before the order and the steals so far) pruned by the cost
-// lower bound (Static.lbc) in two passes; eight (cluster, 64-entry chunk) gathers in flight; the WK_K best candidates in the
-// exact order of the reference (cost, visit order, list position: first strict minimum), as far as they are KNOWN to be the
-// best (each lane keeps its two smallest keys; clusters never scanned cost at least their bound).  The first is always exact.
-// LIVE: stamps / own matches / steals from the walk's LDS tables (state as it stands); else the state k_tick_rows left in
-// HBM (stamp = high half of the node word, own matches = min(orders, list length), no steals).
-template <bool U8, bool LIVE>
+// (alive count > 0, derived from the list length, the own matches before the order and the steals so far: ls_l = own matches
+// << 16 | steals, one word so that a reader sees a consistent pair) pruned by the cost lower bound (Static.lbc) in two passes;
+// eight (cluster, 64-entry chunk) gathers in flight; the WK_K best candidates in the exact order of the reference (cost,
+// visit order, list position: first strict minimum), as far as they are KNOWN to be the best (each lane keeps its two smallest
+// keys; clusters never scanned cost at least their bound).  The first is always exact.
+// The scan may run WHILE the walk serves earlier dry orders: stamps only ever decrease (a steal or a re-pick of a redo chain
+// lowers the stamp of the entry it takes) and ls_l is published once per served order, so whatever mixture of states the scan
+// reads, the vehicles it considers are a superset of those alive when the order's turn comes, and the list a sorted prefix of
+// that superset: its first entry still alive at that time IS the winner.
+template <bool U8>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int tq0, int rho, int pc, int pnode,
-                                         const int *m0_l, const int *moff_l, const int *qend_l, const int *lm_l, const int *sc_l,
-                                         const int *cof_l, const unsigned short *rq_l, const unsigned short *st_l,
-                                         unsigned *cjk_out, int2 *list_out, int *nl_out) {
+                                         const int *m0_l, const int *moff_l, const int *qend_l, const int *ls_l, const int *cda_l,
+                                         const unsigned short *rq_l, const unsigned short *st_l, unsigned *rec) {
     const int lane = lane_id();
     const int C = S.C;
     const int s0 = S.dfs_off[pc], n = S.dfs_off[pc + 1] - s0;
     const int nb = (n + WAVE - 1) >> 6;
     const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
+    int2 *list_out = reinterpret_cast<int2 *>(rec + S.seq_pad);
     int cj[WK_JB], lbj[WK_JB];
     unsigned long long cand[WK_JB], scanned[WK_JB], live[WK_JB];
 #pragma unroll
@@ -2876,15 +2880,14 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
             if (jb < nb && jx < n) {
                 const int c = cj[jb];
                 const int qa = c == 0 ? tq0 : qend_l[c - 1];
-                const int qe = qend_l[c];
-                int lo = qa, hi = qe;
+                int lo = qa, hi = qend_l[c];
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)rq_l[mid - tq0] < rho) lo = mid + 1; else hi = mid; }
                 const int kj = lo - qa;                     // orders of the cluster before this one
-                const int m0c = m0_l[c];
-                alive = LIVE ? m0c - min(kj, lm_l[c]) - sc_l[c] : m0c - min(kj, min(qe - qa, m0c));
+                const int ls = lds_load(&ls_l[c]);
+                alive = m0_l[c] - min(kj, ls >> 16) - (ls & 0xFFFF);
                 ck = (unsigned)c | ((unsigned)kj << 16);
             }
-            cjk_out[jx] = ck;
+            rec[jx] = ck;
             cand[jb] = ballot(alive > 0);
             lbmin = min(lbmin, alive > 0 ? lbj[jb] : IMAX);
         }
@@ -2901,8 +2904,8 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
         int jbc = -1, b = 0;
         unsigned long long cl = 0ull;
         while (true) {
-            // eight (cluster, 64-entry chunk) slots at a time: their stamps, the node words of the entries (HBM), then the
-            // cost gathers, then the two smallest keys of the lane
+            // eight (cluster, 64-entry chunk) slots at a time: their stamps (LDS), the node words of the entries that look
+            // alive (HBM), then the cost gathers, then the two smallest keys of the lane
             int in[8], seq[8], cst[8];
             unsigned yv[8];
             int cof[8];
@@ -2917,27 +2920,15 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                     const int cc = pick_lane(cj, jbc, j);
                     const int m0c = m0_l[cc];
                     const int i = b * WAVE + lane;
-                    if (LIVE) {
-                        in[k8] = (i < m0c ? 1 : 0) & ((int)st_l[moff_l[cc] + min(i, m0c - 1)] > rho ? 1 : 0);
-                        if (in[k8]) yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
-                    } else if (i < m0c) {
-                        yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
-                        in[k8] = -1;                       // stamp still to be looked at
-                    }
-                    cof[k8] = cof_l[cc] & 0xFFFF;
+                    in[k8] = (i < m0c ? 1 : 0) & ((int)st_l[moff_l[cc] + min(i, m0c - 1)] > rho ? 1 : 0);
+                    if (in[k8]) yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
+                    cof[k8] = (cda_l[cc] >> 11) & 0xFFFF;
                     seq[k8] = (((jbc << 6) | j) << 8) | b;
                     ++b;
                     if (b * WAVE >= m0c) { b = 0; cl &= cl - 1ull; }
                 }
             }
             if (!any) break;
-            if (!LIVE) {
-#pragma unroll
-                for (int k8 = 0; k8 < 8; ++k8) {
-                    const unsigned hi = yv[k8] >> 16;
-                    in[k8] = (in[k8] != 0 && (hi == 0u || (int)hi - 1 > rho)) ? 1 : 0;
-                }
-            }
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8)
                 cst[k8] = cost_elem<U8>(crow_b, (unsigned)(in[k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
@@ -2969,72 +2960,7 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
         if (lane == wl) { b1 = b2; b2 = IMAX; ++npop; stop = npop == 2 && nval > 2; }   // the lane's third smallest is unknown
         if (ballot(stop)) break;
     }
-    if (lane == 0) *nl_out = nl;
-}
-
-// k_dfs_spec: speculation for every order k_tick_rows left dry - one 1024-thread workgroup per replica, one wavefront per dry
-// order at a time - against the state k_tick_rows left.  Stamps only ever decrease during the walk (a steal or a re-pick of a
-// redo chain lowers the stamp of the entry it takes), so the vehicles alive for a dry order only become fewer between this
-// kernel and the order's turn in the walk: the candidate list stays a sorted prefix of a superset of them, and its first
-// entry still alive at that time IS the winner.
-template <bool U8>
-__global__ __launch_bounds__(SP_THREADS, 8) void k_dfs_spec(Static S, State D, int t) {
-    extern __shared__ int lds_dyn[];
-    const int C = S.C;
-    const int mto = S.max_tick_orders;
-    int *m0_l = lds_dyn;                  // [C]
-    int *qend_l = m0_l + C;               // [C]
-    int *cof_l = qend_l + C;              // [C+1] first cost column; during the set-up also the prefix of the dry counts
-    unsigned short *rq_l = reinterpret_cast<unsigned short *>(cof_l + C + 1);         // [mto] rank of sorted position
-    int *dq_l = cof_l + C + 1 + (mto + 2) / 2;                                         // [mto] dry orders: position - tq0 | cluster << 16
-    __shared__ int s_nd;
-    const int r = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
-    const DayView dv = day_view(S, r);
-    if (t >= dv.T) return;
-    const int *bkt_off = dv.bkt_off;
-    const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
-    const int nord = tq1 - tq0;
-    for (int i = threadIdx.x; i < nord; i += SP_THREADS) rq_l[i] = (unsigned short)S.so_rank[tq0 + i];
-    for (int c = threadIdx.x; c < C; c += SP_THREADS) {
-        m0_l[c] = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
-        qend_l[c] = bkt_off[(size_t)t * C + c + 1];
-    }
-    __syncthreads();
-    if (wave == 0) {            // dry orders per cluster (everything behind a searching cluster's exhaustion point): exclusive prefix
-        int run = 0;
-        for (int base = 0; base < C; base += WAVE) {
-            const int c = base + lane;
-            int v = 0;
-            if (c < C && S.dfs_off[c + 1] > S.dfs_off[c]) {
-                const int no = qend_l[c] - (c == 0 ? tq0 : qend_l[c - 1]);
-                v = no - min(no, m0_l[c]);
-            }
-            int inc = v;
-            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
-            if (c < C) cof_l[c] = run + inc - v;
-            run += rdlane(inc, WAVE - 1);
-        }
-        if (lane == 0) { cof_l[C] = run; s_nd = run; }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += SP_THREADS) {
-        const int d0 = cof_l[c], d1 = cof_l[c + 1];
-        const int qe = qend_l[c];
-        for (int i = 0; i < d1 - d0; ++i) dq_l[d0 + i] = (qe - (d1 - d0) + i - tq0) | (c << 16);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += SP_THREADS) cof_l[c] = S.cl_off[c];
-    __syncthreads();
-    const int nd = s_nd;
-    const int stride = dfs_rec_ints(S.seq_pad);
-    for (int i = wave; i < nd; i += SP_WAVES) {
-        const int dq = dq_l[i];
-        const int qi = dq & 0xFFFF, pc = (int)((unsigned)dq >> 16);
-        unsigned *rec = S.spec + ((size_t)r * mto + qi) * stride;
-        dfs_scan<U8, false>(S, D, r, tq0, (int)rq_l[qi], pc, S.so_pnode[tq0 + qi], m0_l, nullptr, qend_l, nullptr, nullptr, cof_l, rq_l, nullptr,
-                            rec, reinterpret_cast<int2 *>(rec + S.seq_pad), reinterpret_cast<int *>(rec + S.seq_pad + 2 * WK_K));
-    }
+    if (lane == 0) rec[S.seq_pad + 2 * WK_K] = (unsigned)nl;
 }
 
 template <bool U8>
@@ -3048,20 +2974,23 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     int *qend_l = moff_l + C + 1;         // [C]
     int *lm_l = qend_l + C;               // [C] own-cluster matches of the bucket (a prefix of its orders)
     int *sc_l = lm_l + C;                 // [C] vehicles stolen from the cluster so far
-    int *tk_l = sc_l + C;                 // [C] sum over the cluster's steals of min(orders of the bucket before the thief, own matches)
+    int *ls_l = sc_l + C;                 // [C] lm << 16 | sc as of the last served dry order (what the scanning wavefronts read)
+    int *tk_l = ls_l + C;                 // [C] sum over the cluster's steals of min(orders of the bucket before the thief, own matches)
     int *cdA_l = tk_l + C;                // [C] n_c | first cost column << 11 | can search << 30
-    int *cdB_l = cdA_l + C;               // [C] start of the cluster's cost block
-    int *cof_l = cdB_l + C;               // [C+1] first cost column
-    int *tab_l = cof_l + C + 1;           // rank tables (u16), later the resolve counters
+    int *tab_l = cdA_l + C;               // rank tables (u16), later the resolve counters
     const int ids_n = mto + 2 > RCNT * C ? mto + 2 : RCNT * C;
     unsigned short *rq_l = reinterpret_cast<unsigned short *>(tab_l);                 // [mto] rank of sorted position
     unsigned short *qr_l = rq_l + ((mto + 1) & ~1);                                   // [mto] sorted position of rank
     unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
     const int nwords = (mto + 31) / 32 + 1;
-    unsigned *spec_bits = dry_bits + nwords;                                          // dry orders k_dfs_spec has a record for
-    unsigned *slot_l = spec_bits + nwords;                                            // one record, for the scans done here
-    unsigned short *st_l = reinterpret_cast<unsigned short *>(slot_l + dfs_rec_ints(S.seq_pad));      // [V] stamps
+    unsigned *slot_l = dry_bits + nwords;                                             // one record, for the scans wavefront 0 does itself
+    unsigned *pool_l = slot_l + dfs_rec_ints(S.seq_pad);                              // WK_NS records, filled by wavefronts 1..3
+    unsigned short *st_l = reinterpret_cast<unsigned short *>(pool_l + WK_NS * dfs_rec_ints(S.seq_pad));      // [V] stamps
     __shared__ int s_ev;                  // evaluations of the dry orders
+    __shared__ int s_cursor;              // dry orders of rank < cursor have been claimed by a scanning wavefront (or passed over)
+    __shared__ int s_done;                // the walk is over
+    __shared__ int s_tag[WK_NS];          // rank of the dry order pool record s belongs to
+    __shared__ int s_state[WK_NS];        // 0 free, 1 being filled, 2 ready
     const int r = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const DayView dv = day_view(S, r);
@@ -3086,14 +3015,14 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         const int4 cd = S.cdesc[c];
         const bool capable = S.dfs_off[c + 1] > S.dfs_off[c];
         cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (capable ? CAPABLE : 0);
-        cdB_l[c] = U8 ? cd.z : cd.y;
-        cof_l[c] = S.cl_off[c];
         const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
         const int m0 = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
-        m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = min(q1 - q0, m0); sc_l[c] = 0; tk_l[c] = 0;   // the fast kernel matched while vehicles remained
+        const int own = min(q1 - q0, m0);                 // the fast kernel matched while vehicles remained
+        m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; ls_l[c] = own << 16; tk_l[c] = 0;
     }
     for (int w = threadIdx.x; w < nwords; w += WK_THREADS) dry_bits[w] = 0u;
-    if (threadIdx.x == 0) s_ev = 0;
+    if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; }
+    if (threadIdx.x < WK_NS) { s_tag[threadIdx.x] = -1; s_state[threadIdx.x] = 0; }
     __syncthreads();
     if (wave == 0) {            // exclusive prefix of the list lengths
         int run = 0;
@@ -3139,63 +3068,71 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         }
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) spec_bits[w] = dry_bits[w];
-    __syncthreads();
     PROF_STAMP(0);
-    // ---- the walk: wavefront 0 serves the dry orders in id (rank) order from the records k_dfs_spec left - evaluations (the
-    //      alive counts of the visited clusters as they stand now, closed form), the first candidate still alive, the steal,
-    //      the redo chain - and scans itself only for an order whose kept candidates have all died, or that a redo made dry
+    // ---- the walk.  Wavefront 0 serves the dry orders in id (rank) order: evaluations (the alive counts of the visited clusters
+    //      as they stand, closed form), the first candidate of the order's record still alive, the steal, the redo chain.  The
+    //      records are made by wavefronts 1..3, which scan the dry orders up to WK_NS ahead of the walk, in rank order, claiming
+    //      them through s_cursor (dfs_scan: why a scan against a moving state is exact).  Wavefront 0 scans itself only when
+    //      every kept candidate has died, or when a redo made an order dry that the cursor had already passed.
+    const int stride = dfs_rec_ints(S.seq_pad);
+    auto next_dry = [&](int from) -> int {
+        int best = IMAX;
+        for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
+            unsigned bits = (unsigned)lds_load(reinterpret_cast<const int *>(&dry_bits[w]));
+            if (w == (from >> 5)) bits &= 0xFFFFFFFFu << (from & 31);
+            if (bits != 0u) { best = w * 32 + __ffs((int)bits) - 1; break; }
+        }
+        return wave_min_i32(best);
+    };
+    auto cluster_of = [&](int q) -> int {       // first cluster whose bucket ends behind q
+        int lo = 0, hi = C - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (qend_l[mid] <= q) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
     if (wave == 0) {
         const int nbp = S.seq_pad >> 6;
-        const int stride = dfs_rec_ints(S.seq_pad);
-        const unsigned *spec_r = S.spec + (size_t)r * mto * stride;
-        auto next_dry = [&](int from) -> int {
-            int best = IMAX;
-            for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
-                unsigned bits = dry_bits[w];
-                if (w == (from >> 5)) bits &= 0xFFFFFFFFu << (from & 31);
-                if (bits != 0u) { best = w * 32 + __ffs((int)bits) - 1; break; }
-            }
-            return wave_min_i32(best);
-        };
-        auto cluster_of = [&](int q) -> int {       // first cluster whose bucket ends behind q
-            int lo = 0, hi = C - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (qend_l[mid] <= q) lo = mid + 1; else hi = mid; }
-            return lo;
-        };
-        unsigned ck[WK_JB], ck_n[WK_JB];
-        int2 e = make_int2(IMAX, 0), e_n = make_int2(IMAX, 0);
-        int nl = 0, nl_n = 0;
-        auto load_rec = [&](int rho_x, unsigned (&ckx)[WK_JB], int2 &ex, int &nlx) {
-            // (records of orders a redo made dry do not exist: nlx = -1, scanned below)
-            const int qi = (int)qr_l[rho_x];
-            const bool has = (spec_bits[rho_x >> 5] >> (rho_x & 31)) & 1u;
-            const unsigned *rec = spec_r + (size_t)qi * stride;
-#pragma unroll
-            for (int jb = 0; jb < WK_JB; ++jb) ckx[jb] = (has && jb < nbp) ? rec[jb * WAVE + lane] : 0xFFFFFFFFu;
-            ex = make_int2(IMAX, 0);
-            if (has && lane < WK_K) ex = reinterpret_cast<const int2 *>(rec + S.seq_pad)[lane];
-            nlx = has ? (int)rec[S.seq_pad + 2 * WK_K] : -1;
-        };
+        unsigned ck[WK_JB];
+        int2 e = make_int2(IMAX, 0);
+        int nl = 0;
         int ev_acc = 0;
         int rho = next_dry(0);
-        if (rho != IMAX) load_rec(rho, ck, e, nl);
         while (rho != IMAX) {
             const int q = tq0 + (int)qr_l[rho];
-            int rho_n = next_dry(rho + 1);
-            if (rho_n != IMAX) load_rec(rho_n, ck_n, e_n, nl_n);        // travels while this order is served
-            if (nl < 0) {
-                dfs_scan<U8, true>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, lm_l, sc_l, cof_l, rq_l, st_l,
-                                   slot_l, reinterpret_cast<int2 *>(slot_l + S.seq_pad), reinterpret_cast<int *>(slot_l + S.seq_pad + 2 * WK_K));
+            // the order's record: in the pool (ready, or being filled), still to be claimed (wait), or passed over (scan here)
+            const unsigned *rec = nullptr;
+            int slot = -1;
+            while (true) {
+                const int cur = lds_acquire(&s_cursor);
+                // (a claim publishes its tag before it moves the cursor, and withdraws it if another wavefront moved it first)
+                const int tg = lane < WK_NS ? lds_load(&s_tag[lane]) : -1;
+                const unsigned long long hit = ballot(tg == rho);
+                if (hit != 0ull) {
+                    const int s = __ffsll((long long)hit) - 1;
+                    const int stt = lds_acquire(&s_state[s]);
+                    if (stt == 2 && lds_load(&s_tag[s]) == rho) { slot = s; break; }
+                } else if (cur > rho) {
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (slot >= 0) {
+                rec = pool_l + slot * stride;
+            } else {
+                dfs_scan<U8>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, ls_l, cdA_l, rq_l, st_l, slot_l);
                 wave_fence();
-#pragma unroll
-                for (int jb = 0; jb < WK_JB; ++jb) ck[jb] = jb < nbp ? slot_l[jb * WAVE + lane] : 0xFFFFFFFFu;
-                e = make_int2(IMAX, 0);
-                if (lane < WK_K) e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[lane];
-                nl = (int)slot_l[S.seq_pad + 2 * WK_K];
+                rec = slot_l;
 #ifdef VDS_PROF
                 if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 4] += 1;
 #endif
+            }
+#pragma unroll
+            for (int jb = 0; jb < WK_JB; ++jb) ck[jb] = jb < nbp ? rec[jb * WAVE + lane] : 0xFFFFFFFFu;
+            e = make_int2(IMAX, 0);
+            if (lane < WK_K) e = reinterpret_cast<const int2 *>(rec + S.seq_pad)[lane];
+            nl = (int)rec[S.seq_pad + 2 * WK_K];
+            if (slot >= 0) {
+                wave_fence();
+                if (lane == 0) { s_tag[slot] = -1; lds_release(&s_state[slot], 0); }
             }
             // :986-991 runs for every visited cluster: the alive counts as they stand NOW
             int alive = 0;
@@ -3213,8 +3150,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 bool ok = lane < nl && (int)st_l[moff_l[(unsigned)e.y >> 16] + (e.y & 0xFFFF)] > rho;
                 unsigned long long okb = ballot(ok);
                 if (okb == 0ull) {             // every kept candidate has been taken since: scan again, on the state as it is
-                    dfs_scan<U8, true>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, lm_l, sc_l, cof_l, rq_l, st_l,
-                                       slot_l, reinterpret_cast<int2 *>(slot_l + S.seq_pad), reinterpret_cast<int *>(slot_l + S.seq_pad + 2 * WK_K));
+                    dfs_scan<U8>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, ls_l, cdA_l, rq_l, st_l, slot_l);
                     wave_fence();
                     e = make_int2(IMAX, 0);
                     if (lane == 0) e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[0];
@@ -3235,8 +3171,10 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                     WKCHK(wcl < C && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
                     const int idx = moff_l[wcl] + wpos;
                     int a = (int)st_l[idx];
+                    int lmw = lm_l[wcl];
+                    const int scw = sc_l[wcl] + 1;
                     wave_fence();
-                    if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] += 1; tk_l[wcl] += min(kw, lm_l[wcl]); }
+                    if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] = scw; tk_l[wcl] += min(kw, lmw); }
                     res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
                     wave_fence();
 #ifdef VDS_PROF
@@ -3250,10 +3188,10 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                         const int cda = cdA_l[wcl];
                         const int nc = cda & 2047;
                         const bool capable = (cda & CAPABLE) != 0;
-                        const int boff = cdB_l[wcl];
+                        const int4 cd = S.cdesc[wcl];
+                        const int boff = U8 ? cd.z : cd.y;
                         const int mo = moff_l[wcl], m0 = m0_l[wcl];
                         const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
-                        bool inserted = false;
                         while (true) {
                             const int y = tq0 + (int)qr_l[a];
                             const int pick = S.so_rec[y].y & 0xFFFF;
@@ -3268,12 +3206,12 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                             }
                             const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
                             if (minc == IMAX) {
+                                lmw -= 1;
                                 if (lane == 0) {
-                                    lm_l[wcl] -= 1;
+                                    lm_l[wcl] = lmw;
                                     if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
                                     else out_r[y] = make_int2(-1, -1);
                                 }
-                                inserted = capable;
                                 break;
                             }
                             const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
@@ -3287,23 +3225,51 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                             if (bst == (int)WK_FREE) break;
                             a = bst;
                         }
-                        if (inserted) {         // an order turned dry: it may come before the one already fetched
-                            wave_fence();
-                            const int rho_2 = next_dry(rho + 1);
-                            if (rho_2 != rho_n) { rho_n = rho_2; load_rec(rho_n, ck_n, e_n, nl_n); }
-                        }
                     }
+                    // own matches and steals of the cluster, published as one word once the order is served
+                    wave_fence();
+                    if (lane == 0) lds_release(&ls_l[wcl], (lmw << 16) | scw);
                 }
             }
             if (lane == 0) out_r[q] = res;
 #ifdef VDS_PROF
             if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
 #endif
-            rho = rho_n; e = e_n; nl = nl_n;
-#pragma unroll
-            for (int jb = 0; jb < WK_JB; ++jb) ck[jb] = ck_n[jb];
+            wave_fence();
+            rho = next_dry(rho + 1);
         }
-        if (lane == 0) s_ev = ev_acc;
+        if (lane == 0) { s_ev = ev_acc; lds_release(&s_done, 1); }
+    } else {
+        while (true) {
+            const int cur = lds_acquire(&s_cursor);
+            const int b = next_dry(cur);
+            if (b == IMAX) {
+                if (lds_acquire(&s_done)) break;
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            int slot = -1;
+            if (lane == 0)
+                for (int s = 0; s < WK_NS && slot < 0; ++s) {
+                    int expect = 0;
+                    if (__hip_atomic_compare_exchange_strong(&s_state[s], &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) slot = s;
+                }
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot < 0) { __builtin_amdgcn_s_sleep(2); continue; }
+            int won = 0;
+            if (lane == 0) {
+                lds_release(&s_tag[slot], b);
+                int expect = cur;
+                won = __hip_atomic_compare_exchange_strong(&s_cursor, &expect, b + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+                if (!won) { s_tag[slot] = -1; lds_release(&s_state[slot], 0); }
+            }
+            won = __builtin_amdgcn_readfirstlane(won);
+            if (!won) continue;
+            const int q = tq0 + (int)qr_l[b];
+            dfs_scan<U8>(S, D, r, tq0, b, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, ls_l, cdA_l, rq_l, st_l, pool_l + slot * stride);
+            wave_fence();
+            if (lane == 0) lds_release(&s_state[slot], 2);
+        }
     }
     __syncthreads();
     PROF_STAMP(1);
@@ -3706,11 +3672,8 @@ int replica3_prepare() {      // opt in to more than 64 KB of dynamic LDS per wo
 }
 
 size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, S.seq_pad); }
-size_t dfs_spec_lds(const Static &S) { return dfs_spec_lds_bytes(S.C, S.max_tick_orders); }
-size_t dfs_spec_ints(const Static &S) { return (size_t)S.R * S.max_tick_orders * dfs_rec_ints(S.seq_pad); }
 
-// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), the
-// speculation for the orders it left dry, then the walk
+// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
 void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : 1;
@@ -3719,12 +3682,10 @@ void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hi
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);
         if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
         else hipLaunchKernelGGL((k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        hipLaunchKernelGGL(k_dfs_spec<true>, dim3(S.R), dim3(SP_THREADS), dfs_spec_lds(S), st, S, D, t);
         hipLaunchKernelGGL(k_dfs_walk<true>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     } else {
         if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
         else hipLaunchKernelGGL((k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        hipLaunchKernelGGL(k_dfs_spec<false>, dim3(S.R), dim3(SP_THREADS), dfs_spec_lds(S), st, S, D, t);
         hipLaunchKernelGGL(k_dfs_walk<false>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     }
 }
