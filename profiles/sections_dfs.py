@@ -26,6 +26,10 @@ if env.main_kernel() == "k_dfs_hybrid":
     nw = R * 4
     print("dry orders per replica-tick %.1f, served by a neighbour %.1f, with a redo chain %.2f, scanned again by the walk %.2f" % (
         buf[6] / R / T, buf[2] / R / T, buf[3] / R / T, buf[4] / R / T))
+    print("wavefront 0 per replica-tick: %.0f cycles waiting for a record, %.0f in redo chains; scanning wavefronts: %.1f scans of %.0f cycles" % (
+        buf[8] / R / T, buf[9] / R / T, buf[11] / R / T, buf[10] / max(1, buf[11])))
+    print("wavefront 0 per served order: record + alive counts + candidate stamps %.0f cycles, winner + steal %.0f, result + next dry order %.0f" % (
+        buf[12] / max(1, buf[6]), buf[13] / max(1, buf[6]), buf[14] / max(1, buf[6])))
     buf[2] = buf[3] = buf[4] = 0
 print(env.main_kernel())
 tot = float(buf[:6].sum() + buf[7])

@@ -63,6 +63,8 @@ struct vds_handle {
     long long blk_ints = 0; // total size of the per-cluster cost blocks
     int cost_min = 0, cost_max = 0;
     int max_seq = 0;        // longest visit sequence of FindServerVehicleFunction over the clusters
+    std::vector<unsigned char> lbc_host;     // host copy of Static.lbc (empty: none)
+    std::vector<int> dfs_off_host, dfs_seq_host;
     int depth_limit = 0;
     int t = 0;              // self.step
     int last_stepped = -1;  // tick of the last vds_step
@@ -453,6 +455,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
             if (fits) { unsigned char *d8; if ((rc = upload(h, &d8, c8))) return rc; S.cost8 = d8; }
             else S.u8_ok = 0;
             S.lbc = nullptr;
+            h->lbc_host.clear();
             if (fits && any_seq && (long long)N * C <= (256ll << 20)) {
                 // per (pickup node, cluster): the cheapest way from any node of the cluster - prunes the neighbour search
                 std::vector<unsigned char> lb((size_t)N * C, 255);
@@ -465,13 +468,15 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
                     }
                 }
                 unsigned char *dlb; if ((rc = upload(h, &dlb, lb))) return rc; S.lbc = dlb;
+                h->lbc_host.swap(lb);
             }
         }
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
     }
     h->max_seq = 0;
     for (int c = 0; c < C; ++c) h->max_seq = std::max(h->max_seq, dfs_off[c + 1] - dfs_off[c]);
-    S.seq_pad = std::max(64, (h->max_seq + 63) / 64 * 64);
+    S.seq_pad = h->max_seq <= 64 ? 64 : h->max_seq <= 128 ? 128 : 256;
+    h->dfs_off_host = dfs_off; h->dfs_seq_host = dfs_seq;
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;
     if ((rc = upload(h, &d, dfs_seq))) return rc; S.dfs_seq = d;
     // fast-kernel preconditions: packed (cost << 7 | position) keys, no window rejects
@@ -684,6 +689,37 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         (void)tbase;
         if ((rc = upload(h, &d, so_rank))) return rc; S.so_rank = d;
     }
+    S.so_lb = nullptr; S.so_vis = nullptr;
+    if (h->dfs_mode && h->cfg.force_generic == 0 && h->max_seq <= 256 && mto < 65535 && (long long)so_rec.size() * S.seq_pad * 5 <= (6ll << 30)) {
+        // per sorted order, for the hybrid neighbour-search tick: its visit sequence (j-th visited cluster | orders of that cluster
+        // of the same slot with a smaller id << 16) and, with byte costs, the cost bounds of those clusters (Static.lbc gathered
+        // through the sequence once, here)
+        std::vector<unsigned> so_vis(so_rec.size() * (size_t)S.seq_pad, 0xFFFFFFFFu);
+        std::vector<unsigned char> so_lb(h->lbc_host.empty() ? 0 : so_rec.size() * (size_t)S.seq_pad, 255);
+        std::vector<int> before((size_t)S.C);
+        for (int dd = 0; dd < n_days; ++dd) {
+            const DayDesc &de = ddesc[dd];
+            for (int t = 0; t < de.T; ++t) {
+                const int a = tick_off[de.tick_base + t], b = tick_off[de.tick_base + t + 1];
+                std::fill(before.begin(), before.end(), 0);
+                for (int i = a; i < b; ++i) {               // id (rank) order inside the slot
+                    const size_t q = (size_t)ord_q[i];
+                    const int pc = (int)((unsigned)so_rec[q].z >> 16);
+                    const int s0 = h->dfs_off_host[pc], n = h->dfs_off_host[pc + 1] - s0;
+                    unsigned *dst = so_vis.data() + q * (size_t)S.seq_pad;
+                    for (int j = 0; j < n; ++j) { const int c = h->dfs_seq_host[s0 + j]; dst[j] = (unsigned)c | ((unsigned)before[c] << 16); }
+                    if (!so_lb.empty()) {
+                        const unsigned char *row = h->lbc_host.data() + (size_t)so_pnode[q] * S.C;
+                        unsigned char *dl = so_lb.data() + q * (size_t)S.seq_pad;
+                        for (int j = 0; j < n; ++j) dl[j] = row[h->dfs_seq_host[s0 + j]];
+                    }
+                    before[pc] += 1;
+                }
+            }
+        }
+        unsigned *dv; if ((rc = upload(h, &dv, so_vis))) return rc; S.so_vis = dv;
+        if (!so_lb.empty()) { unsigned char *dl; if ((rc = upload(h, &dl, so_lb))) return rc; S.so_lb = dl; }
+    }
     { DayDesc *dd; if ((rc = upload(h, &dd, ddesc))) return rc; S.day = dd; }
     if ((rc = upload(h, &d, h->replica_day))) return rc; S.replica_day = d;
     {
@@ -708,7 +744,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
                        (Z.n_days <= 1 || Z.chunk_days) && Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
-                       dfs_walk_lds(Z) + 1024 <= 64 * 1024;
+                       dfs_walk_lds(Z) + 1024 <= 64 * 1024 && Z.so_vis != nullptr;
         h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
                      replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }

@@ -35,23 +35,29 @@ namespace vds {
 // timing-only ablation switches (tests/bench ablation hook; results are INVALID when non-zero)
 __device__ int g_ablate = 0;
 #define PROF_WAVES (1 << 16)
-__device__ unsigned long long g_prof[PROF_WAVES * 8];   // bit7 of g_ablate: per-wave, per-section cycles of k_tick_rows
+#define PROF_SLOTS 32
+__device__ unsigned long long g_prof[PROF_WAVES * PROF_SLOTS];   // bit7 of g_ablate: per-wave, per-section cycles of k_tick_rows
 #ifdef VDS_PROF
-#define PROF_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * 8 + (i)] += t_ - tprev; tprev = __builtin_amdgcn_s_memtime(); } } while (0)
-#define PROF_STAMP_NW(i) do { if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * 8 + (i)] += t_ - tprev; tprev = t_; } } while (0)
+#define PROF_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * PROF_SLOTS + (i)] += t_ - tprev; tprev = __builtin_amdgcn_s_memtime(); } } while (0)
+#define PROF_STAMP_NW(i) do { if (prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) g_prof[(size_t)pwave * PROF_SLOTS + (i)] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define PROF_STAMP(i) do { } while (0)
 #define PROF_STAMP_NW(i) do { } while (0)
 #endif
+unsigned long long g_prof_ext[16];    // slots 16..23 of the last read_prof (scan sections), printed when VDS_PROF_EXT is set
 void read_prof(unsigned long long *out, hipStream_t st) {
+    for (int i = 0; i < 16; ++i) g_prof_ext[i] = 0;
     (void)hipStreamSynchronize(st);
-    static unsigned long long host[PROF_WAVES * 8];
+    static unsigned long long host[PROF_WAVES * PROF_SLOTS];
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(host));
     for (int i = 0; i < 16; ++i) out[i] = 0;
     for (size_t w = 0; w < PROF_WAVES; ++w) {
-        for (int i = 0; i < 8; ++i) out[i] += host[w * 8 + i];
-        if (host[w * 8 + 6]) out[15]++;
+        for (int i = 0; i < 8; ++i) out[i] += host[w * PROF_SLOTS + i];
+        for (int i = 8; i < 15; ++i) out[i] += host[w * PROF_SLOTS + i];
+        for (int i = 16; i < 32; ++i) g_prof_ext[i - 16] += host[w * PROF_SLOTS + i];
+        if (host[w * PROF_SLOTS + 6]) out[15]++;
     }
+    if (getenv("VDS_PROF_EXT")) { for (int i = 0; i < 16; ++i) fprintf(stderr, "prof_ext[%d] = %llu\n", i, g_prof_ext[i]); }
     memset(host, 0, sizeof(host));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, sizeof(host));
 }
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(REPL_THREADS) void k_tick_replica(Static S, State D
         __syncthreads();
         PROF_STAMP(5);
 #ifdef VDS_PROF
-        if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+        if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 6] += 1;
 #endif
     }
     // ---- flush: idle counts and this tick's counter deltas
@@ -2004,7 +2010,7 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
         __syncthreads();
         PROF_STAMP(5);
 #ifdef VDS_PROF
-        if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+        if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 6] += 1;
 #endif
     }
     // ---- resolve the preliminary results: vehicle ids, arrivals (:954-960), counters (the id table is dead now)
@@ -2658,7 +2664,7 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
             }
             PROF_STAMP(5);
 #ifdef VDS_PROF
-            if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+            if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 6] += 1;
 #endif
             if (rho_n == IMAX) break;
             rho = rho_n; q = q_n; pc = pc_n; pnode = pnode_n; s0 = s0_n; s1 = s1_n; cj = cj_n;
@@ -2795,7 +2801,6 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_WAVES (WK_THREADS / WAVE)
 #define WK_FREE 0xFFFFu
 #define WK_K 8                              // candidates kept per scanned dry order
-#define WK_JB 4                             // visit sequences of up to WK_JB * 64 clusters
 #define WK_NS 4                             // records the scanning wavefronts may be ahead of the walk
 #define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
 #ifdef WKDEBUG
@@ -2805,7 +2810,7 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #endif
 
 // one scan record (ints): [seq_pad] visited cluster | orders of it before the dry order << 16 (0xFFFFFFFF past the end of the
-// sequence), [WK_K] candidates {cost << 16 | visit index << 8 | 64-entry chunk of the list, cluster << 16 | list position},
+// sequence), [WK_K] candidates {cost << 16 | visit index << 8 | 64-entry chunk of the list, index of the entry's stamp},
 // the number of candidates, pad
 __host__ __device__ inline int dfs_rec_ints(int seq_pad) { return seq_pad + 2 * WK_K + 2; }
 
@@ -2819,116 +2824,135 @@ template <bool U8>
 __device__ __forceinline__ int cost_elem(const char *base, unsigned elem) {
     return U8 ? (int)*reinterpret_cast<const unsigned char *>(base + elem) : *reinterpret_cast<const int *>(base + (elem << 2));
 }
-__device__ __forceinline__ unsigned long long pick_mask(const unsigned long long (&m)[WK_JB], int jb) {
+template <int JB>
+__device__ __forceinline__ unsigned long long pick_mask(const unsigned long long (&m)[JB], int jb) {
     unsigned long long v = m[0];
 #pragma unroll
-    for (int x = 1; x < WK_JB; ++x) v = jb == x ? m[x] : v;
+    for (int x = 1; x < JB; ++x) v = jb == x ? m[x] : v;
     return v;
 }
-__device__ __forceinline__ int pick_lane(const int (&a)[WK_JB], int jb, int l) {
+template <int JB>
+__device__ __forceinline__ int pick_lane(const int (&a)[JB], int jb, int l) {
     int v = rdlane(a[0], l);
 #pragma unroll
-    for (int x = 1; x < WK_JB; ++x) { const int u = rdlane(a[x], l); v = jb == x ? u : v; }
+    for (int x = 1; x < JB; ++x) { const int u = rdlane(a[x], l); v = jb == x ? u : v; }
     return v;
 }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ int lds_acquire(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_release(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// flags between the wavefronts of a workgroup, all in LDS: the DS instructions of a wavefront execute in order, so a flag store
+// after the data stores (a flag load before the data loads) needs compiler ordering only.  (Workgroup-scope release / acquire
+// would also wait for the wavefront's outstanding HBM stores - a full round trip per served order.)
+__device__ __forceinline__ int lds_acquire(const int *p) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    wave_fence();
+    return v;
+}
+__device__ __forceinline__ void lds_release(int *p, int v) {
+    wave_fence();
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
+    wave_fence();
+    const bool ok = __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    wave_fence();
+    return ok;
+}
 
-// dfs_scan: what one dry order (rank rho, pickup cluster pc / node pnode) would be served with, by ONE wavefront: the visit
-// sequence of FindServerVehicleFunction (:978-996), lane (j & 63) of batch (j >> 6) = j-th visited cluster; candidate clusters
-// (alive count > 0, derived from the list length, the own matches before the order and the steals so far: ls_l = own matches
-// << 16 | steals, one word so that a reader sees a consistent pair) pruned by the cost lower bound (Static.lbc) in two passes;
-// eight (cluster, 64-entry chunk) gathers in flight; the WK_K best candidates in the exact order of the reference (cost,
-// visit order, list position: first strict minimum), as far as they are KNOWN to be the best (each lane keeps its two smallest
-// keys; clusters never scanned cost at least their bound).  The first is always exact.
+// dfs_scan: what one dry order (sorted position q, rank rho, pickup node pnode) would be served with, by ONE wavefront: the
+// visit sequence of FindServerVehicleFunction (:978-996) comes precomputed per order (Static.so_vis: j-th visited cluster |
+// orders of that cluster before this one << 16; Static.so_lb: the cost lower bound of that cluster), lane (j & 63) of batch
+// (j >> 6) = j-th visited cluster; candidate clusters (alive count > 0, derived from the list length, the own matches before
+// the order and the steals so far: ls_l = own matches << 16 | steals, one word so that a reader sees a consistent pair) pruned
+// by the bound in two passes; eight (cluster, 64-entry chunk) gathers in flight; the WK_K best candidates in the exact order of
+// the reference (cost, visit order, list position: first strict minimum), as far as they are KNOWN to be the best (each lane
+// keeps its two smallest keys; clusters never scanned cost at least their bound).  The first is always exact.
 // The scan may run WHILE the walk serves earlier dry orders: stamps only ever decrease (a steal or a re-pick of a redo chain
 // lowers the stamp of the entry it takes) and ls_l is published once per served order, so whatever mixture of states the scan
 // reads, the vehicles it considers are a superset of those alive when the order's turn comes, and the list a sorted prefix of
 // that superset: its first entry still alive at that time IS the winner.
-template <bool U8>
-__device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int tq0, int rho, int pc, int pnode,
-                                         const int *m0_l, const int *moff_l, const int *qend_l, const int *ls_l, const int *cda_l,
-                                         const unsigned short *rq_l, const unsigned short *st_l, unsigned *rec) {
+template <bool U8, int JB>
+__device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
+                                         const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
+                                         const unsigned short *st_l, unsigned *rec, unsigned long long *pacc = nullptr) {
     const int lane = lane_id();
-    const int C = S.C;
-    const int s0 = S.dfs_off[pc], n = S.dfs_off[pc + 1] - s0;
-    const int nb = (n + WAVE - 1) >> 6;
+#ifdef VDS_PROF
+    unsigned long long sc_ts = pacc ? __builtin_amdgcn_s_memtime() : 0ull;
+#define SCT(i) do { if (pacc) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - sc_ts; sc_ts = t_; } } while (0)
+#else
+#define SCT(i) do { } while (0)
+#endif
     const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
-    int2 *list_out = reinterpret_cast<int2 *>(rec + S.seq_pad);
-    int cj[WK_JB], lbj[WK_JB];
-    unsigned long long cand[WK_JB], scanned[WK_JB], live[WK_JB];
+    const unsigned *vis = S.so_vis + (size_t)q * S.seq_pad;
+    unsigned ck[JB];
+    int lbj[JB], m0j[JB], moj[JB], cofj[JB];
+    unsigned long long cand[JB], scanned[JB], live[JB];
 #pragma unroll
-    for (int jb = 0; jb < WK_JB; ++jb) {
-        const int jx = jb * WAVE + lane;
-        cj[jb] = (jb < nb && jx < n) ? S.dfs_seq[s0 + jx] : 0;
+    for (int jb = 0; jb < JB; ++jb) {
+        ck[jb] = vis[jb * WAVE + lane];
+        lbj[jb] = (U8 && S.so_lb != nullptr) ? (int)S.so_lb[(size_t)q * S.seq_pad + jb * WAVE + lane] : 0;
     }
-#pragma unroll
-    for (int jb = 0; jb < WK_JB; ++jb) {
-        const int jx = jb * WAVE + lane;
-        lbj[jb] = 0;
-        if (U8 && S.lbc != nullptr && jb < nb && jx < n) lbj[jb] = (int)S.lbc[(size_t)pnode * C + cj[jb]];
-    }
+    SCT(0);
     int lbmin = IMAX;
 #pragma unroll
-    for (int jb = 0; jb < WK_JB; ++jb) {
-        const int jx = jb * WAVE + lane;
-        cand[jb] = 0ull; scanned[jb] = 0ull; live[jb] = 0ull;
-        if (jb * WAVE < S.seq_pad) {
-            unsigned ck = 0xFFFFFFFFu;
-            int alive = 0;
-            if (jb < nb && jx < n) {
-                const int c = cj[jb];
-                const int qa = c == 0 ? tq0 : qend_l[c - 1];
-                int lo = qa, hi = qend_l[c];
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)rq_l[mid - tq0] < rho) lo = mid + 1; else hi = mid; }
-                const int kj = lo - qa;                     // orders of the cluster before this one
-                const int ls = lds_load(&ls_l[c]);
-                alive = m0_l[c] - min(kj, ls >> 16) - (ls & 0xFFFF);
-                ck = (unsigned)c | ((unsigned)kj << 16);
-            }
-            rec[jx] = ck;
-            cand[jb] = ballot(alive > 0);
-            lbmin = min(lbmin, alive > 0 ? lbj[jb] : IMAX);
+    for (int jb = 0; jb < JB; ++jb) {
+        rec[jb * WAVE + lane] = ck[jb];
+        int alive = 0;
+        m0j[jb] = 0; moj[jb] = 0; cofj[jb] = 0;
+        if (ck[jb] != 0xFFFFFFFFu) {
+            const int c = (int)(ck[jb] & 0xFFFFu), kj = (int)(ck[jb] >> 16);
+            const int ls = lds_load(&ls_l[c]);
+            m0j[jb] = m0_l[c]; moj[jb] = moff_l[c]; cofj[jb] = (cda_l[c] >> 11) & 0xFFFF;
+            alive = m0j[jb] - min(kj, ls >> 16) - (ls & 0xFFFF);
         }
+        cand[jb] = ballot(alive > 0); scanned[jb] = 0ull; live[jb] = 0ull;
+        lbmin = min(lbmin, alive > 0 ? lbj[jb] : IMAX);
     }
     lbmin = wave_min_i32(lbmin);
+    SCT(1);
     int b1 = IMAX, b2 = IMAX, nval = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const int bound = pass == 0 ? lbmin + PRUNE_DELTA : (wave_min_i32(b1) >> 16) + WK_SLACK;
+        bool anylive = false;
 #pragma unroll
-        for (int jb = 0; jb < WK_JB; ++jb) {
+        for (int jb = 0; jb < JB; ++jb) {
             live[jb] = cand[jb] & ~scanned[jb] & ballot(lbj[jb] <= bound);
             scanned[jb] |= live[jb];
+            anylive |= live[jb] != 0ull;
         }
         int jbc = -1, b = 0;
         unsigned long long cl = 0ull;
-        while (true) {
+        while (anylive) {
             // eight (cluster, 64-entry chunk) slots at a time: their stamps (LDS), the node words of the entries that look
             // alive (HBM), then the cost gathers, then the two smallest keys of the lane
-            int in[8], seq[8], cst[8];
+            int in[8], seq[8], cst[8], sidx[8];
             unsigned yv[8];
             int cof[8];
+            const uint2 *ip[8];
             bool any = false;
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
-                in[k8] = 0; seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0;
-                while (cl == 0ull && jbc + 1 < nb) { ++jbc; cl = pick_mask(live, jbc); b = 0; }
+                in[k8] = 0; seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0; sidx[k8] = 0; ip[k8] = D.idle;
+                while (cl == 0ull && jbc + 1 < JB) { ++jbc; cl = pick_mask<JB>(live, jbc); b = 0; }
                 if (cl != 0ull) {
                     any = true;
                     const int j = __ffsll((long long)cl) - 1;
-                    const int cc = pick_lane(cj, jbc, j);
-                    const int m0c = m0_l[cc];
+                    const int cc = (int)((unsigned)pick_lane<JB>(reinterpret_cast<const int (&)[JB]>(ck), jbc, j) & 0xFFFFu);
+                    const int m0c = pick_lane<JB>(m0j, jbc, j), moc = pick_lane<JB>(moj, jbc, j);
                     const int i = b * WAVE + lane;
-                    in[k8] = (i < m0c ? 1 : 0) & ((int)st_l[moff_l[cc] + min(i, m0c - 1)] > rho ? 1 : 0);
-                    if (in[k8]) yv[k8] = D.idle[((size_t)cc * S.R + r) * S.idle_cap + i].y;
-                    cof[k8] = (cda_l[cc] >> 11) & 0xFFFF;
+                    in[k8] = i < m0c ? 1 : 0;
+                    sidx[k8] = moc + min(i, m0c - 1);
+                    ip[k8] = D.idle + ((size_t)cc * S.R + r) * S.idle_cap + i;
+                    cof[k8] = pick_lane<JB>(cofj, jbc, j);
                     seq[k8] = (((jbc << 6) | j) << 8) | b;
                     ++b;
                     if (b * WAVE >= m0c) { b = 0; cl &= cl - 1ull; }
                 }
             }
             if (!any) break;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) in[k8] &= ((int)st_l[sidx[k8]] > rho ? 1 : 0);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) if (in[k8]) yv[k8] = ip[k8]->y;
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8)
                 cst[k8] = cost_elem<U8>(crow_b, (unsigned)(in[k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
@@ -2939,31 +2963,43 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                 b2 = min(b2, max(b1, v));
                 b1 = min(b1, v);
             }
+#ifdef VDS_PROF
+            if (pacc) pacc[5] += 1;
+#endif
         }
+        SCT(2 + pass);
     }
     // candidates of clusters never scanned cost at least their bound (and could win a tie on visit order)
     int ulb = IMAX;
 #pragma unroll
-    for (int jb = 0; jb < WK_JB; ++jb) ulb = min(ulb, (((cand[jb] & ~scanned[jb]) >> lane) & 1ull) ? lbj[jb] : IMAX);
+    for (int jb = 0; jb < JB; ++jb) ulb = min(ulb, (((cand[jb] & ~scanned[jb]) >> lane) & 1ull) ? lbj[jb] : IMAX);
     ulb = wave_min_i32(ulb);
-    int nl = 0, npop = 0;
+    // the WK_K smallest keys, ascending: lane kk keeps the kk-th (and the lane it came from = its position inside the chunk)
+    int nl = 0, npop = 0, mykey = IMAX, mywl = 0;
     for (int kk = 0; kk < WK_K; ++kk) {
         const int m = wave_min_i32(b1);
         if (m == IMAX) break;
         if (kk > 0 && (m >> 16) >= ulb) break;
         const int wl = __ffsll((long long)ballot(b1 == m)) - 1;       // lowest lane = lowest list position
-        const int j = (m >> 8) & 255, bb = m & 255;
-        const int cc = pick_lane(cj, j >> 6, j & 63);
-        if (lane == 0) list_out[kk] = make_int2(m, (int)(((unsigned)cc << 16) | (unsigned)(bb * WAVE + wl)));
+        if (lane == kk) { mykey = m; mywl = wl; }
         ++nl;
         bool stop = false;
         if (lane == wl) { b1 = b2; b2 = IMAX; ++npop; stop = npop == 2 && nval > 2; }   // the lane's third smallest is unknown
         if (ballot(stop)) break;
     }
+    {   // ... and each of those lanes resolves its entry: stamp index = start of the cluster's stamps + position
+        const int j = (mykey >> 8) & 255, bb = mykey & 255;
+        int mo = 0;
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) { const int u = __shfl(moj[jb], j & 63, WAVE); mo = (j >> 6) == jb ? u : mo; }
+        if (lane < nl) reinterpret_cast<int2 *>(rec + S.seq_pad)[lane] = make_int2(mykey, mo + bb * WAVE + mywl);
+    }
     if (lane == 0) rec[S.seq_pad + 2 * WK_K] = (unsigned)nl;
+    SCT(4);
 }
 
-template <bool U8>
+// JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
+template <bool U8, int JB>
 __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
@@ -2989,8 +3025,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     __shared__ int s_ev;                  // evaluations of the dry orders
     __shared__ int s_cursor;              // dry orders of rank < cursor have been claimed by a scanning wavefront (or passed over)
     __shared__ int s_done;                // the walk is over
-    __shared__ int s_tag[WK_NS];          // rank of the dry order pool record s belongs to
-    __shared__ int s_state[WK_NS];        // 0 free, 1 being filled, 2 ready
+    __shared__ int s_slot[WK_NS];         // pool record s: 0 free, else rank of its dry order << 2 | 1 being filled / 2 ready
     const int r = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const DayView dv = day_view(S, r);
@@ -3006,10 +3041,13 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     const int pwave = (int)((blockIdx.x * WK_WAVES + wave) & (PROF_WAVES - 1));
 #endif
     // ---- tables
-    for (int i = threadIdx.x; i < nord; i += WK_THREADS) {
-        const int rk = S.so_rank[tq0 + i];
-        rq_l[i] = (unsigned short)rk;
-        qr_l[rk] = (unsigned short)i;
+    for (int i0 = threadIdx.x; i0 < nord; i0 += 6 * WK_THREADS) {       // (six loads in flight per thread)
+        int rk[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) rk[u] = i0 + u * WK_THREADS < nord ? S.so_rank[tq0 + i0 + u * WK_THREADS] : 0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (i0 + u * WK_THREADS < nord) { rq_l[i0 + u * WK_THREADS] = (unsigned short)rk[u]; qr_l[rk[u]] = (unsigned short)(i0 + u * WK_THREADS); }
     }
     for (int c = threadIdx.x; c < C; c += WK_THREADS) {
         const int4 cd = S.cdesc[c];
@@ -3022,8 +3060,9 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     }
     for (int w = threadIdx.x; w < nwords; w += WK_THREADS) dry_bits[w] = 0u;
     if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; }
-    if (threadIdx.x < WK_NS) { s_tag[threadIdx.x] = -1; s_state[threadIdx.x] = 0; }
+    if (threadIdx.x < WK_NS) s_slot[threadIdx.x] = 0;
     __syncthreads();
+    PROF_STAMP(24);
     if (wave == 0) {            // exclusive prefix of the list lengths
         int run = 0;
         for (int base = 0; base < C; base += WAVE) {
@@ -3037,12 +3076,13 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         if (lane == 0) moff_l[C] = run;
     }
     __syncthreads();
+    PROF_STAMP(25);
     // ---- stamps of every idle entry (the fast kernel wrote rank + 1 into the high half of the node word of a taken entry)
-    for (int c = wave; c < C; c += 4 * WK_WAVES) {
-        int m4[4], mo4[4];
-        unsigned y4[4];
+    for (int c = wave; c < C; c += 16 * WK_WAVES) {        // (sixteen lists in flight per wavefront)
+        int m4[16], mo4[16];
+        unsigned y4[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int cu = c + u * WK_WAVES;
             m4[u] = cu < C ? m0_l[cu] : 0;
             mo4[u] = cu < C ? moff_l[cu] : 0;
@@ -3050,7 +3090,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (lane < m4[u]) y4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane].y;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
             if (lane < m4[u]) st_l[mo4[u] + lane] = (unsigned short)((y4[u] >> 16) ? (y4[u] >> 16) - 1u : WK_FREE);
             if (m4[u] > WAVE) {
                 const uint2 *idle = D.idle + ((size_t)(c + u * WK_WAVES) * S.R + r) * S.idle_cap;
@@ -3058,6 +3098,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             }
         }
     }
+    PROF_STAMP(26);
     // dry orders: everything behind a searching cluster's exhaustion point
     for (int c = threadIdx.x; c < C; c += WK_THREADS) {
         if (!(cdA_l[c] & CAPABLE)) continue;
@@ -3084,101 +3125,112 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         }
         return wave_min_i32(best);
     };
-    auto cluster_of = [&](int q) -> int {       // first cluster whose bucket ends behind q
-        int lo = 0, hi = C - 1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (qend_l[mid] <= q) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
     if (wave == 0) {
-        const int nbp = S.seq_pad >> 6;
-        unsigned ck[WK_JB];
-        int2 e = make_int2(IMAX, 0);
-        int nl = 0;
         int ev_acc = 0;
         int rho = next_dry(0);
+#ifdef VDS_PROF
+        unsigned long long p_wait = 0, p_chain = 0, p_seg[4] = {0, 0, 0, 0};
+#endif
         while (rho != IMAX) {
             const int q = tq0 + (int)qr_l[rho];
             // the order's record: in the pool (ready, or being filled), still to be claimed (wait), or passed over (scan here)
-            const unsigned *rec = nullptr;
+            const unsigned *rec = slot_l;
             int slot = -1;
+#ifdef VDS_PROF
+            const unsigned long long p_t0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
             while (true) {
                 const int cur = lds_acquire(&s_cursor);
-                // (a claim publishes its tag before it moves the cursor, and withdraws it if another wavefront moved it first)
-                const int tg = lane < WK_NS ? lds_load(&s_tag[lane]) : -1;
-                const unsigned long long hit = ballot(tg == rho);
-                if (hit != 0ull) {
-                    const int s = __ffsll((long long)hit) - 1;
-                    const int stt = lds_acquire(&s_state[s]);
-                    if (stt == 2 && lds_load(&s_tag[s]) == rho) { slot = s; break; }
-                } else if (cur > rho) {
-                    break;
-                }
+                // (a claim publishes its slot word before it moves the cursor, and withdraws it if another wavefront moved it first)
+                const int sw = lane < WK_NS ? lds_acquire(&s_slot[lane]) : 0;
+                const unsigned long long ready = ballot(sw == ((rho << 2) | 2));
+                if (ready != 0ull) { slot = __ffsll((long long)ready) - 1; break; }
+                if (ballot(sw == ((rho << 2) | 1)) == 0ull && cur > rho) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+#ifdef VDS_PROF
+            unsigned long long p_ts = 0;
+            if (prof) { p_ts = __builtin_amdgcn_s_memtime(); p_wait += p_ts - p_t0; }
+#define PSEG(i) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); p_seg[i] += t_ - p_ts; p_ts = t_; } } while (0)
+#else
+#define PSEG(i) do { } while (0)
+#endif
             if (slot >= 0) {
                 rec = pool_l + slot * stride;
             } else {
-                dfs_scan<U8>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, ls_l, cdA_l, rq_l, st_l, slot_l);
+                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
                 wave_fence();
-                rec = slot_l;
 #ifdef VDS_PROF
-                if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 4] += 1;
+                if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 4] += 1;
 #endif
             }
+            unsigned ck[JB];
 #pragma unroll
-            for (int jb = 0; jb < WK_JB; ++jb) ck[jb] = jb < nbp ? rec[jb * WAVE + lane] : 0xFFFFFFFFu;
-            e = make_int2(IMAX, 0);
+            for (int jb = 0; jb < JB; ++jb) ck[jb] = rec[jb * WAVE + lane];
+            int2 e = make_int2(IMAX, 0);
             if (lane < WK_K) e = reinterpret_cast<const int2 *>(rec + S.seq_pad)[lane];
-            nl = (int)rec[S.seq_pad + 2 * WK_K];
+            int nl = (int)rec[S.seq_pad + 2 * WK_K];
+            // :986-991 runs for every visited cluster: the alive counts as they stand NOW; and the stamps of the candidates
+            int alive = 0;
+            int lmv[JB], scv[JB];
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) {
+                lmv[jb] = 0; scv[jb] = 0;
+                if (ck[jb] != 0xFFFFFFFFu) {
+                    const int cjv = (int)(ck[jb] & 0xFFFFu), kv = (int)(ck[jb] >> 16);
+                    lmv[jb] = lm_l[cjv]; scv[jb] = sc_l[cjv];
+                    alive += m0_l[cjv] - min(kv, lmv[jb]) - scv[jb];
+                }
+            }
+            int stv = lane < nl ? (int)st_l[e.y] : -1;
             if (slot >= 0) {
                 wave_fence();
-                if (lane == 0) { s_tag[slot] = -1; lds_release(&s_state[slot], 0); }
+                if (lane == 0) lds_release(&s_slot[slot], 0);
             }
-            // :986-991 runs for every visited cluster: the alive counts as they stand NOW
-            int alive = 0;
-#pragma unroll
-            for (int jb = 0; jb < WK_JB; ++jb)
-                if (jb < nbp && ck[jb] != 0xFFFFFFFFu) {
-                    const int cjv = (int)(ck[jb] & 0xFFFFu), kv = (int)(ck[jb] >> 16);
-                    alive += m0_l[cjv] - min(kv, lm_l[cjv]) - sc_l[cjv];
-                }
+            PSEG(0);
             const int rs = row_sum_i32(alive);
             const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
             ev_acc += tot;
             int2 res = make_int2(-1, -1);
             if (tot > 0) {
-                bool ok = lane < nl && (int)st_l[moff_l[(unsigned)e.y >> 16] + (e.y & 0xFFFF)] > rho;
-                unsigned long long okb = ballot(ok);
+                unsigned long long okb = ballot(stv > rho);
                 if (okb == 0ull) {             // every kept candidate has been taken since: scan again, on the state as it is
-                    dfs_scan<U8>(S, D, r, tq0, rho, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, ls_l, cdA_l, rq_l, st_l, slot_l);
+                    dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
                     wave_fence();
                     e = make_int2(IMAX, 0);
-                    if (lane == 0) e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[0];
+                    if (lane == 0) { e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[0]; stv = (int)st_l[e.y]; }
                     okb = 1ull;
 #ifdef VDS_PROF
-                    if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 4] += 1;
+                    if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 4] += 1;
 #endif
                 }
                 const int first = __ffsll((long long)okb) - 1;
-                const int key = rdlane(e.x, first), loc = rdlane(e.y, first);
+                const int key = rdlane(e.x, first), idx = rdlane(e.y, first);
+                int a = rdlane(stv, first);                 // the winner's stamp: free, or the own-cluster order that took it later
                 const int wc = key >> 16;
                 if ((long long)wc <= S.reject_threshold) {
-                    const int wcl = (int)((unsigned)loc >> 16), wpos = loc & 0xFFFF;
                     const int jw = (key >> 8) & 255;
-                    int kw = 0;
+                    int ckw = 0, lmw = 0, scw = 0;
 #pragma unroll
-                    for (int jb = 0; jb < WK_JB; ++jb) { const int u = rdlane((int)(ck[jb] >> 16), jw & 63); kw = (jw >> 6) == jb ? u : kw; }
-                    WKCHK(wcl < C && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
-                    const int idx = moff_l[wcl] + wpos;
-                    int a = (int)st_l[idx];
-                    int lmw = lm_l[wcl];
-                    const int scw = sc_l[wcl] + 1;
-                    wave_fence();
-                    if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] = scw; tk_l[wcl] += min(kw, lmw); }
+                    for (int jb = 0; jb < JB; ++jb) {
+                        const int u0 = rdlane((int)ck[jb], jw & 63), u1 = rdlane(lmv[jb], jw & 63), u2 = rdlane(scv[jb], jw & 63);
+                        const bool me = (jw >> 6) == jb;
+                        ckw = me ? u0 : ckw; lmw = me ? u1 : lmw; scw = me ? u2 : scw;
+                    }
+                    const int wcl = ckw & 0xFFFF, kw = (int)((unsigned)ckw >> 16);
+                    scw += 1;
+                    const int mo = moff_l[wcl];
+                    const int wpos = idx - mo;
+                    WKCHK(wcl < C && wpos >= 0 && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
+                    if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] = scw; atomicAdd(&tk_l[wcl], min(kw, lmw)); }
                     res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
                     wave_fence();
 #ifdef VDS_PROF
-                    if (prof && lane == 0) { g_prof[(size_t)pwave * 8 + 2] += 1; if (a != (int)WK_FREE) g_prof[(size_t)pwave * 8 + 3] += 1; }
+                    if (prof && lane == 0) { g_prof[(size_t)pwave * PROF_SLOTS + 2] += 1; if (a != (int)WK_FREE) g_prof[(size_t)pwave * PROF_SLOTS + 3] += 1; }
+#endif
+                    PSEG(1);
+#ifdef VDS_PROF
+                    const unsigned long long p_c0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
                     if (a != (int)WK_FREE) {
                         // the stolen vehicle had been taken later by own-cluster order a of wcl: that order picks again among the
@@ -3190,7 +3242,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                         const bool capable = (cda & CAPABLE) != 0;
                         const int4 cd = S.cdesc[wcl];
                         const int boff = U8 ? cd.z : cd.y;
-                        const int mo = moff_l[wcl], m0 = m0_l[wcl];
+                        const int m0 = m0_l[wcl];
                         const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
                         while (true) {
                             const int y = tq0 + (int)qr_l[a];
@@ -3226,50 +3278,78 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                             a = bst;
                         }
                     }
+#ifdef VDS_PROF
+                    if (prof) { __builtin_amdgcn_s_waitcnt(0); p_chain += __builtin_amdgcn_s_memtime() - p_c0; }
+#endif
                     // own matches and steals of the cluster, published as one word once the order is served
                     wave_fence();
                     if (lane == 0) lds_release(&ls_l[wcl], (lmw << 16) | scw);
                 }
             }
+#ifdef VDS_PROF
+            if (prof) p_ts = __builtin_amdgcn_s_memtime();
+#endif
             if (lane == 0) out_r[q] = res;
 #ifdef VDS_PROF
-            if (prof && lane == 0) g_prof[(size_t)pwave * 8 + 6] += 1;
+            if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 6] += 1;
 #endif
             wave_fence();
             rho = next_dry(rho + 1);
+            PSEG(2);
         }
         if (lane == 0) { s_ev = ev_acc; lds_release(&s_done, 1); }
+#ifdef VDS_PROF
+        if (prof && lane == 0) {
+            g_prof[(size_t)pwave * PROF_SLOTS + 8] += p_wait; g_prof[(size_t)pwave * PROF_SLOTS + 9] += p_chain;
+            for (int i = 0; i < 3; ++i) g_prof[(size_t)pwave * PROF_SLOTS + 12 + i] += p_seg[i];
+        }
+#endif
     } else {
+#ifdef VDS_PROF
+        unsigned long long p_scan = 0, p_n = 0, p_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         while (true) {
             const int cur = lds_acquire(&s_cursor);
             const int b = next_dry(cur);
             if (b == IMAX) {
                 if (lds_acquire(&s_done)) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(10);
                 continue;
             }
-            int slot = -1;
-            if (lane == 0)
-                for (int s = 0; s < WK_NS && slot < 0; ++s) {
-                    int expect = 0;
-                    if (__hip_atomic_compare_exchange_strong(&s_state[s], &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) slot = s;
-                }
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (slot < 0) { __builtin_amdgcn_s_sleep(2); continue; }
-            int won = 0;
+            int slot = -1, won = 0;
             if (lane == 0) {
-                lds_release(&s_tag[slot], b);
-                int expect = cur;
-                won = __hip_atomic_compare_exchange_strong(&s_cursor, &expect, b + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
-                if (!won) { s_tag[slot] = -1; lds_release(&s_state[slot], 0); }
+                for (int s = 0; s < WK_NS && slot < 0; ++s)
+                    if (lds_cas(&s_slot[s], 0, (b << 2) | 1)) slot = s;
+                if (slot >= 0) {
+                    won = lds_cas(&s_cursor, cur, b + 1) ? 1 : 0;
+                    if (!won) lds_release(&s_slot[slot], 0);
+                }
             }
+            slot = __builtin_amdgcn_readfirstlane(slot);
             won = __builtin_amdgcn_readfirstlane(won);
+            if (slot < 0) { __builtin_amdgcn_s_sleep(10); continue; }
             if (!won) continue;
             const int q = tq0 + (int)qr_l[b];
-            dfs_scan<U8>(S, D, r, tq0, b, cluster_of(q), S.so_pnode[q], m0_l, moff_l, qend_l, ls_l, cdA_l, rq_l, st_l, pool_l + slot * stride);
+#ifdef VDS_PROF
+            const unsigned long long p_s0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+            dfs_scan<U8, JB>(S, D, r, q, b, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, pool_l + slot * stride
+#ifdef VDS_PROF
+                         , prof ? p_acc : nullptr
+#endif
+                         );
             wave_fence();
-            if (lane == 0) lds_release(&s_state[slot], 2);
+            if (lane == 0) lds_release(&s_slot[slot], (b << 2) | 2);
+#ifdef VDS_PROF
+            if (prof) { p_scan += __builtin_amdgcn_s_memtime() - p_s0; p_n += 1; }
+#endif
         }
+#ifdef VDS_PROF
+        if (prof && lane == 0) {
+            g_prof[(size_t)pwave * PROF_SLOTS + 10] += p_scan; g_prof[(size_t)pwave * PROF_SLOTS + 11] += p_n;
+            for (int i = 0; i < 8; ++i) g_prof[(size_t)pwave * PROF_SLOTS + 16 + i] += p_acc[i];
+        }
+#endif
     }
     __syncthreads();
     PROF_STAMP(1);
@@ -3325,12 +3405,13 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         }
     }
     __syncthreads();
+    PROF_STAMP(27);
     // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = free entries, node words clean)
-    for (int c = wave; c < C; c += 4 * WK_WAVES) {
-        uint2 e4[4];
-        bool keep4[4], small4[4];
+    for (int c = wave; c < C; c += 12 * WK_WAVES) {        // (twelve lists in flight per wavefront)
+        uint2 e4[12];
+        bool keep4[12], small4[12];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 12; ++u) {
             const int cu = c + u * WK_WAVES;
             const int mo = cu < C ? moff_l[cu] : 0, m0 = cu < C ? m0_l[cu] : 0;
             small4[u] = cu < C && m0 <= WAVE && sc_l[cu] != m0;
@@ -3339,11 +3420,12 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (keep4[u]) e4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 12; ++u) {
             const unsigned long long kb = ballot(keep4[u]);
             if (keep4[u]) D.idle[((size_t)(c + u * WK_WAVES) * S.R + r) * S.idle_cap + popc64(kb & lanemask_lt())] = e4[u];
         }
     }
+    PROF_STAMP(28);
     for (int c = wave; c < C; c += WK_WAVES) {
         const int mo = moff_l[c], m0 = m0_l[c];
         if (sc_l[c] == m0 || m0 <= WAVE) continue;
@@ -3682,11 +3764,15 @@ void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hi
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);
         if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
         else hipLaunchKernelGGL((k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        hipLaunchKernelGGL(k_dfs_walk<true>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        if (S.seq_pad <= 64) hipLaunchKernelGGL((k_dfs_walk<true, 1>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        else if (S.seq_pad <= 128) hipLaunchKernelGGL((k_dfs_walk<true, 2>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        else hipLaunchKernelGGL((k_dfs_walk<true, 4>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     } else {
         if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
         else hipLaunchKernelGGL((k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        hipLaunchKernelGGL(k_dfs_walk<false>, dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        if (S.seq_pad <= 64) hipLaunchKernelGGL((k_dfs_walk<false, 1>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        else if (S.seq_pad <= 128) hipLaunchKernelGGL((k_dfs_walk<false, 2>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        else hipLaunchKernelGGL((k_dfs_walk<false, 4>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     }
 }
 
