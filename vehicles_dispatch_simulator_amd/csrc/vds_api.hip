@@ -745,6 +745,13 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                        (Z.n_days <= 1 || Z.chunk_days) && Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
                        dfs_walk_lds(Z) + 1024 <= 64 * 1024 && Z.so_vis != nullptr;
+        h->D.slog = nullptr;
+        if (h->hybrid_ok) {
+            h->alloc_sink = &h->order_allocs;
+            rc = dev_alloc(h, &h->D.slog, (size_t)Z.R * std::max(Z.max_tick_orders, 1));
+            h->alloc_sink = nullptr;
+            if (rc) return rc;
+        }
         h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
                      replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }

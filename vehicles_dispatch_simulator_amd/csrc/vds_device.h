@@ -122,6 +122,7 @@ struct State {
     int *ring_cnt;
     int4 *fl;
     int4 *inbox;
+    int4 *slog;          // [R][max_tick_orders] steal log of the hybrid neighbour-search tick: {rank of the thief, cluster | orders of that cluster before the thief << 16, the thief's result}
     int2 *out;
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices

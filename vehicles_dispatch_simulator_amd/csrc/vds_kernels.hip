@@ -116,6 +116,11 @@ __device__ __forceinline__ int popc64(unsigned long long x) { return __popcll(x)
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// ordering point for LDS traffic inside one wavefront: the DS instructions of a wavefront execute in order and the compiler keeps
+// may-alias LDS accesses in program order, so nothing has to be waited for - this only stops the scheduler from moving code across
+// (wave_fence() above, and an empty asm with a memory clobber too, are lowered to s_waitcnt vmcnt(0): they wait for every HBM
+// access in flight - a round trip per use)
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_sched_barrier(0); }
 
 // ---------------------------------------------------------------------------------------
 // Self-test kernel for the DPP primitives (tests/test_gpu_primitives.py).
@@ -2801,7 +2806,10 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_WAVES (WK_THREADS / WAVE)
 #define WK_FREE 0xFFFFu
 #define WK_K 8                              // candidates kept per scanned dry order
-#define WK_NS 4                             // records the scanning wavefronts may be ahead of the walk
+#define WK_NS 8                             // records the scanning wavefronts may be ahead of the walk
+#define WK_REC (4 * WK_K + 2)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
+                                            // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, 0},
+                                            // the number of candidates, pad
 #define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
 #ifdef WKDEBUG
 #define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
@@ -2809,15 +2817,11 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WKCHK(cond, code, a, b2) do { } while (0)
 #endif
 
-// one scan record (ints): [seq_pad] visited cluster | orders of it before the dry order << 16 (0xFFFFFFFF past the end of the
-// sequence), [WK_K] candidates {cost << 16 | visit index << 8 | 64-entry chunk of the list, index of the entry's stamp},
-// the number of candidates, pad
-__host__ __device__ inline int dfs_rec_ints(int seq_pad) { return seq_pad + 2 * WK_K + 2; }
-
-__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int seq_pad) {
+__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
-    return ((size_t)8 * C + 1 + ids + words + (1 + WK_NS) * dfs_rec_ints(seq_pad) + ((size_t)V + 1) / 2) * sizeof(int);
+    const size_t bmw = (size_t)(C + 31) / 32;
+    return ((size_t)8 * C + 1 + ids + words + (1 + WK_NS) * WK_REC + WK_WAVES * bmw + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
 }
 
 template <bool U8>
@@ -2844,17 +2848,17 @@ __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load
 // would also wait for the wavefront's outstanding HBM stores - a full round trip per served order.)
 __device__ __forceinline__ int lds_acquire(const int *p) {
     const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wave_fence();
+    wave_order();
     return v;
 }
 __device__ __forceinline__ void lds_release(int *p, int v) {
-    wave_fence();
+    wave_order();
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
-    wave_fence();
+    wave_order();
     const bool ok = __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wave_fence();
+    wave_order();
     return ok;
 }
 
@@ -2869,7 +2873,7 @@ __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
 // The scan may run WHILE the walk serves earlier dry orders: stamps only ever decrease (a steal or a re-pick of a redo chain
 // lowers the stamp of the entry it takes) and ls_l is published once per served order, so whatever mixture of states the scan
 // reads, the vehicles it considers are a superset of those alive when the order's turn comes, and the list a sorted prefix of
-// that superset: its first entry still alive at that time IS the winner.
+// that superset: its first entry still alive at that time IS the winner (none kept: nothing was alive, the order is rejected).
 template <bool U8, int JB>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
@@ -2895,7 +2899,6 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
     int lbmin = IMAX;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
-        rec[jb * WAVE + lane] = ck[jb];
         int alive = 0;
         m0j[jb] = 0; moj[jb] = 0; cofj[jb] = 0;
         if (ck[jb] != 0xFFFFFFFFu) {
@@ -2923,7 +2926,9 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
         unsigned long long cl = 0ull;
         while (anylive) {
             // eight (cluster, 64-entry chunk) slots at a time: their stamps (LDS), the node words of the entries that look
-            // alive (HBM), then the cost gathers, then the two smallest keys of the lane
+            // alive (HBM), then the cost gathers, then the two smallest keys of the lane.  (Fetching the cluster's segment of
+            // the cost row together with the node words and shuffling the cost out of it was measured: the extra loads make
+            // every load slower, 19.6 k instead of 15.6 k cycles per scan.)
             int in[8], seq[8], cst[8], sidx[8];
             unsigned yv[8];
             int cof[8];
@@ -2987,14 +2992,17 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
         if (lane == wl) { b1 = b2; b2 = IMAX; ++npop; stop = npop == 2 && nval > 2; }   // the lane's third smallest is unknown
         if (ballot(stop)) break;
     }
-    {   // ... and each of those lanes resolves its entry: stamp index = start of the cluster's stamps + position
+    {   // ... and each of those lanes resolves its entry: stamp index = start of the cluster's stamps + position; cluster | k
         const int j = (mykey >> 8) & 255, bb = mykey & 255;
-        int mo = 0;
+        int mo = 0, ckw = 0;
 #pragma unroll
-        for (int jb = 0; jb < JB; ++jb) { const int u = __shfl(moj[jb], j & 63, WAVE); mo = (j >> 6) == jb ? u : mo; }
-        if (lane < nl) reinterpret_cast<int2 *>(rec + S.seq_pad)[lane] = make_int2(mykey, mo + bb * WAVE + mywl);
+        for (int jb = 0; jb < JB; ++jb) {
+            const int u = __shfl(moj[jb], j & 63, WAVE), u2 = __shfl((int)ck[jb], j & 63, WAVE);
+            mo = (j >> 6) == jb ? u : mo; ckw = (j >> 6) == jb ? u2 : ckw;
+        }
+        if (lane < nl) reinterpret_cast<int4 *>(rec)[lane] = make_int4(mykey, mo + bb * WAVE + mywl, ckw, 0);
     }
-    if (lane == 0) rec[S.seq_pad + 2 * WK_K] = (unsigned)nl;
+    if (lane == 0) rec[4 * WK_K] = (unsigned)nl;
     SCT(4);
 }
 
@@ -3020,9 +3028,17 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
     const int nwords = (mto + 31) / 32 + 1;
     unsigned *slot_l = dry_bits + nwords;                                             // one record, for the scans wavefront 0 does itself
-    unsigned *pool_l = slot_l + dfs_rec_ints(S.seq_pad);                              // WK_NS records, filled by wavefronts 1..3
-    unsigned short *st_l = reinterpret_cast<unsigned short *>(pool_l + WK_NS * dfs_rec_ints(S.seq_pad));      // [V] stamps
+    unsigned *pool_l = slot_l + WK_REC;                                               // WK_NS records, filled by wavefronts 1..3
+    const int bmw = (C + 31) / 32;
+    unsigned *bm_l = pool_l + WK_NS * WK_REC;                                         // [WK_WAVES][bmw] cluster bitmaps of the evaluation pass
+    int *lg_l = reinterpret_cast<int *>(bm_l + WK_WAVES * bmw);                       // [64][4] the steal log's current chunk
+    unsigned short *st_l = reinterpret_cast<unsigned short *>(lg_l + 4 * WAVE);       // [V] stamps
     __shared__ int s_ev;                  // evaluations of the dry orders
+    __shared__ int s_nlog;                // steals (entries of the replica's steal log)
+#ifdef WKDEBUG
+    __shared__ int s_dbg, s_dbga, s_dbgb;
+    if (threadIdx.x == 0) { s_dbga = 0; s_dbgb = 0; }
+#endif
     __shared__ int s_cursor;              // dry orders of rank < cursor have been claimed by a scanning wavefront (or passed over)
     __shared__ int s_done;                // the walk is over
     __shared__ int s_slot[WK_NS];         // pool record s: 0 free, else rank of its dry order << 2 | 1 being filled / 2 ready
@@ -3059,7 +3075,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; ls_l[c] = own << 16; tk_l[c] = 0;
     }
     for (int w = threadIdx.x; w < nwords; w += WK_THREADS) dry_bits[w] = 0u;
-    if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; }
+    if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; s_nlog = 0; }
     if (threadIdx.x < WK_NS) s_slot[threadIdx.x] = 0;
     __syncthreads();
     PROF_STAMP(24);
@@ -3077,26 +3093,16 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     }
     __syncthreads();
     PROF_STAMP(25);
-    // ---- stamps of every idle entry (the fast kernel wrote rank + 1 into the high half of the node word of a taken entry)
-    for (int c = wave; c < C; c += 16 * WK_WAVES) {        // (sixteen lists in flight per wavefront)
-        int m4[16], mo4[16];
-        unsigned y4[16];
+    // ---- stamps: free, or the rank of the own-cluster order the fast kernel gave the entry to (its preliminary result says which)
+    for (int i = threadIdx.x; i < (moff_l[C] + 1) / 2; i += WK_THREADS) reinterpret_cast<unsigned *>(st_l)[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < nord; i0 += 6 * WK_THREADS) {
+        int2 pr[6];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int cu = c + u * WK_WAVES;
-            m4[u] = cu < C ? m0_l[cu] : 0;
-            mo4[u] = cu < C ? moff_l[cu] : 0;
-            y4[u] = 0u;
-            if (lane < m4[u]) y4[u] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + lane].y;
-        }
+        for (int u = 0; u < 6; ++u) pr[u] = i0 + u * WK_THREADS < nord ? out_r[tq0 + i0 + u * WK_THREADS] : make_int2(-1, -1);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (lane < m4[u]) st_l[mo4[u] + lane] = (unsigned short)((y4[u] >> 16) ? (y4[u] >> 16) - 1u : WK_FREE);
-            if (m4[u] > WAVE) {
-                const uint2 *idle = D.idle + ((size_t)(c + u * WK_WAVES) * S.R + r) * S.idle_cap;
-                for (int i = WAVE + lane; i < m4[u]; i += WAVE) { const unsigned y = idle[i].y; st_l[mo4[u] + i] = (unsigned short)((y >> 16) ? (y >> 16) - 1u : WK_FREE); }
-            }
-        }
+        for (int u = 0; u < 6; ++u)
+            if (pr[u].x != -1) st_l[moff_l[(unsigned)pr[u].x >> 16] + (pr[u].x & 0xFFFF)] = rq_l[i0 + u * WK_THREADS];
     }
     PROF_STAMP(26);
     // dry orders: everything behind a searching cluster's exhaustion point
@@ -3115,7 +3121,6 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     //      records are made by wavefronts 1..3, which scan the dry orders up to WK_NS ahead of the walk, in rank order, claiming
     //      them through s_cursor (dfs_scan: why a scan against a moving state is exact).  Wavefront 0 scans itself only when
     //      every kept candidate has died, or when a redo made an order dry that the cursor had already passed.
-    const int stride = dfs_rec_ints(S.seq_pad);
     auto next_dry = [&](int from) -> int {
         int best = IMAX;
         for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
@@ -3126,10 +3131,14 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         return wave_min_i32(best);
     };
     if (wave == 0) {
-        int ev_acc = 0;
+        int nlog = 0;
+        int4 *slog = D.slog + (size_t)r * mto;
         int rho = next_dry(0);
+#ifdef WKDEBUG
+        int dbg_ev = 0;
+#endif
 #ifdef VDS_PROF
-        unsigned long long p_wait = 0, p_chain = 0, p_seg[4] = {0, 0, 0, 0};
+        unsigned long long p_wait = 0, p_chain = 0, p_seg[4] = {0, 0, 0, 0}, p_cnt[4] = {0, 0, 0, 0};
 #endif
         while (rho != IMAX) {
             const int q = tq0 + (int)qr_l[rho];
@@ -3156,82 +3165,78 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
 #define PSEG(i) do { } while (0)
 #endif
             if (slot >= 0) {
-                rec = pool_l + slot * stride;
+                rec = pool_l + slot * WK_REC;
             } else {
                 dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
-                wave_fence();
+                wave_order();
 #ifdef VDS_PROF
-                if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 4] += 1;
+                p_cnt[2] += 1;
 #endif
             }
-            unsigned ck[JB];
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb) ck[jb] = rec[jb * WAVE + lane];
-            int2 e = make_int2(IMAX, 0);
-            if (lane < WK_K) e = reinterpret_cast<const int2 *>(rec + S.seq_pad)[lane];
-            int nl = (int)rec[S.seq_pad + 2 * WK_K];
-            // :986-991 runs for every visited cluster: the alive counts as they stand NOW; and the stamps of the candidates
-            int alive = 0;
-            int lmv[JB], scv[JB];
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb) {
-                lmv[jb] = 0; scv[jb] = 0;
-                if (ck[jb] != 0xFFFFFFFFu) {
-                    const int cjv = (int)(ck[jb] & 0xFFFFu), kv = (int)(ck[jb] >> 16);
-                    lmv[jb] = lm_l[cjv]; scv[jb] = sc_l[cjv];
-                    alive += m0_l[cjv] - min(kv, lmv[jb]) - scv[jb];
-                }
-            }
+            int4 e = make_int4(IMAX, 0, 0, 0);
+            if (lane < WK_K) e = reinterpret_cast<const int4 *>(rec)[lane];
+            int nl = (int)rec[4 * WK_K];
             int stv = lane < nl ? (int)st_l[e.y] : -1;
             if (slot >= 0) {
-                wave_fence();
+                wave_order();
                 if (lane == 0) lds_release(&s_slot[slot], 0);
             }
-            PSEG(0);
-            const int rs = row_sum_i32(alive);
-            const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
-            ev_acc += tot;
-            int2 res = make_int2(-1, -1);
-            if (tot > 0) {
-                unsigned long long okb = ballot(stv > rho);
-                if (okb == 0ull) {             // every kept candidate has been taken since: scan again, on the state as it is
-                    dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
-                    wave_fence();
-                    e = make_int2(IMAX, 0);
-                    if (lane == 0) { e = reinterpret_cast<const int2 *>(slot_l + S.seq_pad)[0]; stv = (int)st_l[e.y]; }
-                    okb = 1ull;
+            unsigned long long okb = ballot(stv > rho);
+            if (nl > 0 && okb == 0ull) {           // every kept candidate has been taken since: scan again, on the state as it is
+                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
+                wave_order();
+                e = make_int4(IMAX, 0, 0, 0);
+                if (lane < WK_K) e = reinterpret_cast<const int4 *>(slot_l)[lane];
+                nl = (int)slot_l[4 * WK_K];
+                stv = lane < nl ? (int)st_l[e.y] : -1;
+                okb = ballot(stv > rho);
 #ifdef VDS_PROF
-                    if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 4] += 1;
+                p_cnt[2] += 1;
 #endif
+            }
+            PSEG(0);
+#ifdef WKDEBUG
+            {   // reference: the alive counts of the visited clusters as they stand now
+                int alive = 0;
+                for (int jb = 0; jb < JB; ++jb) {
+                    const unsigned v = S.so_vis[(size_t)q * S.seq_pad + jb * WAVE + lane];
+                    if (v != 0xFFFFFFFFu) { const int c = (int)(v & 0xFFFFu); const int ls = ls_l[c]; alive += m0_l[c] - min((int)(v >> 16), ls >> 16) - (ls & 0xFFFF); }
                 }
+                const int rs = row_sum_i32(alive);
+                dbg_ev += rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
+            }
+#endif
+            if (okb != 0ull) {                     // (no candidate at all: nothing was alive when the order was scanned - rejected, :973;
+                                                   //  the fast kernel has written that result already)
                 const int first = __ffsll((long long)okb) - 1;
-                const int key = rdlane(e.x, first), idx = rdlane(e.y, first);
+                const int key = rdlane(e.x, first), idx = rdlane(e.y, first), ckw = rdlane(e.z, first);
                 int a = rdlane(stv, first);                 // the winner's stamp: free, or the own-cluster order that took it later
                 const int wc = key >> 16;
                 if ((long long)wc <= S.reject_threshold) {
-                    const int jw = (key >> 8) & 255;
-                    int ckw = 0, lmw = 0, scw = 0;
-#pragma unroll
-                    for (int jb = 0; jb < JB; ++jb) {
-                        const int u0 = rdlane((int)ck[jb], jw & 63), u1 = rdlane(lmv[jb], jw & 63), u2 = rdlane(scv[jb], jw & 63);
-                        const bool me = (jw >> 6) == jb;
-                        ckw = me ? u0 : ckw; lmw = me ? u1 : lmw; scw = me ? u2 : scw;
-                    }
-                    const int wcl = ckw & 0xFFFF, kw = (int)((unsigned)ckw >> 16);
-                    scw += 1;
+                    const int wcl = ckw & 0xFFFF;
                     const int mo = moff_l[wcl];
                     const int wpos = idx - mo;
                     WKCHK(wcl < C && wpos >= 0 && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
-                    if (lane == 0) { st_l[idx] = (unsigned short)rho; sc_l[wcl] = scw; atomicAdd(&tk_l[wcl], min(kw, lmw)); }
-                    res = make_int2((int)(((unsigned)wcl << 16) | (unsigned)wpos), wc);
-                    wave_fence();
+                    // the steal: stamp, and a log entry {rank, cluster | k, result} - staged in LDS and written out 64 at a time (an
+                    // HBM store per served order would cost this wavefront a round trip at its next register reuse); the
+                    // order's result reaches D.out from the log, after the walk
+                    if (lane == 0) {
+                        st_l[idx] = (unsigned short)rho;
+                        int *lg = lg_l + 4 * (nlog & (WAVE - 1));
+                        lg[0] = rho; lg[1] = ckw; lg[2] = (int)(((unsigned)wcl << 16) | (unsigned)wpos); lg[3] = wc;
+                    }
+                    ++nlog;
+                    if ((nlog & (WAVE - 1)) == 0)
+                        slog[nlog - WAVE + lane] = make_int4(lg_l[4 * lane], lg_l[4 * lane + 1], lg_l[4 * lane + 2], lg_l[4 * lane + 3]);
+                    wave_order();
 #ifdef VDS_PROF
-                    if (prof && lane == 0) { g_prof[(size_t)pwave * PROF_SLOTS + 2] += 1; if (a != (int)WK_FREE) g_prof[(size_t)pwave * PROF_SLOTS + 3] += 1; }
+                    p_cnt[0] += 1; if (a != (int)WK_FREE) p_cnt[1] += 1;
 #endif
                     PSEG(1);
 #ifdef VDS_PROF
                     const unsigned long long p_c0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
+                    int exhausted = 0;
                     if (a != (int)WK_FREE) {
                         // the stolen vehicle had been taken later by own-cluster order a of wcl: that order picks again among the
                         // entries alive at ITS time (stamp > a); if its new pick had been taken by a later order, that one picks
@@ -3258,22 +3263,21 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                             }
                             const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
                             if (minc == IMAX) {
-                                lmw -= 1;
+                                exhausted = 1;
                                 if (lane == 0) {
-                                    lm_l[wcl] = lmw;
                                     if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
-                                    else out_r[y] = make_int2(-1, -1);
+                                    out_r[y] = make_int2(-1, -1);           // (rejected, unless the search serves it - then the log says so)
                                 }
                                 break;
                             }
                             const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
                             const int bst = (int)st_l[mo + minp];
-                            wave_fence();
+                            wave_order();
                             if (lane == 0) {
                                 st_l[mo + minp] = (unsigned short)a;
                                 out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
                             }
-                            wave_fence();
+                            wave_order();
                             if (bst == (int)WK_FREE) break;
                             a = bst;
                         }
@@ -3281,27 +3285,31 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
 #ifdef VDS_PROF
                     if (prof) { __builtin_amdgcn_s_waitcnt(0); p_chain += __builtin_amdgcn_s_memtime() - p_c0; }
 #endif
-                    // own matches and steals of the cluster, published as one word once the order is served
-                    wave_fence();
-                    if (lane == 0) lds_release(&ls_l[wcl], (lmw << 16) | scw);
+                    // own matches << 16 | steals of the cluster: one update once the order is served (what the scans read)
+                    wave_order();
+                    if (lane == 0) atomicAdd(&ls_l[wcl], 1 - (exhausted << 16));
                 }
             }
 #ifdef VDS_PROF
             if (prof) p_ts = __builtin_amdgcn_s_memtime();
+            p_cnt[3] += 1;
 #endif
-            if (lane == 0) out_r[q] = res;
-#ifdef VDS_PROF
-            if (prof && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 6] += 1;
-#endif
-            wave_fence();
+            wave_order();
             rho = next_dry(rho + 1);
             PSEG(2);
         }
-        if (lane == 0) { s_ev = ev_acc; lds_release(&s_done, 1); }
+        if (lane < (nlog & (WAVE - 1)))
+            slog[(nlog & ~(WAVE - 1)) + lane] = make_int4(lg_l[4 * lane], lg_l[4 * lane + 1], lg_l[4 * lane + 2], lg_l[4 * lane + 3]);
+        if (lane == 0) { s_nlog = nlog; lds_release(&s_done, 1); }
+#ifdef WKDEBUG
+        if (lane == 0) s_dbg = dbg_ev;
+#endif
 #ifdef VDS_PROF
         if (prof && lane == 0) {
             g_prof[(size_t)pwave * PROF_SLOTS + 8] += p_wait; g_prof[(size_t)pwave * PROF_SLOTS + 9] += p_chain;
             for (int i = 0; i < 3; ++i) g_prof[(size_t)pwave * PROF_SLOTS + 12 + i] += p_seg[i];
+            g_prof[(size_t)pwave * PROF_SLOTS + 2] += p_cnt[0]; g_prof[(size_t)pwave * PROF_SLOTS + 3] += p_cnt[1];
+            g_prof[(size_t)pwave * PROF_SLOTS + 4] += p_cnt[2]; g_prof[(size_t)pwave * PROF_SLOTS + 6] += p_cnt[3];
         }
 #endif
     } else {
@@ -3333,12 +3341,12 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
 #ifdef VDS_PROF
             const unsigned long long p_s0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
-            dfs_scan<U8, JB>(S, D, r, q, b, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, pool_l + slot * stride
+            dfs_scan<U8, JB>(S, D, r, q, b, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, pool_l + slot * WK_REC
 #ifdef VDS_PROF
                          , prof ? p_acc : nullptr
 #endif
                          );
-            wave_fence();
+            wave_order();
             if (lane == 0) lds_release(&s_slot[slot], (b << 2) | 2);
 #ifdef VDS_PROF
             if (prof) { p_scan += __builtin_amdgcn_s_memtime() - p_s0; p_n += 1; }
@@ -3353,9 +3361,91 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     }
     __syncthreads();
     PROF_STAMP(1);
-    // ---- evaluations of the own-cluster orders and the final list lengths, closed form: the own matches of a bucket are its
-    //      first n orders; the i-th looked at m0 - i - (steals before it) entries, and a steal that came after k of the
-    //      bucket's orders is seen by the n - min(k, n) own matches behind it (tk = sum of min(k, n) over the steals)
+    // ---- evaluations (:986-991 for the dry orders, :924 for the own-cluster ones), after the fact: with the final own matches
+    //      lm of every bucket and the steal log {rank of the thief, cluster | orders of that cluster before the thief << 16},
+    //        dry order of rank p:  sum over its visited clusters c of  m0_c - min(k_c(p), lm_c) - #steals from c by ranks < p
+    //      (the own matches of a bucket are a prefix of its orders, and an exhaustion after p's turn only removes matches p never
+    //      counted: min(k, lm at p's turn) = min(k, final lm));
+    //        own-cluster orders of bucket c (its first lm_c):  lm*m0 - lm(lm-1)/2 - (steals*lm - tk),  tk = sum over the steals
+    //      from c of min(k, lm_c) - a steal that came after k of the bucket's orders is seen by the lm - min(k, lm) matches behind it
+    const int nlog = s_nlog;
+    const int4 *slog = D.slog + (size_t)r * mto;
+    for (int c = threadIdx.x; c < C; c += WK_THREADS) { const int ls = ls_l[c]; lm_l[c] = ls >> 16; sc_l[c] = ls & 0xFFFF; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nlog; i += WK_THREADS) {
+        const int4 sl = slog[i];
+        const int c = sl.y & 0xFFFF;
+        atomicAdd(&tk_l[c], min((int)((unsigned)sl.y >> 16), lm_l[c]));
+        out_r[tq0 + (int)qr_l[sl.x]] = make_int2(sl.z, sl.w);          // the served dry order's result
+    }
+    {
+        int acc = 0;        // per lane; reduced at the end
+        // (a) per dry order: sum of m0 - min(k, lm) over its visit sequence; the dry orders are dealt round-robin to the wavefronts
+        //     (lane l holds word l of the dry bits of a 64-word block), four orders' rows in flight
+        for (int wb = 0; wb < nwords; wb += WAVE) {
+            const unsigned myw = wb + lane < nwords ? dry_bits[wb + lane] : 0u;
+            int inc = __popc(myw);
+            const int own = inc;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            const int excl = inc - own, total = rdlane(inc, WAVE - 1);
+            for (int k0 = wave; k0 < total; k0 += 4 * WK_WAVES) {
+                unsigned vv[4][JB];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kx = k0 + u * WK_WAVES;
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb) vv[u][jb] = 0xFFFFFFFFu;
+                    if (kx < total) {
+                        const int hl = __ffsll((long long)ballot(excl <= kx && kx < excl + own)) - 1;      // the lane whose word holds the kx-th dry order
+                        unsigned bits = (unsigned)rdlane((int)myw, hl);
+                        for (int d = kx - rdlane(excl, hl); d > 0; --d) bits &= bits - 1u;
+                        const int rk = (wb + hl) * 32 + __ffs((int)bits) - 1;
+                        const unsigned *vis = S.so_vis + (size_t)(tq0 + (int)qr_l[rk]) * S.seq_pad;
+#pragma unroll
+                        for (int jb = 0; jb < JB; ++jb) vv[u][jb] = vis[jb * WAVE + lane];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb)
+                        if (vv[u][jb] != 0xFFFFFFFFu) { const int c = (int)(vv[u][jb] & 0xFFFFu); acc += m0_l[c] - min((int)(vv[u][jb] >> 16), lm_l[c]); }
+            }
+        }
+        // (b) per searching cluster with dry orders: the steals from the clusters of its visit sequence, counted once per dry order
+        //     of a later rank (the dry orders of a bucket are its last ones, in rank order)
+        unsigned *bm = bm_l + wave * bmw;
+        for (int pc = wave; pc < C; pc += WK_WAVES) {
+            if (!(cdA_l[pc] & CAPABLE)) continue;
+            const int qa = pc == 0 ? tq0 : qend_l[pc - 1];
+            const int qd = qa + lm_l[pc], qe = qend_l[pc];
+            if (qd >= qe || nlog == 0) continue;
+            for (int w = lane; w < bmw; w += WAVE) bm[w] = 0u;
+            wave_order();
+            const int s0 = S.dfs_off[pc], n = S.dfs_off[pc + 1] - s0;
+            for (int j = lane; j < n; j += WAVE) { const int c = S.dfs_seq[s0 + j]; atomicOr(&bm[c >> 5], 1u << (c & 31)); }
+            wave_order();
+            for (int i0 = 0; i0 < nlog; i0 += WAVE) {
+                int2 sl = make_int2(IMAX, 0);
+                if (i0 + lane < nlog) { const int4 s4 = slog[i0 + lane]; sl = make_int2(s4.x, s4.y); }
+                const int c = sl.y & 0xFFFF;
+                const bool member = i0 + lane < nlog && ((bm[c >> 5] >> (c & 31)) & 1u);
+                for (int qq = qd; qq < qe; ++qq) {
+                    const int rk = (int)rq_l[qq - tq0];
+                    const int cn = popc64(ballot(member && sl.x < rk));        // (the vote outside the lane-0 branch)
+                    if (lane == 0) acc -= cn;
+                }
+            }
+            wave_order();
+        }
+        const int rs = row_sum_i32(acc);
+        const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
+        if (lane == 0 && tot != 0) atomicAdd(&s_ev, tot);
+    }
+    __syncthreads();
+#ifdef WKDEBUG
+    if (threadIdx.x == 0 && s_ev != s_dbg) printf("k_dfs_walk evals: r %d t %d post-hoc %d walk %d nlog %d\n", r, t, s_ev, s_dbg, nlog);
+#endif
     for (int c = threadIdx.x; c < C; c += WK_THREADS) {
         const int nm = lm_l[c], m0 = m0_l[c], sc = sc_l[c];
         const int ev = nm * m0 - (nm * (nm - 1)) / 2 - (sc * nm - tk_l[c]);
@@ -3440,7 +3530,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 if (keep) e = idle[i];
             }
             const unsigned long long kb = ballot(keep);
-            wave_fence();
+            wave_order();
             if (keep) idle[kept + popc64(kb & lanemask_lt())] = e;
             kept += popc64(kb);
         }
@@ -3753,7 +3843,7 @@ int replica3_prepare() {      // opt in to more than 64 KB of dynamic LDS per wo
     return (a == hipSuccess && b == hipSuccess) ? 0 : -1;
 }
 
-size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, S.seq_pad); }
+size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders); }
 
 // hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
 void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
