@@ -3378,6 +3378,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         atomicAdd(&tk_l[c], min((int)((unsigned)sl.y >> 16), lm_l[c]));
         out_r[tq0 + (int)qr_l[sl.x]] = make_int2(sl.z, sl.w);          // the served dry order's result
     }
+    PROF_STAMP(29);
     {
         int acc = 0;        // per lane; reduced at the end
         // (a) per dry order: sum of m0 - min(k, lm) over its visit sequence; the dry orders are dealt round-robin to the wavefronts
@@ -3412,32 +3413,65 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                         if (vv[u][jb] != 0xFFFFFFFFu) { const int c = (int)(vv[u][jb] & 0xFFFFu); acc += m0_l[c] - min((int)(vv[u][jb] >> 16), lm_l[c]); }
             }
         }
+        PROF_STAMP(30);
         // (b) per searching cluster with dry orders: the steals from the clusters of its visit sequence, counted once per dry order
-        //     of a later rank (the dry orders of a bucket are its last ones, in rank order)
+        //     of a later rank (the dry orders of a bucket are its last ones, in rank order); four clusters' sequences in flight
         unsigned *bm = bm_l + wave * bmw;
-        for (int pc = wave; pc < C; pc += WK_WAVES) {
-            if (!(cdA_l[pc] & CAPABLE)) continue;
-            const int qa = pc == 0 ? tq0 : qend_l[pc - 1];
-            const int qd = qa + lm_l[pc], qe = qend_l[pc];
-            if (qd >= qe || nlog == 0) continue;
-            for (int w = lane; w < bmw; w += WAVE) bm[w] = 0u;
-            wave_order();
-            const int s0 = S.dfs_off[pc], n = S.dfs_off[pc + 1] - s0;
-            for (int j = lane; j < n; j += WAVE) { const int c = S.dfs_seq[s0 + j]; atomicOr(&bm[c >> 5], 1u << (c & 31)); }
-            wave_order();
-            for (int i0 = 0; i0 < nlog; i0 += WAVE) {
-                int2 sl = make_int2(IMAX, 0);
-                if (i0 + lane < nlog) { const int4 s4 = slog[i0 + lane]; sl = make_int2(s4.x, s4.y); }
-                const int c = sl.y & 0xFFFF;
-                const bool member = i0 + lane < nlog && ((bm[c >> 5] >> (c & 31)) & 1u);
-                for (int qq = qd; qq < qe; ++qq) {
-                    const int rk = (int)rq_l[qq - tq0];
-                    const int cn = popc64(ballot(member && sl.x < rk));        // (the vote outside the lane-0 branch)
-                    if (lane == 0) acc -= cn;
+        int2 sl0 = make_int2(IMAX, 0);
+        if (lane < nlog) { const int4 s4 = slog[lane]; sl0 = make_int2(s4.x, s4.y); }
+        int taken = 0;          // searching clusters with dry orders met so far: dealt round-robin to the wavefronts
+        for (int cb = 0; cb < C && nlog > 0; cb += WAVE) {
+            const int cme = cb + lane;
+            int qdm = 0, qem = 0;
+            if (cme < C && (cdA_l[cme] & CAPABLE)) { qdm = (cme == 0 ? tq0 : qend_l[cme - 1]) + lm_l[cme]; qem = qend_l[cme]; }
+            unsigned long long dm = ballot(qdm < qem);
+            while (dm != 0ull) {
+                int cjs[4][JB], qd4[4], qe4[4], n4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    qd4[u] = 0; qe4[u] = 0; n4[u] = 0;
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb) cjs[u][jb] = 0;
+                    while (dm != 0ull && (taken & (WK_WAVES - 1)) != wave) { dm &= dm - 1ull; ++taken; }
+                    if (dm != 0ull) {
+                        const int l = __ffsll((long long)dm) - 1;
+                        dm &= dm - 1ull; ++taken;
+                        const int pc = cb + l;
+                        qd4[u] = rdlane(qdm, l); qe4[u] = rdlane(qem, l);
+                        const int s0 = S.dfs_off[pc];
+                        n4[u] = S.dfs_off[pc + 1] - s0;
+#pragma unroll
+                        for (int jb = 0; jb < JB; ++jb) if (jb * WAVE + lane < n4[u]) cjs[u][jb] = S.dfs_seq[s0 + jb * WAVE + lane];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (qd4[u] >= qe4[u]) continue;
+                    for (int w = lane; w < bmw; w += WAVE) bm[w] = 0u;
+                    wave_order();
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb) if (jb * WAVE + lane < n4[u]) atomicOr(&bm[cjs[u][jb] >> 5], 1u << (cjs[u][jb] & 31));
+                    wave_order();
+                    for (int i0 = 0; i0 < nlog; i0 += WAVE) {
+                        int2 sl = sl0;
+                        if (i0 > 0) { sl = make_int2(IMAX, 0); if (i0 + lane < nlog) { const int4 s4 = slog[i0 + lane]; sl = make_int2(s4.x, s4.y); } }
+                        const int c = sl.y & 0xFFFF;
+                        const bool member = i0 + lane < nlog && ((bm[c >> 5] >> (c & 31)) & 1u);
+                        // the dry orders of the bucket, one per lane: the steals each of them counts
+                        for (int qb = qd4[u]; qb < qe4[u]; qb += WAVE) {
+                            const int rkm = qb + lane < qe4[u] ? (int)rq_l[qb + lane - tq0] : -1;
+                            const int nq = min(WAVE, qe4[u] - qb);
+                            for (int x = 0; x < nq; ++x) {
+                                const int cn = popc64(ballot(member && sl.x < rdlane(rkm, x)));        // (the vote outside the lane-0 branch)
+                                if (lane == 0) acc -= cn;
+                            }
+                        }
+                    }
+                    wave_order();
                 }
             }
-            wave_order();
         }
+        PROF_STAMP(31);
         const int rs = row_sum_i32(acc);
         const int tot = rdlane(rs, 0) + rdlane(rs, 16) + rdlane(rs, 32) + rdlane(rs, 48);
         if (lane == 0 && tot != 0) atomicAdd(&s_ev, tot);
