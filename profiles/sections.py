@@ -11,7 +11,7 @@ env.reset(w.vehicle_nodes(R))
 T = env.T
 env.run(T); env.sync()
 env.reset_again()
-buf = np.zeros(16, dtype=np.uint64)
+buf = np.zeros(32, dtype=np.uint64)
 env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
 env._lib.vds_debug_ablate(env._h, 128)
 env.profile(True); env.run(T); ms = env.profile_read(T + 8); env.profile(False)

@@ -8,7 +8,7 @@ w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
 T = env.T
-buf = np.zeros(16, dtype=np.uint64)
+buf = np.zeros(32, dtype=np.uint64)
 env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
 env._lib.vds_debug_ablate(env._h, 128)
 env.profile(True); env.run(T); ms = env.profile_read(T + 8); env.profile(False)
@@ -22,15 +22,25 @@ if env.main_kernel() == "k_tick_replica3":
              "5 per dry order: barrier + winner (+ redo) + barrier", None, "7 evaluations + resolve + compaction + flush"]
     nw = R * 8
 if env.main_kernel() == "k_dfs_hybrid":
-    names = ["0 k_dfs_walk: tables + stamps into LDS + dry bits", "1 k_dfs_walk: the walk (wavefront 0)", None, None, None, "5 k_dfs_walk: evaluations from the stamps", None, "7 k_dfs_walk: resolve + compaction"]
-    nw = R * 4
-    print("dry orders per replica-tick %.1f, served by a neighbour %.1f, with a redo chain %.2f, scanned again by the walk %.2f" % (
+    # k_dfs_walk, 4 wavefronts per replica: cycles per wavefront and tick between the stamps (all wavefronts wait at the barriers)
+    sec = [("tables (ranks, lengths) + barrier", 24), ("prefix of the list lengths + barrier", 25), ("stamps from the preliminary results", 26), ("dry bits + barrier", 0),
+           ("the walk (wavefront 0 serves, 1-3 scan)", 1), ("steal log -> results, tk", 29), ("evaluations (a): dry orders' visit rows", 30),
+           ("evaluations (b): steals per searching cluster", 31), ("reduce + closed form + barrier", 5), ("resolve: vehicle ids, arrivals, counters", 27),
+           ("compaction, lists up to 64", 28), ("compaction, longer lists", 7)]
+    print("dry orders per replica-tick %.1f, served by a neighbour %.1f, with a redo chain %.2f, scanned (again) by the walk itself %.2f" % (
         buf[6] / R / T, buf[2] / R / T, buf[3] / R / T, buf[4] / R / T))
     print("wavefront 0 per replica-tick: %.0f cycles waiting for a record, %.0f in redo chains; scanning wavefronts: %.1f scans of %.0f cycles" % (
         buf[8] / R / T, buf[9] / R / T, buf[11] / R / T, buf[10] / max(1, buf[11])))
-    print("wavefront 0 per served order: record + alive counts + candidate stamps %.0f cycles, winner + steal %.0f, result + next dry order %.0f" % (
+    print("wavefront 0 per served order: record + candidate stamps %.0f cycles, winner + steal (without the chain) %.0f, next dry order %.0f" % (
         buf[12] / max(1, buf[6]), buf[13] / max(1, buf[6]), buf[14] / max(1, buf[6])))
-    buf[2] = buf[3] = buf[4] = 0
+    sc = [float(buf[16 + i]) / max(1, buf[11]) for i in range(5)]
+    print("one scan: visit row + bounds %.0f, alive counts %.0f, first pass %.0f, second pass %.0f, the %s best %.0f cycles; %.2f eight-slot groups" % (
+        sc[0], sc[1], sc[2], sc[3], "WK_K", sc[4], float(buf[21]) / max(1, buf[11])))
+    print("instrumented: %.2f ms/launch" % ms.mean())
+    tot = sum(float(buf[i]) for _, i in sec)
+    for n, i in sec:
+        print("%-50s %9.0f cycles/wave/tick  %5.1f%%" % (n, buf[i] / (R * 4) / T, 100.0 * buf[i] / tot))
+    sys.exit(0)
 print(env.main_kernel())
 tot = float(buf[:6].sum() + buf[7])
 print("instrumented: %.2f ms/launch; DFS rounds per replica-tick: %.1f" % (ms.mean(), buf[6] / nw / T))

@@ -1276,10 +1276,10 @@ int vds_debug_ablate(vds_handle *h, int32_t flags) {
     return VDS_OK;
 }
 
-int vds_debug_read_prof(vds_handle *h, uint64_t *out16) {
-    if (!h || !out16) return VDS_EINVAL;
+int vds_debug_read_prof(vds_handle *h, uint64_t *out32) {
+    if (!h || !out32) return VDS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    read_prof((unsigned long long *)out16, h->stream);
+    read_prof((unsigned long long *)out32, h->stream);
     return VDS_OK;
 }
 

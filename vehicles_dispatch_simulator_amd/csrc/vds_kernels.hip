@@ -44,20 +44,17 @@ __device__ unsigned long long g_prof[PROF_WAVES * PROF_SLOTS];   // bit7 of g_ab
 #define PROF_STAMP(i) do { } while (0)
 #define PROF_STAMP_NW(i) do { } while (0)
 #endif
-unsigned long long g_prof_ext[16];    // slots 16..23 of the last read_prof (scan sections), printed when VDS_PROF_EXT is set
+// out[0..14]: slots 0..14 summed over the wavefronts, out[15]: wavefronts that recorded slot 6, out[16..31]: slots 16..31
 void read_prof(unsigned long long *out, hipStream_t st) {
-    for (int i = 0; i < 16; ++i) g_prof_ext[i] = 0;
     (void)hipStreamSynchronize(st);
     static unsigned long long host[PROF_WAVES * PROF_SLOTS];
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(host));
-    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int i = 0; i < 32; ++i) out[i] = 0;
     for (size_t w = 0; w < PROF_WAVES; ++w) {
-        for (int i = 0; i < 8; ++i) out[i] += host[w * PROF_SLOTS + i];
-        for (int i = 8; i < 15; ++i) out[i] += host[w * PROF_SLOTS + i];
-        for (int i = 16; i < 32; ++i) g_prof_ext[i - 16] += host[w * PROF_SLOTS + i];
+        for (int i = 0; i < 15; ++i) out[i] += host[w * PROF_SLOTS + i];
+        for (int i = 16; i < 32; ++i) out[i] += host[w * PROF_SLOTS + i];
         if (host[w * PROF_SLOTS + 6]) out[15]++;
     }
-    if (getenv("VDS_PROF_EXT")) { for (int i = 0; i < 16; ++i) fprintf(stderr, "prof_ext[%d] = %llu\n", i, g_prof_ext[i]); }
     memset(host, 0, sizeof(host));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, sizeof(host));
 }
@@ -3550,23 +3547,35 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         }
     }
     PROF_STAMP(28);
-    for (int c = wave; c < C; c += WK_WAVES) {
-        const int mo = moff_l[c], m0 = m0_l[c];
-        if (sc_l[c] == m0 || m0 <= WAVE) continue;
-        uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
-        int kept = 0;
-        for (int base = 0; base < m0; base += WAVE) {
-            const int i = base + lane;
-            uint2 e = make_uint2(0u, 0u);
-            bool keep = false;
-            if (i < m0) {
-                keep = (unsigned)st_l[mo + i] == WK_FREE;
-                if (keep) e = idle[i];
+    {   // the lists of more than 64 entries that lost something (rare): found by a vote, dealt round-robin to the wavefronts
+        int met = 0;
+        for (int cb = 0; cb < C; cb += WAVE) {
+            const int cme = cb + lane;
+            unsigned long long lm = ballot(cme < C && m0_l[min(cme, C - 1)] > WAVE && sc_l[min(cme, C - 1)] != m0_l[min(cme, C - 1)]);
+            for (; lm != 0ull; lm &= lm - 1ull, ++met) {
+                if ((met & (WK_WAVES - 1)) != wave) continue;
+                const int c = cb + __ffsll((long long)lm) - 1;
+                const int mo = moff_l[c], m0 = m0_l[c];
+                uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;
+                int kept = 0;
+                for (int base = 0; base < m0; base += 4 * WAVE) {      // four chunks read before the first is written (targets never lie ahead)
+                    uint2 e4[4];
+                    bool k4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = base + u * WAVE + lane;
+                        e4[u] = make_uint2(0u, 0u);
+                        k4[u] = i < m0 && (unsigned)st_l[mo + min(i, m0 - 1)] == WK_FREE;
+                        if (k4[u]) e4[u] = idle[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long kb = ballot(k4[u]);
+                        if (k4[u]) idle[kept + popc64(kb & lanemask_lt())] = e4[u];
+                        kept += popc64(kb);
+                    }
+                }
             }
-            const unsigned long long kb = ballot(keep);
-            wave_order();
-            if (keep) idle[kept + popc64(kb & lanemask_lt())] = e;
-            kept += popc64(kb);
         }
     }
     PROF_STAMP(7);
