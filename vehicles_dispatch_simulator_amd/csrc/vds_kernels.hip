@@ -777,7 +777,7 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
                 if (idx < A) key_row[idx] = key[a];
             }
         }
-        wave_fence();
+        wave_order();
         int rank[4] = {0, 0, 0, 0};
         if (Amax <= 16) {           // common case: one arrival per lane
 #pragma unroll 4
@@ -794,14 +794,14 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
                 for (int a = 0; a < 4; ++a) rank[a] += (ok && kk < key[a]) ? 1 : 0;
             }
         }
-        wave_fence();   // every key has been read: the scratch now takes the ranked arrivals
+        wave_order();   // every key has been read: the scratch now takes the ranked arrivals
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int idx = a * 16 + l16;
             if (a * 16 < Amax && idx < A) arr_row[rank[a]] = make_uint2((unsigned)e[a].x, (unsigned)meta_dest(e[a].w));
         }
         if (rowvalid && l16 == 0 && A > 0) D.ring_cnt[si] = 0;
-        wave_fence();
+        wave_order();
     }
     PROF_STAMP(2);
     if (PD ? ballot(k > 0) == 0 : k == 0) {
@@ -3246,16 +3246,24 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                         const int boff = U8 ? cd.z : cd.y;
                         const int m0 = m0_l[wcl];
                         const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
+                        // the list's node words travel together with the first victim's pickup node (one HBM level, not two), and
+                        // serve every step of the chain; lists of more than 64 entries read them step by step
+                        unsigned yv0 = 0u;
+                        if (m0 <= WAVE && lane < m0) yv0 = idle[lane].y;
                         while (true) {
                             const int y = tq0 + (int)qr_l[a];
                             const int pick = S.so_rec[y].y & 0xFFFF;
                             int lc = IMAX, lp = -1;
-                            for (int base = 0; base < m0; base += WAVE) {
-                                const int ii = base + lane;
-                                if (ii < m0 && (int)st_l[mo + ii] > a) {
-                                    const int lo2 = (int)(idle[ii].y & 0xFFFF);
-                                    const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
-                                    if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
+                            if (m0 <= WAVE) {
+                                if (lane < m0 && (int)st_l[mo + lane] > a) { lc = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + (int)(yv0 & 0xFFFF))); lp = lane; }
+                            } else {
+                                for (int base = 0; base < m0; base += WAVE) {
+                                    const int ii = base + lane;
+                                    if (ii < m0 && (int)st_l[mo + ii] > a) {
+                                        const int lo2 = (int)(idle[ii].y & 0xFFFF);
+                                        const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
+                                        if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
+                                    }
                                 }
                             }
                             const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
