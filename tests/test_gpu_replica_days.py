@@ -60,6 +60,8 @@ def test_every_replica_replays_its_own_day(name, mode):
     init[5] = init[0]                             # same day, same start: must stay identical
     env = mk_env(g, R, **MODES[mode])
     env.load_order_days(days, replica_day)
+    if mode == "fast" and bool(g["neighbor_can_server"]) and int(g["depth_limit"]) > 0:
+        assert env.main_kernel() == "k_dfs_hybrid"          # per-row order streams in stamp mode: the hybrid tick serves interleaved days too
     env.reset(init)
     oracles = []
     for r in range(R):

@@ -742,7 +742,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         // hybrid tick: the fast kernel's preconditions (packed keys, no live pickup window, every cost block in LDS), one
         // order day per workgroup, 16-bit ranks / positions / columns, the walk's LDS footprint
         h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
-                       (Z.n_days <= 1 || Z.chunk_days) && Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
+                       Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
                        dfs_walk_lds(Z) + 1024 <= 64 * 1024 && Z.so_vis != nullptr;
         h->D.slog = nullptr;

@@ -612,16 +612,18 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (pos >= mnew) loc[s] = 0;
         dead[s] = pos < mnew ? 0 : IMAX;
     }
-    static_assert(!(PD && ST), "stamp mode: shared or workgroup-uniform order day");
     int recy = 0, recx = 0;
-    int recy4[4] = {0, 0, 0, 0};
+    int recy4[4] = {0, 0, 0, 0}, recx4[4] = {0, 0, 0, 0};
     int kmax = k;
-    if (ST && lane < k) recx = lds_rec[lane].x;            // stamp mode stages the order's rank in .x
+    if (ST && !PD && lane < k) recx = lds_rec[lane].x;     // stamp mode stages the order's rank in .x
     if (PD) {
         kmax = max(max(rdlane(k, 0), rdlane(k, 16)), max(rdlane(k, 32), rdlane(k, 48)));
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-            if (jj * 16 < kmax && jj * 16 + l16 < k) recy4[jj] = S.so_rec[q0 + jj * 16 + l16].y;
+            if (jj * 16 < kmax && jj * 16 + l16 < k) {
+                recy4[jj] = S.so_rec[q0 + jj * 16 + l16].y;
+                if (ST) recx4[jj] = S.so_rank[q0 + jj * 16 + l16];      // per-row order streams: the rank comes with the row's own records
+            }
     } else {
         if (lane < k) recy = lds_rec[lane].y;
     }
@@ -645,7 +647,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             const int rmin = live ? row_min_i32(best) : IMAX;
             const bool hit = ST ? rmin < ST_TAKEN : rmin != IMAX;
             const int wpos = rmin & 127;
-            const int mark = ST ? (ST_TAKEN | rdlane(recx, jj * 16 + ji)) : IMAX;       // stamp mode: the taker's rank rides in the dead mask
+            const int mark = ST ? (ST_TAKEN | (PD ? __builtin_amdgcn_ds_bpermute((rowbase + ji) << 2, recx4[jj]) : rdlane(recx, jj * 16 + ji))) : IMAX;   // stamp mode: the taker's rank rides in the dead mask
 #pragma unroll
             for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? mark : dead[s];
             res[jj] = (l16 == ji) ? rmin : res[jj];
@@ -3899,17 +3901,19 @@ size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max
 // hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
 void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
-    const int dm = S.n_days <= 1 ? 0 : 1;
+    const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
     if (S.u8_ok) {
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);
-        if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<true, 2, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
+        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
         else hipLaunchKernelGGL((k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
         if (S.seq_pad <= 64) hipLaunchKernelGGL((k_dfs_walk<true, 1>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
         else if (S.seq_pad <= 128) hipLaunchKernelGGL((k_dfs_walk<true, 2>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
         else hipLaunchKernelGGL((k_dfs_walk<true, 4>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
     } else {
-        if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<false, 2, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
         else hipLaunchKernelGGL((k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
         if (S.seq_pad <= 64) hipLaunchKernelGGL((k_dfs_walk<false, 1>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
         else if (S.seq_pad <= 128) hipLaunchKernelGGL((k_dfs_walk<false, 2>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
