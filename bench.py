@@ -104,11 +104,12 @@ def cpu_baseline_all_cores(w, init_rows, budget_s: float = 8.0, max_procs: int =
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="timed days (default 100: a 1.2 s timed region at configs[1])")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=1024, help="replicas PER GPU")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-neighbour-leg", action="store_true", help="skip the extra configs[3] (neighbour search) leg")
     ap.add_argument("--check", action="store_true", help="verify replica 0 against the oracle after the run")
     ap.add_argument("--distinct-days", type=int, default=16, help="extra leg: the same workload with this many different order days (0/1 = skip)")
     a = ap.parse_args()
@@ -260,6 +261,28 @@ def main():
             env2.close()
         per_days["value"] = per_days["interleaved"]["value"]
 
+    # ---- neighbour-search mode (rank 0, N = 1, only next to the headline workload): BASELINE configs[3] - the same city with
+    #      NeighborCanServer and a 2000 m service radius (DFS depth 2) - a few days, so that the line also shows the second tick path
+    nbr = None
+    if rank == 0 and world == 1 and a.workload == "cfg2" and not a.no_neighbour_leg:
+        w4 = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
+        env4 = w4.make_env(R, device=local_rank, stream=stream.cuda_stream)
+        env4.reset(w4.vehicle_nodes(R))
+        T4 = env4.T
+        env4.reset_again(); env4.run(T4)
+        torch.cuda.synchronize()
+        nd4 = max(2, min(a.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(nd4):
+            env4.reset_again(); env4.run(T4)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t1
+        env4.sync()
+        nbr = {"workload": "configs[3]: %d replicas/GPU x 192 clusters with neighbour DFS depth 2, 10k vehicles, 200k orders/day" % R,
+               "value": T4 * R * nd4 / dt4, "unit": "env-steps*replicas/s", "ms_per_step": dt4 / nd4 * 1e3, "steps": nd4,
+               "kernel": env4.main_kernel(), "evidence": "profiles/r02_cfg4_hybrid (bench.py --workload cfg4 --check: roofline, parity)"}
+        env4.close()
+
     check = None
     if a.check and rank == 0:
         from oracle.oracle import Oracle
@@ -302,6 +325,8 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_all
         if per_days is not None:
             out["per_replica_days"] = per_days
+        if nbr is not None:
+            out["neighbour_search"] = nbr
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
-B="python bench.py --no-cpu-baseline --distinct-days ${DISTINCT:-0} $@"
+B="python bench.py --no-cpu-baseline --no-neighbour-leg --distinct-days ${DISTINCT:-0} $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/write.log 2>&1
