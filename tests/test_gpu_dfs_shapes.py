@@ -84,3 +84,16 @@ def test_everything_is_delivered_to_one_cluster_bursts_of_arrivals():
     init = np.stack([synth.init_vehicle_nodes(random.Random(61 + r), city.N, V) for r in range(R)])
     cn = check(city, 2, V, O, 79, R, init, pick=pick, dele=dele)
     assert (cn[:, 2] > 800).all()                          # plenty of matches: vehicles pile up in cluster 7 and are found by the search
+
+
+def test_hundreds_of_dry_orders_per_slot():
+    """Few vehicles, many orders, every pickup in a handful of clusters: hundreds of dry orders per slot and replica - more than one
+    64-entry chunk of the hybrid tick's steal log, its record pool going round many times, redo chains that empty buckets."""
+    city = synth.make_city(seed=906, N=700, C=36)
+    V, R, O = 3000, 3, 40000
+    start, pick, dele = synth.make_orders(85, city.N, O)
+    hot = np.flatnonzero(city.node2cluster < 6)
+    pick = hot[synth.uniform_int(6, 11, np.arange(O), hot.size)].astype(np.int32)
+    init = np.stack([synth.init_vehicle_nodes(random.Random(71 + r), city.N, V) for r in range(R)])
+    cn = check(city, 2, V, O, 85, R, init, pick=pick, dele=dele)
+    assert (cn[:, 2] > 15000).all()      # on average more than 100 served per slot, most of them by a neighbour (30 of 36 clusters see no pickup)
