@@ -407,12 +407,7 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
                 post_arrival(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
     }
-    if (ST) {
-#pragma unroll
-        for (int s = 0; s < J; ++s)
-            if (stp[s] != 0u) idle[lane * J + s] = make_uint2(veh[s], loc[s] | (stp[s] << 16));
-        return;
-    }
+    if (ST) return;         // nothing is edited: who took which entry is in the preliminary results
     if (changed) {                                                 // :963 IdleVehicles.remove, order preserved
         int before = 0;
 #pragma unroll
@@ -667,11 +662,9 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         }
         if (rowvalid) {
 #pragma unroll
-            for (int s = 0; s < J; ++s) {
+            for (int s = 0; s < J; ++s) {       // only the appended arrivals are written: who took which entry is in the preliminary results
                 const int pos = l16 * J + s;
-                const bool taken = dead[s] != IMAX && dead[s] >= ST_TAKEN;
-                if (pos < mnew && (pos >= m || taken))
-                    idle[pos] = make_uint2(veh[s], (unsigned)loc[s] | (taken ? (unsigned)((dead[s] & 0xFFFF) + 1) << 16 : 0u));
+                if (pos >= m && pos < mnew) idle[pos] = make_uint2(veh[s], (unsigned)loc[s]);
             }
             if (l16 < 3) D.hdr[b * HDR_WORDS + l16] = l16 == HDR_ORDERS ? k : mnew;          // the list keeps its length until the walk commits
             if (l16 == CNT_ARRIVALS && A > 0) D.cnt[b * CNT_WORDS + l16] = cntv + A;
