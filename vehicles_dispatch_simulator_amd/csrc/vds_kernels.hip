@@ -336,8 +336,8 @@ __device__ int drain_ring(const Static &S, const State &D, size_t b, int t, int 
 // ---------------------------------------------------------------------------------------
 // Generic match phase of one bucket (own-cluster scan, :924-965).  Lane l holds idle positions
 // l*J .. l*J+J-1, so "lowest position" == "lowest lane, then lowest slot".
-// ST: stamp mode (see rows_match) - taken entries stay in the list and get rank + 1 into the high half of their node word,
-// results are {cl << 16 | list position, wait}, nothing is posted and m keeps the list length.
+// ST: stamp mode (see rows_match) - taken entries stay in the list, results are {cl << 16 | list position, wait}, nothing is
+// posted and m keeps the list length.
 template <int J, bool LDSBLK, typename CT = int, bool ST = false>
 __device__ void match_bucket(const Static &S, const State &D, int r, int t, int now, int &m, int q0, int k,
                              const CT *blk, int nc, uint2 *idle, long long &wait_sum, long long &value_sum,
@@ -345,9 +345,6 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
     const int lane = lane_id();
     unsigned veh[J], loc[J];
     bool av[J];
-    unsigned stp[J];
-#pragma unroll
-    for (int s = 0; s < J; ++s) stp[s] = 0u;
 #pragma unroll
     for (int s = 0; s < J; ++s) {
         int pos = lane * J + s;
@@ -361,7 +358,6 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
     for (int base = 0; base < k; base += WAVE) {
         const int kk = min(WAVE, k - base);
         int4 rec = lane < kk ? S.so_rec[q0 + base + lane] : make_int4(0, 0, 0, 0);
-        const int rk = (ST && lane < kk) ? S.so_rank[q0 + base + lane] : 0;
         int res_veh = -1, res_wait = -1;
         for (int j = 0; j < kk; ++j) {
             evals += navail;
@@ -389,11 +385,6 @@ __device__ void match_bucket(const Static &S, const State &D, int r, int t, int 
             if (lane == w) {
 #pragma unroll
                 for (int s = 0; s < J; ++s) av[s] = (s == ws) ? false : av[s];
-            }
-            if (ST) {
-                const unsigned mark = (unsigned)rdlane(rk, j) + 1u;
-#pragma unroll
-                for (int s = 0; s < J; ++s) stp[s] = (lane == w && s == ws) ? mark : stp[s];
             }
             if (lane == j) { res_veh = ST ? (int)(((unsigned)cl << 16) | (unsigned)(w * J + ws)) : wveh; res_wait = minc; }
             wait_sum += minc;                                      // :952
@@ -578,11 +569,10 @@ __device__ __forceinline__ void rows_load_idle(const uint2 *idle, int l16, int m
 // order records from HBM (lane l of a row holds order jj*16 + l) and the pickup of order j reaches the row's lanes
 // through the LDS crossbar (ds_bpermute) instead of a scalar readlane; the loop runs to the longest row of the wavefront.
 // ST ("stamp mode", first half of the hybrid neighbour-search tick): own-cluster matching exactly as
-// below, but nothing is committed - no arrival posts, no compaction, no order counters.  A taken entry stays in the list and
-// gets the RANK of its order (position in id order inside the slot) + 1 into the high half of its node word; the result of an
-// order is {cluster << 16 | list position, wait}.  k_dfs_walk then serves the orders that found their cluster empty from the
-// neighbours (:936-940) against the vehicles alive at their time (stamp > rank) and commits the whole slot.
-#define ST_TAKEN 0x40000000
+// below, but nothing is committed - no arrival posts, no compaction, no order counters.  A taken entry stays in the list; the
+// preliminary result of an order is {cluster << 16 | list position, wait}, from which k_dfs_walk stamps every entry with the
+// rank of the order that took it, serves the orders that found their cluster empty from the neighbours (:936-940) against
+// the vehicles alive at their time (stamp > rank) and commits the whole slot.
 template <int J, typename CT, bool PD, bool ST>
 __device__ __forceinline__ void rows_match(const Static &S, const State &D, int t, int now, int q0, int k, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, const uint2 *arr_row, int qb, int r, bool rowvalid, size_t b, int m, int A,
@@ -607,18 +597,14 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (pos >= mnew) loc[s] = 0;
         dead[s] = pos < mnew ? 0 : IMAX;
     }
-    int recy = 0, recx = 0;
-    int recy4[4] = {0, 0, 0, 0}, recx4[4] = {0, 0, 0, 0};
+    int recy = 0;
+    int recy4[4] = {0, 0, 0, 0};
     int kmax = k;
-    if (ST && !PD && lane < k) recx = lds_rec[lane].x;     // stamp mode stages the order's rank in .x
     if (PD) {
         kmax = max(max(rdlane(k, 0), rdlane(k, 16)), max(rdlane(k, 32), rdlane(k, 48)));
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-            if (jj * 16 < kmax && jj * 16 + l16 < k) {
-                recy4[jj] = S.so_rec[q0 + jj * 16 + l16].y;
-                if (ST) recx4[jj] = S.so_rank[q0 + jj * 16 + l16];      // per-row order streams: the rank comes with the row's own records
-            }
+            if (jj * 16 < kmax && jj * 16 + l16 < k) recy4[jj] = S.so_rec[q0 + jj * 16 + l16].y;
     } else {
         if (lane < k) recy = lds_rec[lane].y;
     }
@@ -640,11 +626,10 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
                 best = min(best, v);
             }
             const int rmin = live ? row_min_i32(best) : IMAX;
-            const bool hit = ST ? rmin < ST_TAKEN : rmin != IMAX;
+            const bool hit = rmin != IMAX;
             const int wpos = rmin & 127;
-            const int mark = ST ? (ST_TAKEN | (PD ? __builtin_amdgcn_ds_bpermute((rowbase + ji) << 2, recx4[jj]) : rdlane(recx, jj * 16 + ji))) : IMAX;   // stamp mode: the taker's rank rides in the dead mask
 #pragma unroll
-            for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? mark : dead[s];
+            for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? IMAX : dead[s];
             res[jj] = (l16 == ji) ? rmin : res[jj];
             evals += live ? navail : 0;
             navail -= hit ? 1 : 0;
@@ -658,7 +643,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             if (jj * 16 >= kmax) break;
             const int j = jj * 16 + l16;
             const int rv = res[jj];
-            if (rowvalid && j < k) D.out[(size_t)r * S.Oq + (q0 - qb) + j] = rv < ST_TAKEN ? make_int2((int)(((unsigned)c << 16) | (unsigned)(rv & 127)), rv >> 7) : make_int2(-1, -1);
+            if (rowvalid && j < k) D.out[(size_t)r * S.Oq + (q0 - qb) + j] = rv != IMAX ? make_int2((int)(((unsigned)c << 16) | (unsigned)(rv & 127)), rv >> 7) : make_int2(-1, -1);
         }
         if (rowvalid) {
 #pragma unroll
@@ -933,7 +918,6 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
         int4 rec = make_int4(0, 0, 0, 0);
         if (!PD && (int)threadIdx.x < min(k, 64)) {
             rec = S.so_rec[q0 + threadIdx.x];
-            if (ST) rec.x = S.so_rank[q0 + threadIdx.x];        // the order id is only needed by the commit (k_dfs_walk)
         }
         if (U8) {
             for (int i = threadIdx.x; i < n4; i += ROWS_WAVES * WAVE) lds4[i] = blk4[i];
