@@ -116,7 +116,10 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
  * if its SimCity loop had ended (:1048).  vds_read_orders rows are strided by the longest day.  n_days == 1 is
  * vds_load_orders.  With more than one day the fast kernel (k_tick_rows) runs the shared-day code with one day lookup per
  * workgroup when every aligned group of 16 replicas replays one day (e.g. the default block map with R / n_days a multiple
- * of 16; ~0.9x the shared-day rate), otherwise its per-row order-stream variant (~0.6x). */
+ * of 16; ~0.9x the shared-day rate).  Any other map: the library forms the workgroups from the replicas of one day itself
+ * (a row slot -> replica permutation, every day's last group padded: ~0.7x, the rows of a workgroup are no longer neighbours
+ * in memory), or - when that padding would exceed a quarter of the replicas, e.g. fewer than ~13 replicas per day - gives
+ * every 16-lane row its own order stream (~0.6x). */
 int vds_load_order_days(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min,
                         const int32_t *pickup, const int32_t *delivery, const int32_t *replica_day);
 

@@ -186,15 +186,17 @@ def test_full_size_distinct_days_config2():
     env.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_grid"])
-def test_days_in_blocks_of_sixteen_replicas_take_the_workgroup_uniform_path(name):
+@pytest.mark.parametrize("name,layout", [("tiny_kmeans", "blocks"), ("tiny_grid", "blocks"), ("tiny_kmeans", "interleaved"),
+                                         ("tiny_kmeans_dfs2", "interleaved"), ("tiny_kmeans_dfs2", "blocks")])
+def test_days_in_blocks_of_sixteen_replicas_take_the_workgroup_uniform_path(name, layout):
     """A block-wise replica -> day map (every aligned group of 16 replicas on one day) runs the shared-day kernel code with
     the day looked up once per workgroup (k_tick_rows day mode 1): every replica still equals its own oracle, incl. a
-    last, partially filled group and a day that ends early."""
+    last, partially filled group and a day that ends early.  "interleaved" (replica r on day r % 3, 14 / 13 / 13 replicas):
+    the library forms the workgroups from the replicas of one day itself (row slot -> replica permutation, padded groups)."""
     g = load_golden(name)
     V, N, R = int(g["V"]), int(g["N"]), 40
     days = synth_days(g, 3, seed=333)
-    replica_day = np.array([0] * 16 + [2] * 16 + [1] * 8, dtype=np.int32)
+    replica_day = np.array([0] * 16 + [2] * 16 + [1] * 8, dtype=np.int32) if layout == "blocks" else (np.arange(R) % 3).astype(np.int32)
     valid = g["node2cluster"] >= 0
     init = np.stack([synth.init_vehicle_nodes(random.Random(90 + r), N, V, valid) for r in range(R)]).astype(np.int32)
     env = mk_env(g, R)

@@ -665,12 +665,27 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     S.chunk_days = n_days > 1 ? 1 : 0;
     for (int r = 0; r < S.R && S.chunk_days; ++r)
         if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
+    // a map that mixes days inside aligned groups of 16 replicas: k_tick_rows forms its workgroups from the replicas of ONE day
+    // (row slot -> replica permutation, every day's last group padded) instead of giving every 16-lane row its own order stream
+    std::vector<int> rperm;
+    if (n_days > 1 && !S.chunk_days && h->cfg.force_generic == 0) {
+        std::vector<std::vector<int>> by_day(n_days);
+        for (int r = 0; r < S.R; ++r) by_day[h->replica_day[r]].push_back(r);
+        for (int dd = 0; dd < n_days; ++dd) {
+            for (int r : by_day[dd]) rperm.push_back(r);
+            while (rperm.size() % 16) rperm.push_back(-1);
+        }
+        if (rperm.size() * 4 <= (size_t)S.R * 5) S.chunk_days = 1;      // at most a quarter of padding; else per-row order streams
+        else rperm.clear();
+    }
     S.max_tick_orders = mto;
     int rc;
     int *d;
     int4 *d4;
     struct Sink { vds_handle *h; ~Sink() { h->alloc_sink = nullptr; } } sink{h};
     h->alloc_sink = &h->order_allocs;
+    S.rperm = nullptr; S.rslots = 0;
+    if (!rperm.empty()) { if ((rc = upload(h, &d, rperm))) return rc; S.rperm = d; S.rslots = (int)rperm.size(); }
     if ((rc = upload(h, &d4, so_rec))) return rc; S.so_rec = d4;
     if ((rc = upload(h, &d, bkt_off))) return rc; S.bkt_off = d;
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;

@@ -72,6 +72,8 @@ struct DayView { const int *bkt_off; const int *tick_off; int now0, T, q_base; }
 struct Static {
     int N, C, V, R, Oq, T;           // Oq: result slots per replica (max over days); T: longest day
     int n_days;                      // 1: one order stream shared by every replica (the fast path of k_tick_rows)
+    const int *rperm;                // [rslots] k_tick_rows row slot -> replica, grouped by order day in groups of 16 (-1 padding); null: identity
+    int rslots;
     int chunk_days;                  // n_days > 1 and every aligned group of 16 replicas (one k_tick_rows workgroup) replays one day
     const DayDesc *day;              // [n_days]
     const int *replica_day;          // [R]

@@ -849,8 +849,11 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
     unsigned long long tprev = 0ull;
 #endif
     const int pwave = (int)((blockIdx.x * ROWS_WAVES + wave) & (PROF_WAVES - 1));
-    const int r = (chunk * ROWS_WAVES + wave) * 4 + g;
-    bool rowvalid = r < S.R;
+    // the workgroup's 16 rows: consecutive replicas, or - order days per replica with a map that does not keep 16 aligned
+    // replicas on one day - the replicas Static.rperm groups by day (-1: padding of a day's last group)
+    const int rslot = (chunk * ROWS_WAVES + wave) * 4 + g;
+    const int r = (DM == 1 && S.rperm != nullptr) ? S.rperm[rslot] : rslot;
+    bool rowvalid = r >= 0 && r < S.R;
     // the row's order day: shared by all replicas (scalar values) or looked up per row
     int q0, k, now, qb = 0;
     if (PD) {
@@ -867,7 +870,8 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
         }
     } else if (DM == 1) {
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
-        const int4 dd = S.replica_desc[min((int)((blockIdx.x % nchunks) * ROWS_WAVES * 4), S.R - 1)];
+        const int r0 = (int)((blockIdx.x % nchunks) * ROWS_WAVES * 4);       // (a group's first slot is never padding)
+        const int4 dd = S.replica_desc[S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1)];
         rowvalid = rowvalid && t < dd.z;             // (workgroup-uniform apart from r < R)
         const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
         q0 = bo[0]; k = bo[1] - q0;
@@ -949,7 +953,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : RO
     // 6. the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int gg = (__ffsll((long long)rest) - 1) >> 4;
-        bucket_tick<true, true, 4, true, CT, ST>(S, D, c, (chunk * ROWS_WAVES + wave) * 4 + gg, t, lds_blk, nc);
+        bucket_tick<true, true, 4, true, CT, ST>(S, D, c, rdlane(r, gg * 16), t, lds_blk, nc);
     }
 }
 
@@ -3821,7 +3825,7 @@ static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_
 // main kernel of a non-DFS tick (the one bench.py brackets with events)
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
     const int chunks = (S.R + 15) / 16;
-    const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+    const int rchunks = ((S.rperm != nullptr ? S.rslots : S.R) + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
     if (S.fast_ok && S.u8_ok) {
@@ -3877,7 +3881,7 @@ size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max
 
 // hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
 void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
-    const int rchunks = (S.R + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+    const int rchunks = ((S.rperm != nullptr ? S.rslots : S.R) + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
     if (S.u8_ok) {
