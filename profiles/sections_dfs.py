@@ -34,8 +34,9 @@ if env.main_kernel() == "k_dfs_hybrid":
     print("wavefront 0 per served order: record + candidate stamps %.0f cycles, winner + steal (without the chain) %.0f, next dry order %.0f" % (
         buf[12] / max(1, buf[6]), buf[13] / max(1, buf[6]), buf[14] / max(1, buf[6])))
     sc = [float(buf[16 + i]) / max(1, buf[11]) for i in range(5)]
-    print("one scan: visit row + bounds %.0f, alive counts %.0f, first pass %.0f, second pass %.0f, the %s best %.0f cycles; %.2f eight-slot groups" % (
-        sc[0], sc[1], sc[2], sc[3], "WK_K", sc[4], float(buf[21]) / max(1, buf[11])))
+    print("one scan: visit row + bounds %.0f, alive counts %.0f, first pass %.0f, second pass %.0f, the %s best %.0f cycles; %.2f eight-slot groups; %.2f of the scans serve two orders of one bucket" % (
+        sc[0], sc[1], sc[2], sc[3], "WK_K", sc[4], float(buf[21]) / max(1, buf[11]), float(buf[22]) / max(1, buf[11])))
+    print("searching clusters with dry orders per replica-tick: %.1f" % (float(buf[23]) / R / T))
     print("instrumented: %.2f ms/launch" % ms.mean())
     tot = sum(float(buf[i]) for _, i in sec)
     for n, i in sec:

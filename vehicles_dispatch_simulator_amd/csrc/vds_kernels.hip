@@ -2786,10 +2786,13 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_WAVES (WK_THREADS / WAVE)
 #define WK_FREE 0xFFFFu
 #define WK_K 3                              // candidates kept per scanned dry order (2-4 measure the same; 8 costs 2 % in the extraction loop)
-#define WK_NS 8                             // records the scanning wavefronts may be ahead of the walk
+#define WK_NS 32                            // pool of scan records (the second order of a paired scan may wait there for a while)
 #define WK_REC (4 * WK_K + 2)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
                                             // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, 0},
                                             // the number of candidates, pad
+#ifndef WK_PAIR_SPAN
+#define WK_PAIR_SPAN 65536                  // a paired scan takes the bucket's next order only if its rank is at most this far ahead
+#endif
 #define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
 #ifdef WKDEBUG
 #define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
@@ -2801,7 +2804,7 @@ __host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
     const size_t bmw = (size_t)(C + 31) / 32;
-    return ((size_t)8 * C + 1 + ids + words + (1 + WK_NS) * WK_REC + WK_WAVES * bmw + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)8 * C + 1 + ids + 2 * words + (1 + WK_NS) * WK_REC + WK_WAVES * bmw + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
 }
 
 template <bool U8>
@@ -2854,10 +2857,13 @@ __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
 // lowers the stamp of the entry it takes) and ls_l is published once per served order, so whatever mixture of states the scan
 // reads, the vehicles it considers are a superset of those alive when the order's turn comes, and the list a sorted prefix of
 // that superset: its first entry still alive at that time IS the winner (none kept: nothing was alive, the order is rejected).
-template <bool U8, int JB>
-__device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
+template <bool U8, int JB, int G = 1>
+__device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, const int (&rho)[G], const int (&pnode)[G],
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
-                                         const unsigned short *st_l, unsigned *rec, unsigned long long *pacc = nullptr) {
+                                         const unsigned short *st_l, unsigned *const (&rec)[G], unsigned long long *pacc = nullptr) {
+    // G = 2: the dry orders at sorted positions q and q + 1 of ONE bucket (same visit sequence; rho[1] > rho[0], so whatever is
+    // alive for the second is alive for the first) share the walk over the candidate lists: one set of stamp reads and node-word
+    // loads, a cost gather and a pair of smallest keys per order.  A cluster scanned for either order counts as scanned for both.
     const int lane = lane_id();
 #ifdef VDS_PROF
     unsigned long long sc_ts = pacc ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -2865,40 +2871,61 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
 #else
 #define SCT(i) do { } while (0)
 #endif
-    const char *crow_b = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode * S.N);
-    const unsigned *vis = S.so_vis + (size_t)q * S.seq_pad;
-    unsigned ck[JB];
-    int lbj[JB], m0j[JB], moj[JB], cofj[JB];
-    unsigned long long cand[JB], scanned[JB], live[JB];
+    const char *crow_b[G];
+    unsigned ck[G][JB];
+    int lbj[G][JB], m0j[JB], moj[JB], cofj[JB];
+    unsigned long long cand[G][JB], scanned[JB], live[JB];
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) {
-        ck[jb] = vis[jb * WAVE + lane];
-        lbj[jb] = (U8 && S.so_lb != nullptr) ? (int)S.so_lb[(size_t)q * S.seq_pad + jb * WAVE + lane] : 0;
+    for (int o = 0; o < G; ++o) {
+        crow_b[o] = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pnode[o] * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pnode[o] * S.N);
+        const unsigned *vis = S.so_vis + (size_t)(q + o) * S.seq_pad;
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) {
+            ck[o][jb] = vis[jb * WAVE + lane];
+            lbj[o][jb] = (U8 && S.so_lb != nullptr) ? (int)S.so_lb[(size_t)(q + o) * S.seq_pad + jb * WAVE + lane] : 0;
+        }
     }
     SCT(0);
-    int lbmin = IMAX;
+    int lbmin[G];
+#pragma unroll
+    for (int o = 0; o < G; ++o) lbmin[o] = IMAX;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
-        int alive = 0;
+        int alive[G];
+#pragma unroll
+        for (int o = 0; o < G; ++o) alive[o] = 0;
         m0j[jb] = 0; moj[jb] = 0; cofj[jb] = 0;
-        if (ck[jb] != 0xFFFFFFFFu) {
-            const int c = (int)(ck[jb] & 0xFFFFu), kj = (int)(ck[jb] >> 16);
+        if (ck[0][jb] != 0xFFFFFFFFu) {
+            const int c = (int)(ck[0][jb] & 0xFFFFu);
             const int ls = lds_load(&ls_l[c]);
             m0j[jb] = m0_l[c]; moj[jb] = moff_l[c]; cofj[jb] = (cda_l[c] >> 11) & 0xFFFF;
-            alive = m0j[jb] - min(kj, ls >> 16) - (ls & 0xFFFF);
+#pragma unroll
+            for (int o = 0; o < G; ++o) alive[o] = m0j[jb] - min((int)(ck[o][jb] >> 16), ls >> 16) - (ls & 0xFFFF);
         }
-        cand[jb] = ballot(alive > 0); scanned[jb] = 0ull; live[jb] = 0ull;
-        lbmin = min(lbmin, alive > 0 ? lbj[jb] : IMAX);
+        scanned[jb] = 0ull; live[jb] = 0ull;
+#pragma unroll
+        for (int o = 0; o < G; ++o) {
+            cand[o][jb] = ballot(alive[o] > 0);
+            lbmin[o] = min(lbmin[o], alive[o] > 0 ? lbj[o][jb] : IMAX);
+        }
     }
-    lbmin = wave_min_i32(lbmin);
+#pragma unroll
+    for (int o = 0; o < G; ++o) lbmin[o] = wave_min_i32(lbmin[o]);
     SCT(1);
-    int b1 = IMAX, b2 = IMAX, nval = 0;
+    int b1[G], b2[G], nval[G];
+#pragma unroll
+    for (int o = 0; o < G; ++o) { b1[o] = IMAX; b2[o] = IMAX; nval[o] = 0; }
     for (int pass = 0; pass < 2; ++pass) {
-        const int bound = pass == 0 ? lbmin + PRUNE_DELTA : (wave_min_i32(b1) >> 16) + WK_SLACK;
+        int bound[G];
+#pragma unroll
+        for (int o = 0; o < G; ++o) bound[o] = pass == 0 ? lbmin[o] + PRUNE_DELTA : (wave_min_i32(b1[o]) >> 16) + WK_SLACK;
         bool anylive = false;
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
-            live[jb] = cand[jb] & ~scanned[jb] & ballot(lbj[jb] <= bound);
+            unsigned long long lv = 0ull;
+#pragma unroll
+            for (int o = 0; o < G; ++o) lv |= cand[o][jb] & ballot(lbj[o][jb] <= bound[o]);
+            live[jb] = lv & ~scanned[jb];
             scanned[jb] |= live[jb];
             anylive |= live[jb] != 0ull;
         }
@@ -2909,22 +2936,25 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
             // alive (HBM), then the cost gathers, then the two smallest keys of the lane.  (Fetching the cluster's segment of
             // the cost row together with the node words and shuffling the cost out of it was measured: the extra loads make
             // every load slower, 19.6 k instead of 15.6 k cycles per scan.)
-            int in[8], seq[8], cst[8], sidx[8];
+            int in[G][8], seq[8], sidx[8];
             unsigned yv[8];
             int cof[8];
             const uint2 *ip[8];
             bool any = false;
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
-                in[k8] = 0; seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0; sidx[k8] = 0; ip[k8] = D.idle;
+                seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0; sidx[k8] = 0; ip[k8] = D.idle;
+#pragma unroll
+                for (int o = 0; o < G; ++o) in[o][k8] = 0;
                 while (cl == 0ull && jbc + 1 < JB) { ++jbc; cl = pick_mask<JB>(live, jbc); b = 0; }
                 if (cl != 0ull) {
                     any = true;
                     const int j = __ffsll((long long)cl) - 1;
-                    const int cc = (int)((unsigned)pick_lane<JB>(reinterpret_cast<const int (&)[JB]>(ck), jbc, j) & 0xFFFFu);
+                    const int cc = (int)((unsigned)pick_lane<JB>(reinterpret_cast<const int (&)[JB]>(ck[0]), jbc, j) & 0xFFFFu);
                     const int m0c = pick_lane<JB>(m0j, jbc, j), moc = pick_lane<JB>(moj, jbc, j);
                     const int i = b * WAVE + lane;
-                    in[k8] = i < m0c ? 1 : 0;
+#pragma unroll
+                    for (int o = 0; o < G; ++o) in[o][k8] = i < m0c ? 1 : 0;
                     sidx[k8] = moc + min(i, m0c - 1);
                     ip[k8] = D.idle + ((size_t)cc * S.R + r) * S.idle_cap + i;
                     cof[k8] = pick_lane<JB>(cofj, jbc, j);
@@ -2935,18 +2965,26 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
             }
             if (!any) break;
 #pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) in[k8] &= ((int)st_l[sidx[k8]] > rho ? 1 : 0);
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) if (in[k8]) yv[k8] = ip[k8]->y;
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8)
-                cst[k8] = cost_elem<U8>(crow_b, (unsigned)(in[k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
-#pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
-                const int v = in[k8] ? (cst[k8] << 16) | seq[k8] : IMAX;
-                nval += in[k8];
-                b2 = min(b2, max(b1, v));
-                b1 = min(b1, v);
+                const int st = (int)st_l[sidx[k8]];
+#pragma unroll
+                for (int o = 0; o < G; ++o) in[o][k8] &= (st > rho[o] ? 1 : 0);
+            }
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) if (in[0][k8]) yv[k8] = ip[k8]->y;        // (alive for a later order = alive for the first)
+#pragma unroll
+            for (int o = 0; o < G; ++o) {
+                int cst[8];
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8)
+                    cst[k8] = cost_elem<U8>(crow_b[o], (unsigned)(in[o][k8] ? cof[k8] + (int)(yv[k8] & 0xFFFF) : 0));
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const int v = in[o][k8] ? (cst[k8] << 16) | seq[k8] : IMAX;
+                    nval[o] += in[o][k8];
+                    b2[o] = min(b2[o], max(b1[o], v));
+                    b1[o] = min(b1[o], v);
+                }
             }
 #ifdef VDS_PROF
             if (pacc) pacc[5] += 1;
@@ -2954,36 +2992,48 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
         }
         SCT(2 + pass);
     }
-    // candidates of clusters never scanned cost at least their bound (and could win a tie on visit order)
-    int ulb = IMAX;
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) ulb = min(ulb, (((cand[jb] & ~scanned[jb]) >> lane) & 1ull) ? lbj[jb] : IMAX);
-    ulb = wave_min_i32(ulb);
-    // the WK_K smallest keys, ascending: lane kk keeps the kk-th (and the lane it came from = its position inside the chunk)
-    int nl = 0, npop = 0, mykey = IMAX, mywl = 0;
-    for (int kk = 0; kk < WK_K; ++kk) {
-        const int m = wave_min_i32(b1);
-        if (m == IMAX) break;
-        if (kk > 0 && (m >> 16) >= ulb) break;
-        const int wl = __ffsll((long long)ballot(b1 == m)) - 1;       // lowest lane = lowest list position
-        if (lane == kk) { mykey = m; mywl = wl; }
-        ++nl;
-        bool stop = false;
-        if (lane == wl) { b1 = b2; b2 = IMAX; ++npop; stop = npop == 2 && nval > 2; }   // the lane's third smallest is unknown
-        if (ballot(stop)) break;
-    }
-    {   // ... and each of those lanes resolves its entry: stamp index = start of the cluster's stamps + position; cluster | k
-        const int j = (mykey >> 8) & 255, bb = mykey & 255;
-        int mo = 0, ckw = 0;
+    for (int o = 0; o < G; ++o) {
+        // candidates of clusters never scanned cost at least their bound (and could win a tie on visit order)
+        int ulb = IMAX;
 #pragma unroll
-        for (int jb = 0; jb < JB; ++jb) {
-            const int u = __shfl(moj[jb], j & 63, WAVE), u2 = __shfl((int)ck[jb], j & 63, WAVE);
-            mo = (j >> 6) == jb ? u : mo; ckw = (j >> 6) == jb ? u2 : ckw;
+        for (int jb = 0; jb < JB; ++jb) ulb = min(ulb, (((cand[o][jb] & ~scanned[jb]) >> lane) & 1ull) ? lbj[o][jb] : IMAX);
+        ulb = wave_min_i32(ulb);
+        // the WK_K smallest keys, ascending: lane kk keeps the kk-th (and the lane it came from = its position inside the chunk)
+        int nl = 0, npop = 0, mykey = IMAX, mywl = 0;
+        for (int kk = 0; kk < WK_K; ++kk) {
+            const int m = wave_min_i32(b1[o]);
+            if (m == IMAX) break;
+            if (kk > 0 && (m >> 16) >= ulb) break;
+            const int wl = __ffsll((long long)ballot(b1[o] == m)) - 1;       // lowest lane = lowest list position
+            if (lane == kk) { mykey = m; mywl = wl; }
+            ++nl;
+            bool stop = false;
+            if (lane == wl) { b1[o] = b2[o]; b2[o] = IMAX; ++npop; stop = npop == 2 && nval[o] > 2; }   // the lane's third smallest is unknown
+            if (ballot(stop)) break;
         }
-        if (lane < nl) reinterpret_cast<int4 *>(rec)[lane] = make_int4(mykey, mo + bb * WAVE + mywl, ckw, 0);
+        {   // ... and each of those lanes resolves its entry: stamp index = start of the cluster's stamps + position; cluster | k
+            const int j = (mykey >> 8) & 255, bb = mykey & 255;
+            int mo = 0, ckw = 0;
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) {
+                const int u = __shfl(moj[jb], j & 63, WAVE), u2 = __shfl((int)ck[o][jb], j & 63, WAVE);
+                mo = (j >> 6) == jb ? u : mo; ckw = (j >> 6) == jb ? u2 : ckw;
+            }
+            if (lane < nl) reinterpret_cast<int4 *>(rec[o])[lane] = make_int4(mykey, mo + bb * WAVE + mywl, ckw, 0);
+        }
+        if (lane == 0) rec[o][4 * WK_K] = (unsigned)nl;
     }
-    if (lane == 0) rec[4 * WK_K] = (unsigned)nl;
     SCT(4);
+}
+// one order
+template <bool U8, int JB>
+__device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
+                                         const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
+                                         const unsigned short *st_l, unsigned *rec, unsigned long long *pacc = nullptr) {
+    const int rho1[1] = {rho}, pn1[1] = {pnode};
+    unsigned *const rec1[1] = {rec};
+    dfs_scan<U8, JB, 1>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, rec1, pacc);
 }
 
 // JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
@@ -3007,7 +3057,8 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     unsigned short *qr_l = rq_l + ((mto + 1) & ~1);                                   // [mto] sorted position of rank
     unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
     const int nwords = (mto + 31) / 32 + 1;
-    unsigned *slot_l = dry_bits + nwords;                                             // one record, for the scans wavefront 0 does itself
+    unsigned *clm_bits = dry_bits + nwords;                                           // dry orders somebody has claimed for scanning
+    unsigned *slot_l = clm_bits + nwords;                                             // one record, for the scans wavefront 0 does itself
     unsigned *pool_l = slot_l + WK_REC;                                               // WK_NS records, filled by wavefronts 1..3
     const int bmw = (C + 31) / 32;
     unsigned *bm_l = pool_l + WK_NS * WK_REC;                                         // [WK_WAVES][bmw] cluster bitmaps of the evaluation pass
@@ -3019,7 +3070,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     __shared__ int s_dbg, s_dbga, s_dbgb;
     if (threadIdx.x == 0) { s_dbga = 0; s_dbgb = 0; }
 #endif
-    __shared__ int s_cursor;              // dry orders of rank < cursor have been claimed by a scanning wavefront (or passed over)
+    __shared__ int s_cursor;              // rank of the dry order the walk is at: the scanning wavefronts look for work from there on
     __shared__ int s_done;                // the walk is over
     __shared__ int s_slot[WK_NS];         // pool record s: 0 free, else rank of its dry order << 2 | 1 being filled / 2 ready
     const int r = blockIdx.x;
@@ -3054,7 +3105,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         const int own = min(q1 - q0, m0);                 // the fast kernel matched while vehicles remained
         m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; ls_l[c] = own << 16; tk_l[c] = 0;
     }
-    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) dry_bits[w] = 0u;
+    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) { dry_bits[w] = 0u; clm_bits[w] = 0u; }
     if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; s_nlog = 0; }
     if (threadIdx.x < WK_NS) s_slot[threadIdx.x] = 0;
     __syncthreads();
@@ -3128,13 +3179,18 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
 #ifdef VDS_PROF
             const unsigned long long p_t0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
+            if (lane == 0) lds_release(&s_cursor, rho);
             while (true) {
-                const int cur = lds_acquire(&s_cursor);
-                // (a claim publishes its slot word before it moves the cursor, and withdraws it if another wavefront moved it first)
+                // (a scanning wavefront publishes its slot word before it claims the order, and withdraws it if another was first)
                 const int sw = lane < WK_NS ? lds_acquire(&s_slot[lane]) : 0;
                 const unsigned long long ready = ballot(sw == ((rho << 2) | 2));
                 if (ready != 0ull) { slot = __ffsll((long long)ready) - 1; break; }
-                if (ballot(sw == ((rho << 2) | 1)) == 0ull && cur > rho) break;
+                if (ballot(sw == ((rho << 2) | 1)) == 0ull) {
+                    // not in the pool: claim it for a scan by this wavefront - unless a scanning wavefront has just done so
+                    unsigned old = 0u;
+                    if (lane == 0) old = atomicOr(&clm_bits[rho >> 5], 1u << (rho & 31));
+                    if (!((unsigned)__builtin_amdgcn_readfirstlane((int)old) & (1u << (rho & 31)))) break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
 #ifdef VDS_PROF
@@ -3305,37 +3361,78 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         unsigned long long p_scan = 0, p_n = 0, p_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         while (true) {
-            const int cur = lds_acquire(&s_cursor);
-            const int b = next_dry(cur);
+            // the first dry order from the walk's position on that nobody has claimed
+            const int from = lds_acquire(&s_cursor);
+            int b = IMAX;
+            for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
+                unsigned bits = (unsigned)lds_load(reinterpret_cast<const int *>(&dry_bits[w])) & ~(unsigned)lds_load(reinterpret_cast<const int *>(&clm_bits[w]));
+                if (w == (from >> 5)) bits &= 0xFFFFFFFFu << (from & 31);
+                if (bits != 0u) { b = w * 32 + __ffs((int)bits) - 1; break; }
+            }
+            b = wave_min_i32(b);
             if (b == IMAX) {
                 if (lds_acquire(&s_done)) break;
                 __builtin_amdgcn_s_sleep(10);
                 continue;
             }
-            int slot = -1, won = 0;
-            if (lane == 0) {
-                for (int s = 0; s < WK_NS && slot < 0; ++s)
-                    if (lds_cas(&s_slot[s], 0, (b << 2) | 1)) slot = s;
-                if (slot >= 0) {
-                    won = lds_cas(&s_cursor, cur, b + 1) ? 1 : 0;
-                    if (!won) lds_release(&s_slot[slot], 0);
-                }
+            const int swl = lane < WK_NS ? lds_load(&s_slot[lane]) : -1;
+            unsigned long long freem = ballot(swl == 0);
+            if (freem == 0ull) { __builtin_amdgcn_s_sleep(10); continue; }
+            const int slot = __ffsll((long long)freem) - 1;
+            freem &= freem - 1ull;
+            int won = 0;
+            if (lane == 0 && lds_cas(&s_slot[slot], 0, (b << 2) | 1)) {
+                won = (atomicOr(&clm_bits[b >> 5], 1u << (b & 31)) & (1u << (b & 31))) ? 0 : 1;
+                if (!won) lds_release(&s_slot[slot], 0);
             }
-            slot = __builtin_amdgcn_readfirstlane(slot);
             won = __builtin_amdgcn_readfirstlane(won);
-            if (slot < 0) { __builtin_amdgcn_s_sleep(10); continue; }
             if (!won) continue;
             const int q = tq0 + (int)qr_l[b];
+            // the next order of the same bucket (dry as well: the dry orders of a bucket are its last ones) shares the scan,
+            // pool permitting
+            int b2nd = -1, slot2 = -1;
+            int pn[2] = {0, 0};
+            if (q + 1 < tq1 && popc64(freem) >= 2) {
+                const int4 ra = S.so_rec[q], rb = S.so_rec[q + 1];
+                pn[0] = S.so_pnode[q]; pn[1] = S.so_pnode[q + 1];
+                if (((unsigned)ra.z >> 16) == ((unsigned)rb.z >> 16)) {
+                    const int r2 = (int)rq_l[q + 1 - tq0];
+                    const int s2 = __ffsll((long long)freem) - 1;
+                    int won2 = 0;
+                    if (lane == 0 && r2 - b <= WK_PAIR_SPAN && lds_cas(&s_slot[s2], 0, (r2 << 2) | 1)) {
+                        won2 = (atomicOr(&clm_bits[r2 >> 5], 1u << (r2 & 31)) & (1u << (r2 & 31))) ? 0 : 1;
+                        if (!won2) lds_release(&s_slot[s2], 0);
+                    }
+                    if (__builtin_amdgcn_readfirstlane(won2)) { b2nd = r2; slot2 = s2; }
+                }
+            } else {
+                pn[0] = S.so_pnode[q];
+            }
 #ifdef VDS_PROF
             const unsigned long long p_s0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
-            dfs_scan<U8, JB>(S, D, r, q, b, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, pool_l + slot * WK_REC
+            if (b2nd >= 0) {
+                const int rho2[2] = {b, b2nd};
+                unsigned *const rec2[2] = {pool_l + slot * WK_REC, pool_l + slot2 * WK_REC};
+                dfs_scan<U8, JB, 2>(S, D, r, q, rho2, pn, m0_l, moff_l, ls_l, cdA_l, st_l, rec2
 #ifdef VDS_PROF
-                         , prof ? p_acc : nullptr
+                                    , prof ? p_acc : nullptr
 #endif
-                         );
-            wave_order();
-            if (lane == 0) lds_release(&s_slot[slot], (b << 2) | 2);
+                                    );
+                wave_order();
+                if (lane == 0) { lds_release(&s_slot[slot], (b << 2) | 2); lds_release(&s_slot[slot2], (b2nd << 2) | 2); }
+#ifdef VDS_PROF
+                if (prof) p_acc[6] += 1;
+#endif
+            } else {
+                dfs_scan<U8, JB>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, pool_l + slot * WK_REC
+#ifdef VDS_PROF
+                                 , prof ? p_acc : nullptr
+#endif
+                                 );
+                wave_order();
+                if (lane == 0) lds_release(&s_slot[slot], (b << 2) | 2);
+            }
 #ifdef VDS_PROF
             if (prof) { p_scan += __builtin_amdgcn_s_memtime() - p_s0; p_n += 1; }
 #endif
@@ -3413,6 +3510,9 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             int qdm = 0, qem = 0;
             if (cme < C && (cdA_l[cme] & CAPABLE)) { qdm = (cme == 0 ? tq0 : qend_l[cme - 1]) + lm_l[cme]; qem = qend_l[cme]; }
             unsigned long long dm = ballot(qdm < qem);
+#ifdef VDS_PROF
+            if (prof && wave == 0 && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 23] += popc64(dm);
+#endif
             while (dm != 0ull) {
                 int cjs[4][JB], qd4[4], qe4[4], n4[4];
 #pragma unroll
