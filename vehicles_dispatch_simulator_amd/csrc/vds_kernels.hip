@@ -2787,9 +2787,10 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_FREE 0xFFFFu
 #define WK_K 3                              // candidates kept per scanned dry order (2-4 measure the same; 8 costs 2 % in the extraction loop)
 #define WK_NS 32                            // pool of scan records (the second order of a paired scan may wait there for a while)
-#define WK_REC (4 * WK_K + 2)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
+#define WK_REC (4 * WK_K + 6)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
                                             // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, 0},
-                                            // the number of candidates, pad
+                                            // the number of candidates; and for the first candidate, if an own-cluster order a holds it: a, the
+                                            // two entries {cost << 16 | position} a would pick instead, whether those are all it could pick; pad
 #ifndef WK_PAIR_SPAN
 #define WK_PAIR_SPAN 65536                  // a paired scan takes the bucket's next order only if its rank is at most this far ahead
 #endif
@@ -2860,7 +2861,7 @@ __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
 template <bool U8, int JB, int G = 1>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, const int (&rho)[G], const int (&pnode)[G],
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
-                                         const unsigned short *st_l, unsigned *const (&rec)[G], unsigned long long *pacc = nullptr) {
+                                         const unsigned short *st_l, const unsigned short *qr_l, int tq0, unsigned *const (&rec)[G], unsigned long long *pacc = nullptr) {
     // G = 2: the dry orders at sorted positions q and q + 1 of ONE bucket (same visit sequence; rho[1] > rho[0], so whatever is
     // alive for the second is alive for the first) share the walk over the candidate lists: one set of stamp reads and node-word
     // loads, a cost gather and a pair of smallest keys per order.  A cluster scanned for either order counts as scanned for both.
@@ -3021,6 +3022,34 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                 mo = (j >> 6) == jb ? u : mo; ckw = (j >> 6) == jb ? u2 : ckw;
             }
             if (lane < nl) reinterpret_cast<int4 *>(rec[o])[lane] = make_int4(mykey, mo + bb * WAVE + mywl, ckw, 0);
+            // the first candidate is the likely winner.  If an own-cluster order a holds it (taken later than this order), stealing
+            // it makes a pick again (k_dfs_walk, redo chain): what a would pick - the two best entries of its cluster alive at ITS
+            // time (stamp > a; the same shrinking-set argument makes the first of them still alive the re-pick) - is worked out
+            // here, two HBM levels off the walk's critical path.  Lists of more than 64 entries: left to the walk.
+            const int sidx0 = rdlane(mo + bb * WAVE + mywl, 0), wcl = rdlane(ckw, 0) & 0xFFFF;
+            int a0 = -1, r1 = IMAX, r2 = IMAX, complete = 0;
+            if (nl > 0) {
+                const int st0 = (int)st_l[sidx0];
+                const int m0w = m0_l[wcl];
+                if (st0 != (int)WK_FREE && st0 > rho[o] && m0w <= WAVE) {
+                    a0 = st0;
+                    const int mow = moff_l[wcl];
+                    const int4 cd = S.cdesc[wcl];
+                    const int ncw = cda_l[wcl] & 2047;
+                    const int pick = S.so_rec[tq0 + (int)qr_l[a0]].y & 0xFFFF;
+                    const bool al = lane < m0w && (int)st_l[mow + min(lane, m0w - 1)] > a0;
+                    int key = IMAX;
+                    if (al) {
+                        const int lo2 = (int)(D.idle[((size_t)wcl * S.R + r) * S.idle_cap + lane].y & 0xFFFF);
+                        key = (cost_elem<U8>(U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk),
+                                             (unsigned)((U8 ? cd.z : cd.y) + pick * ncw + lo2)) << 16) | lane;
+                    }
+                    r1 = wave_min_i32(key);
+                    r2 = wave_min_i32(key == r1 ? IMAX : key);
+                    complete = popc64(ballot(al)) <= 2 ? 1 : 0;
+                }
+            }
+            if (lane == 0) { rec[o][4 * WK_K + 1] = (unsigned)a0; rec[o][4 * WK_K + 2] = (unsigned)r1; rec[o][4 * WK_K + 3] = (unsigned)r2; rec[o][4 * WK_K + 4] = (unsigned)complete; }
         }
         if (lane == 0) rec[o][4 * WK_K] = (unsigned)nl;
     }
@@ -3030,10 +3059,10 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
 template <bool U8, int JB>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
-                                         const unsigned short *st_l, unsigned *rec, unsigned long long *pacc = nullptr) {
+                                         const unsigned short *st_l, const unsigned short *qr_l, int tq0, unsigned *rec, unsigned long long *pacc = nullptr) {
     const int rho1[1] = {rho}, pn1[1] = {pnode};
     unsigned *const rec1[1] = {rec};
-    dfs_scan<U8, JB, 1>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, rec1, pacc);
+    dfs_scan<U8, JB, 1>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, qr_l, tq0, rec1, pacc);
 }
 
 // JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
@@ -3203,7 +3232,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (slot >= 0) {
                 rec = pool_l + slot * WK_REC;
             } else {
-                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
+                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
                 wave_order();
 #ifdef VDS_PROF
                 p_cnt[2] += 1;
@@ -3212,6 +3241,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             int4 e = make_int4(IMAX, 0, 0, 0);
             if (lane < WK_K) e = reinterpret_cast<const int4 *>(rec)[lane];
             int nl = (int)rec[4 * WK_K];
+            int ra0 = (int)rec[4 * WK_K + 1], rr1 = (int)rec[4 * WK_K + 2], rr2 = (int)rec[4 * WK_K + 3], rcomp = (int)rec[4 * WK_K + 4];
             int stv = lane < nl ? (int)st_l[e.y] : -1;
             if (slot >= 0) {
                 wave_order();
@@ -3219,11 +3249,12 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             }
             unsigned long long okb = ballot(stv > rho);
             if (nl > 0 && okb == 0ull) {           // every kept candidate has been taken since: scan again, on the state as it is
-                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, slot_l);
+                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
                 wave_order();
                 e = make_int4(IMAX, 0, 0, 0);
                 if (lane < WK_K) e = reinterpret_cast<const int4 *>(slot_l)[lane];
                 nl = (int)slot_l[4 * WK_K];
+                ra0 = (int)slot_l[4 * WK_K + 1]; rr1 = (int)slot_l[4 * WK_K + 2]; rr2 = (int)slot_l[4 * WK_K + 3]; rcomp = (int)slot_l[4 * WK_K + 4];
                 stv = lane < nl ? (int)st_l[e.y] : -1;
                 okb = ballot(stv > rho);
 #ifdef VDS_PROF
@@ -3287,9 +3318,35 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                         const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
                         // the list's node words travel together with the first victim's pickup node (one HBM level, not two), and
                         // serve every step of the chain; lists of more than 64 entries read them step by step
+                        // first step from the record, when the scan worked it out for this very holder: the first of its two entries
+                        // still alive at a's time is the re-pick; none alive and nothing else existed: the bucket is exhausted
+                        bool chain = true;
+                        if (first == 0 && ra0 == a) {
+                            const int p1 = rr1 != IMAX ? (rr1 & 0xFFFF) : -1, p2 = rr2 != IMAX ? (rr2 & 0xFFFF) : -1;
+                            const int s1 = p1 >= 0 ? (int)st_l[mo + p1] : -1, s2 = p2 >= 0 ? (int)st_l[mo + p2] : -1;
+                            const int pk = s1 > a ? p1 : (s2 > a ? p2 : -1);
+                            if (pk >= 0) {
+                                const int y = tq0 + (int)qr_l[a];
+                                const int bst = s1 > a ? s1 : s2;
+                                if (lane == 0) {
+                                    st_l[mo + pk] = (unsigned short)a;
+                                    out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)pk), (s1 > a ? rr1 : rr2) >> 16);
+                                }
+                                wave_order();
+                                if (bst == (int)WK_FREE) chain = false; else a = bst;
+                            } else if (rcomp) {
+                                const int y = tq0 + (int)qr_l[a];
+                                exhausted = 1;
+                                if (lane == 0) {
+                                    if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
+                                    out_r[y] = make_int2(-1, -1);
+                                }
+                                chain = false;
+                            }
+                        }
                         unsigned yv0 = 0u;
-                        if (m0 <= WAVE && lane < m0) yv0 = idle[lane].y;
-                        while (true) {
+                        if (chain && m0 <= WAVE && lane < m0) yv0 = idle[lane].y;
+                        while (chain) {
                             const int y = tq0 + (int)qr_l[a];
                             const int pick = S.so_rec[y].y & 0xFFFF;
                             int lc = IMAX, lp = -1;
@@ -3414,7 +3471,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (b2nd >= 0) {
                 const int rho2[2] = {b, b2nd};
                 unsigned *const rec2[2] = {pool_l + slot * WK_REC, pool_l + slot2 * WK_REC};
-                dfs_scan<U8, JB, 2>(S, D, r, q, rho2, pn, m0_l, moff_l, ls_l, cdA_l, st_l, rec2
+                dfs_scan<U8, JB, 2>(S, D, r, q, rho2, pn, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2
 #ifdef VDS_PROF
                                     , prof ? p_acc : nullptr
 #endif
@@ -3425,7 +3482,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 if (prof) p_acc[6] += 1;
 #endif
             } else {
-                dfs_scan<U8, JB>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, pool_l + slot * WK_REC
+                dfs_scan<U8, JB>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, pool_l + slot * WK_REC
 #ifdef VDS_PROF
                                  , prof ? p_acc : nullptr
 #endif
