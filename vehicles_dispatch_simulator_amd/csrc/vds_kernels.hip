@@ -815,11 +815,15 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
 #ifndef ROWS_PD_MIN_WAVES
 #define ROWS_PD_MIN_WAVES 6
 #endif
+// the stamp-mode instantiation (no commit: no posts, no compaction) needs 65 VGPRs: one wavefront per SIMD more
+#ifndef ROWS_ST_MIN_WAVES
+#define ROWS_ST_MIN_WAVES 8
+#endif
 // DM (day mode): 0 = one order day shared by every replica; 1 = several days, but the 16 replicas of every workgroup replay
 // the same one (vds_load_order_days with a block-wise replica -> day map): the shared-day code with the day looked up once
 // per workgroup through scalar loads; 2 = per-row order streams (PD below).
 template <bool U8, int DM, bool ST = false>
-__global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ROWS_MIN_WAVES) void k_tick_rows(Static S, State D, int t, int lds_ints) {
+__global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((ST && DM == 0) ? ROWS_ST_MIN_WAVES : ROWS_MIN_WAVES)) void k_tick_rows(Static S, State D, int t, int lds_ints) {
     constexpr bool PD = DM == 2;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
