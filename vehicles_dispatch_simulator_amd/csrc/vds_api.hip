@@ -23,6 +23,7 @@ void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
 size_t dfs_walk_lds(const Static &);
+int dfs_walk_pool(const Static &);
 size_t replica3_lds(const Static &);
 int replica3_prepare();
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
@@ -756,6 +757,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         // need the byte copy of the matrix for the staged row
         // hybrid tick: the fast kernel's preconditions (packed keys, no live pickup window, every cost block in LDS), one
         // order day per workgroup, 16-bit ranks / positions / columns, the walk's LDS footprint
+        h->S.walk_pool = 0; h->S.walk_pool = dfs_walk_pool(h->S);
         h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
                        Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&

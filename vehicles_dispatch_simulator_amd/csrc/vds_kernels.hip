@@ -2790,7 +2790,8 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WK_WAVES (WK_THREADS / WAVE)
 #define WK_FREE 0xFFFFu
 #define WK_K 3                              // candidates kept per scanned dry order (2-4 measure the same; 8 costs 2 % in the extraction loop)
-#define WK_NS 32                            // pool of scan records (the second order of a paired scan may wait there for a while)
+#define WK_NS 32                            // pool of scan records (the second order of a paired scan may wait there for a while):
+#define WK_NS_MIN 8                         // Static.walk_pool of them, as many as keep the workgroup within a quarter of a CU's LDS
 #define WK_REC (4 * WK_K + 6)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
                                             // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, 0},
                                             // the number of candidates; and for the first candidate, if an own-cluster order a holds it: a, the
@@ -2805,11 +2806,11 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #define WKCHK(cond, code, a, b2) do { } while (0)
 #endif
 
-__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto) {
+__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int ns = WK_NS) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
     const size_t bmw = (size_t)(C + 31) / 32;
-    return ((size_t)8 * C + 1 + ids + 2 * words + (1 + WK_NS) * WK_REC + WK_WAVES * bmw + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)8 * C + 1 + ids + 2 * words + (1 + ns) * WK_REC + WK_WAVES * bmw + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
 }
 
 template <bool U8>
@@ -3094,7 +3095,8 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     unsigned *slot_l = clm_bits + nwords;                                             // one record, for the scans wavefront 0 does itself
     unsigned *pool_l = slot_l + WK_REC;                                               // WK_NS records, filled by wavefronts 1..3
     const int bmw = (C + 31) / 32;
-    unsigned *bm_l = pool_l + WK_NS * WK_REC;                                         // [WK_WAVES][bmw] cluster bitmaps of the evaluation pass
+    const int ns = S.walk_pool;
+    unsigned *bm_l = pool_l + ns * WK_REC;                                         // [WK_WAVES][bmw] cluster bitmaps of the evaluation pass
     int *lg_l = reinterpret_cast<int *>(bm_l + WK_WAVES * bmw);                       // [64][4] the steal log's current chunk
     unsigned short *st_l = reinterpret_cast<unsigned short *>(lg_l + 4 * WAVE);       // [V] stamps
     __shared__ int s_ev;                  // evaluations of the dry orders
@@ -3215,7 +3217,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (lane == 0) lds_release(&s_cursor, rho);
             while (true) {
                 // (a scanning wavefront publishes its slot word before it claims the order, and withdraws it if another was first)
-                const int sw = lane < WK_NS ? lds_acquire(&s_slot[lane]) : 0;
+                const int sw = lane < ns ? lds_acquire(&s_slot[lane]) : 0;
                 const unsigned long long ready = ballot(sw == ((rho << 2) | 2));
                 if (ready != 0ull) { slot = __ffsll((long long)ready) - 1; break; }
                 if (ballot(sw == ((rho << 2) | 1)) == 0ull) {
@@ -3436,7 +3438,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 __builtin_amdgcn_s_sleep(10);
                 continue;
             }
-            const int swl = lane < WK_NS ? lds_load(&s_slot[lane]) : -1;
+            const int swl = lane < ns ? lds_load(&s_slot[lane]) : -1;
             unsigned long long freem = ballot(swl == 0);
             if (freem == 0ull) { __builtin_amdgcn_s_sleep(10); continue; }
             const int slot = __ffsll((long long)freem) - 1;
@@ -4038,7 +4040,13 @@ int replica3_prepare() {      // opt in to more than 64 KB of dynamic LDS per wo
     return (a == hipSuccess && b == hipSuccess) ? 0 : -1;
 }
 
-size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders); }
+size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, S.walk_pool > 0 ? S.walk_pool : WK_NS_MIN); }
+// the record pool: WK_NS records, fewer (down to WK_NS_MIN) when that keeps the walk's workgroup within 40 KB - four per CU
+int dfs_walk_pool(const Static &S) {
+    int ns = WK_NS;
+    while (ns > WK_NS_MIN && dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, ns) + 128 > 40 * 1024) --ns;
+    return ns;
+}
 
 // hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
 void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
