@@ -877,11 +877,13 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
         const int r0 = (int)((blockIdx.x % nchunks) * ROWS_WAVES * 4);       // (a group's first slot is never padding)
         const int4 dd = S.replica_desc[S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1)];
         rowvalid = rowvalid && t < dd.z;             // (workgroup-uniform apart from r < R)
-        const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
-        q0 = bo[0]; k = bo[1] - q0;
+        q0 = 0; k = 0;
+        if (t < dd.z) {                              // (past the day's last slot its bucket table must not be read: the last day's ends there)
+            const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
+            q0 = bo[0]; k = bo[1] - q0;
+        }
         now = dd.y + t * S.tick_minutes;
         qb = dd.w;
-        if (t >= dd.z) { q0 = 0; k = 0; }
     } else {
         q0 = S.bkt_off[(size_t)t * S.C + c];
         k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
