@@ -2801,6 +2801,9 @@ __global__ __launch_bounds__(R3_THREADS) void k_tick_replica3(Static S, State D,
 #ifndef WK_PAIR_SPAN
 #define WK_PAIR_SPAN 65536                  // a paired scan takes the bucket's next order only if its rank is at most this far ahead
 #endif
+#ifndef WK_RES
+#define WK_RES 10                           // orders a thread resolves at a time (their loads in flight together)
+#endif
 #define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
 #ifdef WKDEBUG
 #define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
@@ -3644,18 +3647,18 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     int *rc_l = tab_l;
     for (int i = threadIdx.x; i < RCNT * C; i += WK_THREADS) rc_l[i] = 0;
     __syncthreads();
-    for (int qq = tq0 + (int)threadIdx.x; qq < tq1; qq += 3 * WK_THREADS) {
-        int4 rec[3];
-        int2 pr[3];
-        int veh[3];
+    for (int qq = tq0 + (int)threadIdx.x; qq < tq1; qq += WK_RES * WK_THREADS) {
+        int4 rec[WK_RES];
+        int2 pr[WK_RES];
+        int veh[WK_RES];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < WK_RES; ++u) {
             const int q = qq + u * WK_THREADS;
             rec[u] = make_int4(0, 0, 0, 0); pr[u] = make_int2(-1, -1);
             if (q < tq1) { rec[u] = S.so_rec[q]; pr[u] = out_r[q]; }
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < WK_RES; ++u) {
             veh[u] = -1;
             if (pr[u].x != -1) {
                 const int vc = (int)((unsigned)pr[u].x >> 16), vpos = pr[u].x & 0xFFFF;
@@ -3666,7 +3669,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < WK_RES; ++u) {
             const int q = qq + u * WK_THREADS;
             if (q >= tq1) continue;
             int *cl = rc_l + (int)((unsigned)rec[u].z >> 16) * RCNT;
