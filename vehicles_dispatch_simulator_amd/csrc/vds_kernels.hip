@@ -3107,8 +3107,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     __shared__ int s_ev;                  // evaluations of the dry orders
     __shared__ int s_nlog;                // steals (entries of the replica's steal log)
 #ifdef WKDEBUG
-    __shared__ int s_dbg, s_dbga, s_dbgb;
-    if (threadIdx.x == 0) { s_dbga = 0; s_dbgb = 0; }
+    __shared__ int s_dbg;                 // (make dbg) the dry orders' evaluations counted by the walk itself, against the closed form
 #endif
     __shared__ int s_cursor;              // rank of the dry order the walk is at: the scanning wavefronts look for work from there on
     __shared__ int s_done;                // the walk is over
