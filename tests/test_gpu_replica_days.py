@@ -217,3 +217,29 @@ def test_days_in_blocks_of_sixteen_replicas_take_the_workgroup_uniform_path(name
         for k in ("idle_off", "idle_veh", "arr_off", "arr_veh", "arr_min"):
             np.testing.assert_array_equal(G[k], L[k], err_msg="replica %d %s" % (r, k))
     env.close()
+
+
+def test_reloading_days_on_one_handle_neighbour_search():
+    """vds_load_orders again and again on one handle (Simulation.Reload): the per-day tables of the hybrid neighbour-search tick
+    (visit rows, cost bounds, steal log) are rebuilt each time; every day equals its oracle, incl. the evaluations."""
+    g = load_golden("tiny_kmeans_dfs2")
+    V, N, R = int(g["V"]), int(g["N"]), 5
+    days = synth_days(g, 3, seed=77)
+    valid = g["node2cluster"] >= 0
+    init = np.stack([synth.init_vehicle_nodes(random.Random(5 + r), N, V, valid) for r in range(R)]).astype(np.int32)
+    env = mk_env(g, R)
+    for d in (0, 1, 2, 0):
+        env.load_orders(*days[d])
+        assert env.main_kernel() == "k_dfs_hybrid"
+        env.reset(init)
+        env.run(env.T)
+        env.sync()
+        got, cn = env.orders(), env.counters()
+        for r in range(R):
+            o = mk_oracle(g, days[d])
+            o.reset(init[r]); o.run_day()
+            exp, oc = o.orders(), o.counters()
+            for k in ("status", "vehicle", "wait"):
+                np.testing.assert_array_equal(got[k][r][:exp[k].size], exp[k], err_msg="day %d replica %d %s" % (d, r, k))
+            assert cn[r, 7] == oc["evals"] and cn[r, 1] == oc["reject_num"]
+    env.close()
