@@ -652,7 +652,10 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
                 if (pos >= m && pos < mnew) idle[pos] = make_uint2(veh[s], (unsigned)loc[s]);
             }
             if (l16 < 3) D.hdr[b * HDR_WORDS + l16] = l16 == HDR_ORDERS ? k : mnew;          // the list keeps its length until the walk commits
-            if (l16 == CNT_ARRIVALS && A > 0) D.cnt[b * CNT_WORDS + l16] = cntv + A;
+            if (l16 == CNT_ARRIVALS && A > 0) {
+                if (ST) atomicAdd(reinterpret_cast<unsigned long long *>(&D.cnt[b * CNT_WORDS + l16]), (unsigned long long)A);   // (stamp mode does not load the counters)
+                else D.cnt[b * CNT_WORDS + l16] = cntv + A;
+            }
         }
         return;
     }
@@ -794,7 +797,10 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
                 if (idx < A) idle[m + idx] = arr_row[idx];
             }
             if (l16 < 3) D.hdr[b * HDR_WORDS + l16] = l16 == HDR_ORDERS ? 0 : m + A;
-            if (l16 == CNT_ARRIVALS && A > 0) D.cnt[b * CNT_WORDS + l16] = cntv + A;
+            if (l16 == CNT_ARRIVALS && A > 0) {
+                if (ST) atomicAdd(reinterpret_cast<unsigned long long *>(&D.cnt[b * CNT_WORDS + l16]), (unsigned long long)A);   // (stamp mode does not load the counters)
+                else D.cnt[b * CNT_WORDS + l16] = cntv + A;
+            }
         }
         return;
     }
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
         m = hdr[HDR_IDLE];
         far = hdr[HDR_FL] | hdr[HDR_INBOX0 + p];
         A = D.ring_cnt[si] & 0xFFFF;
-        if (l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];
+        if (!ST && l16 < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + l16];      // (stamp mode only counts the arrivals: one atomic, no read)
     }
     const int nc = cd.x;
     const bool wg_ok = nc * nc <= lds_elems && k <= 64;
