@@ -76,7 +76,11 @@ typedef struct vds_config {
                                          generation (k_tick_replica2, lower-bound rounds: what 0 falls back to when the hybrid tick's
                                          preconditions do not hold), 4 = third
                                          generation (k_tick_replica3: own-cluster pass once + dry-order walk; exact,
-                                         measured slower at configs[3]); 0 = fastest */
+                                         measured slower at configs[3]); 5 = the row-mapped kernel (k_tick_rows) where 0
+                                         would pick the lanes tick; 6 = the lanes tick (k_tick_lanes: lane = replica,
+                                         transposed state tables) at any replica count - 0 picks it from 32 replicas on
+                                         when there is one shared order day, no neighbour search, costs <= 254;
+                                         0 = fastest */
 } vds_config;
 
 /* Fill cfg with defaults (tick 10 min, threshold 6e11, caps auto). */

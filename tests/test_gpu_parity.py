@@ -151,7 +151,20 @@ MODES = {
     "dfs_v1": {"force_generic": 2},          # neighbour search by the first-generation kernel (lists edited in place)
     "dfs_v2": {"force_generic": 3},          # ... by the second-generation kernel (lower-bound rounds); default = hybrid tick
     "dfs_v3": {"force_generic": 4},          # ... by the third-generation kernel (own-cluster pass once + dry-order walk); default = second
+    # lanes tick (k_tick_lanes, layout T: lane = replica; the default from 32 replicas on when there is no neighbour search) -
+    # one, two, four lanes per bucket; tiny per-lane LDS tables (buckets that outgrow them take the slow path); slow path only;
+    # far tables.  With neighbour search the library keeps its own choice (these fixtures then repeat the default run).
+    "lanes": {"force_generic": 6, "lanes_debug": (0, 0, 0, 0)},
+    "lanes_l2": {"force_generic": 6, "lanes_debug": (1, 0, 0, 0)},
+    "lanes_l4": {"force_generic": 6, "lanes_debug": (2, 0, 0, 0)},
+    "lanes_auto": {"force_generic": 6},
+    "lanes_tiny": {"force_generic": 6, "lanes_debug": (0, 8, 16, 0)},
+    "lanes_tiny_l4": {"force_generic": 6, "lanes_debug": (2, 4, 16, 0)},
+    "lanes_slow": {"force_generic": 6, "lanes_debug": (1, 0, 0, 1)},
+    "lanes_far": {"force_generic": 6, "ring_ticks": 2},
+    "rows": {"force_generic": 5},            # the row-mapped kernel where the lanes tick would be the default
 }
+LANES = [m for m in MODES if m.startswith("lanes")]
 
 
 @pytest.mark.parametrize("mode", list(MODES))
@@ -168,7 +181,7 @@ def test_device_resident_dispatch_tensor(name):
     run_day(g, R=5, same_init=True, device_dispatch=True)
 
 
-@pytest.mark.parametrize("mode", ["fast", "generic"])
+@pytest.mark.parametrize("mode", ["fast", "generic", "rows"] + LANES)
 @pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid"])
 def test_many_replicas_ragged(name, mode):
     """R not a multiple of the workgroup's replica run; every replica its own vehicle seed."""
@@ -199,7 +212,7 @@ def test_tight_ring_cap_overflow_is_reported():
     env.close()
 
 
-@pytest.mark.parametrize("mode", ["fast", "generic", "far"])
+@pytest.mark.parametrize("mode", ["fast", "generic", "far"] + LANES)
 def test_burst_of_identical_orders(mode):
     """100 identical orders / 120 co-located vehicles: ties everywhere, 100 arrivals in one slot."""
     g, P = _burst(load_golden("tiny_kmeans"), 100)
@@ -228,7 +241,7 @@ def test_small_caps_overflow_is_reported():
     env.close()
 
 
-@pytest.mark.parametrize("mode", ["fast", "generic"])
+@pytest.mark.parametrize("mode", ["fast", "generic"] + LANES)
 def test_all_vehicles_in_one_cluster_oversize_bucket(mode):
     """> 256 idle vehicles in one cluster exercises the deferred 16-slot kernel."""
     g = load_golden("tiny_kmeans")

@@ -22,6 +22,8 @@ void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
+size_t lanes_lds_bytes(const Static &, int *);
+int lanes_prepare(const Static &);
 size_t dfs_walk_lds(const Static &);
 int dfs_walk_pool(const Static &);
 size_t replica3_lds(const Static &);
@@ -62,6 +64,11 @@ struct vds_handle {
     bool dfs3_ok = false;   // k_tick_replica3 preconditions hold
     bool hybrid_ok = false; // hybrid neighbour-search tick (k_tick_rows in stamp mode + k_dfs_walk) preconditions hold
     long long blk_ints = 0; // total size of the per-cluster cost blocks
+    // lanes tick (k_tick_lanes, layout T): static preconditions, the layout the state tables were allocated for, test overrides
+    bool lanes_static_ok = false;
+    int alloc_layoutT = -1;
+    int dbg_lanes_lg = -1, dbg_lanes_loc = 0, dbg_lanes_keys = 0, dbg_lanes_slow = 0;
+    std::vector<long long> blk8s_off;        // [C] offsets of the stride-(n_c + 1) byte blocks
     int cost_min = 0, cost_max = 0;
     int max_seq = 0;        // longest visit sequence of FindServerVehicleFunction over the clusters
     std::vector<unsigned char> lbc_host;     // host copy of Static.lbc (empty: none)
@@ -144,6 +151,11 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
     }
 }
 
+// replica count from which vds_config.force_generic == 0 picks the lanes tick (k_tick_lanes) over the row-mapped kernel
+#ifndef LANES_AUTO_MIN_R
+#define LANES_AUTO_MIN_R (1 << 30)
+#endif
+
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" {
@@ -222,7 +234,7 @@ void vds_config_init(vds_config *cfg) {
 
 const char *vds_main_kernel(const vds_handle *h) {
     if (!h || !h->have_orders) return "";
-    if (!h->dfs_mode) return h->S.fast_ok ? "k_tick_rows" : "k_tick";
+    if (!h->dfs_mode) return h->S.layoutT ? "k_tick_lanes" : (h->S.fast_ok ? "k_tick_rows" : "k_tick");
     if (h->hybrid_ok && h->cfg.force_generic == 0) return "k_dfs_hybrid";
     if (h->S.C <= 3072 && h->cfg.force_generic != 1) {
         if (h->dfs3_ok && h->cfg.force_generic == 4) return "k_tick_replica3";
@@ -473,6 +485,27 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
             }
         }
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
+        // lanes tick: byte blocks with row stride n_c + 1 whose extra column holds 0xFF - the loc byte of a taken / absent idle
+        // entry points there, so such an entry loses every comparison without a test in the match loop.  Needs costs <= 254.
+        S.blk8s = nullptr;
+        h->blk8s_off.assign(C, 0);
+        bool s_ok = S.u8_ok && max_nc <= 254;
+        for (size_t i = 0; i < blk.size() && s_ok; ++i) s_ok = blk[i] <= 254;
+        if (s_ok) {
+            long long tot = 0;
+            for (int c = 0; c < C; ++c) { const long long nc = cdesc[c].x; h->blk8s_off[c] = tot; tot += (nc * (nc + 1) + 15) / 16 * 16; }
+            s_ok = tot < (1ll << 31);
+            if (s_ok) {
+                std::vector<unsigned char> b8s((size_t)std::max<long long>(tot, 16), 0xFF);
+                for (int c = 0; c < C; ++c) {
+                    const long long nc = cdesc[c].x;
+                    for (long long pp = 0; pp < nc; ++pp)
+                        for (long long l = 0; l < nc; ++l) b8s[(size_t)(h->blk8s_off[c] + pp * (nc + 1) + l)] = (unsigned char)blk[(size_t)cdesc[c].y + pp * nc + l];
+                }
+                unsigned char *d8; if ((rc = upload(h, &d8, b8s))) return rc; S.blk8s = d8;
+            }
+        }
+        h->lanes_static_ok = s_ok;
     }
     h->max_seq = 0;
     for (int c = 0; c < C; ++c) h->max_seq = std::max(h->max_seq, dfs_off[c + 1] - dfs_off[c]);
@@ -492,6 +525,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     // LDS budget for the cluster cost block
     const int lds_budget_ints = (64 * 1024) / 4;
     h->lds_ints = std::min((max_nc * max_nc + 3) / 4 * 4, lds_budget_ints);
+    h->lanes_static_ok = h->lanes_static_ok && !h->dfs_mode && S.fast_ok && S.V < (1 << 24);
     h->have_static = true;
     return VDS_OK;
 }
@@ -514,12 +548,17 @@ static int alloc_state(vds_handle *h, int O) {
     ring_cap = round_up(ring_cap, 16);
     if (ring_cap > 65520) return fail(h, VDS_EINVAL, "ring_cap=%d > 65520 unsupported", ring_cap);
     int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
-    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap)
+    S.G = (R + 63) / 64;
+    if (S.layoutT && (std::max(idle_cap, S.idle_cap) > 65532 || H > 32)) S.layoutT = 0;      // list positions travel in 16 bits, insert ticks in 5
+    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_layoutT >= S.layoutT)
         return VDS_OK;                                   // another day on the same handle: the state tables still fit
     for (void *p : h->state_allocs) (void)hipFree(p);
     h->state_allocs.clear();
     S.idle_cap = idle_cap; S.fl_cap = far_cap; S.in_cap = far_cap; S.H = H; S.ring_cap = ring_cap;
     const size_t B = (size_t)C * R;
+    // layout T pads the replica dimension of idle / ring to whole groups of 64 (vds_device.h); its tables also hold layout 0
+    const size_t BT = S.layoutT ? (size_t)C * S.G * 64 : B;
+    h->alloc_layoutT = S.layoutT;
     int rc;
     struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
     h->alloc_sink = &h->state_allocs;
@@ -530,11 +569,11 @@ static int alloc_state(vds_handle *h, int O) {
         h->alloc_sink = &h->idle_allocs;
         for (void *p : h->idle_allocs) (void)hipFree(p);
         h->idle_allocs.clear();
-        rc = dev_alloc(h, &D.idle, B * idle_cap);
+        rc = dev_alloc(h, &D.idle, std::max(B * idle_cap, BT * idle_cap / 2));      // (layout T: 4-byte entries)
         h->alloc_sink = keep;
         if (rc) return rc;
     }
-    if ((rc = dev_alloc(h, &D.ring, (size_t)H * B * ring_cap))) return rc;
+    if ((rc = dev_alloc(h, &D.ring, (size_t)H * BT * ring_cap))) return rc;
     if ((rc = dev_alloc(h, &D.ring_cnt, (size_t)H * B))) return rc;
     if ((rc = dev_alloc(h, &D.fl, B * far_cap))) return rc;
     if ((rc = dev_alloc(h, &D.inbox, 2 * B * far_cap))) return rc;
@@ -743,9 +782,52 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[h->replica_day[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
         int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
     }
-    if ((rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1)))) return rc;
+    // ---- lanes tick (k_tick_lanes, layout T: lane = replica): one shared order day, byte costs <= 254, no neighbour search.
+    //      force_generic 0: from 32 replicas on; 6: at any replica count; 5 (and everything else): the row-mapped kernel.
+    {
+        S.G = (S.R + 63) / 64;
+        S.lane_loc_slots = h->dbg_lanes_loc > 0 ? round_up(h->dbg_lanes_loc, 4) : 64;
+        S.lane_key_slots = std::max(16, h->dbg_lanes_keys > 0 ? h->dbg_lanes_keys : 32);
+        S.lane_force_slow = h->dbg_lanes_slow;
+        const bool can = h->lanes_static_ok && n_days == 1 && Omax <= (1 << 26) && lanes_prepare(S) == 0;
+        S.layoutT = (can && ((h->cfg.force_generic == 0 && S.R >= LANES_AUTO_MIN_R) || h->cfg.force_generic == 6)) ? 1 : 0;
+        S.cdesc_lanes = nullptr; S.lane_blocks = nullptr; S.lane_nblocks = 0;
+        if (S.layoutT) {
+            // lanes per bucket (1, 2, 4) by the cluster's share of the day: the per-lane LDS tables hold lane_loc_slots idle
+            // entries and lane_key_slots arrivals, a bucket gets L times that; buckets that outgrow them take the slow path
+            std::vector<long long> deliv(C, 0), pick(C, 0);
+            for (const int4 &rr : so_rec) { deliv[rr.z & 0xFFFF]++; pick[(unsigned)rr.z >> 16]++; }
+            const double nproc = std::max<double>(1.0, (double)so_rec.size());
+            std::vector<int> lg(C, 0);
+            std::vector<double> wgt(C, 0.0);
+            for (int c = 0; c < C; ++c) {
+                const double share = deliv[c] / nproc;
+                const double a_peak = share * mto, m_exp = share * S.V;
+                const double need = std::max((a_peak * 1.6 + 6.0) / S.lane_key_slots, (m_exp * 1.3 + a_peak + 8.0) / S.lane_loc_slots);
+                lg[c] = h->dbg_lanes_lg >= 0 ? std::min(h->dbg_lanes_lg, 2) : (need <= 1.0 ? 0 : need <= 2.0 ? 1 : 2);
+                wgt[c] = ((double)pick[c] / nproc) * (m_exp + a_peak + 1.0) / (1 << lg[c]) + 1e-9 * (h->cl_off[c + 1] - h->cl_off[c]);
+            }
+            std::vector<int> ord(C);
+            for (int c = 0; c < C; ++c) ord[c] = c;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wgt[a] > wgt[b]; });
+            std::vector<int4> cdl(C);
+            std::vector<int2> blocks;
+            for (int i = 0; i < C; ++i) {
+                const int c = ord[i], nc = h->cl_off[c + 1] - h->cl_off[c];
+                cdl[i] = make_int4(nc | (lg[c] << 16), (int)h->blk8s_off[c], c, nc + 1);
+                for (int wi = 0; wi < (S.G << lg[c]); ++wi) blocks.push_back(make_int2(i, wi));
+            }
+            int4 *dcl; if ((rc = upload(h, &dcl, cdl))) return rc; S.cdesc_lanes = dcl;
+            int2 *dbl; if ((rc = upload(h, &dbl, blocks))) return rc; S.lane_blocks = dbl;
+            S.lane_nblocks = (int)blocks.size();
+        }
+    }
     h->alloc_sink = nullptr;
     if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;
+    h->alloc_sink = &h->order_allocs;            // results: [R][Oq], or - layout T - [Oq][64 G]
+    rc = dev_alloc(h, &h->D.out, (size_t)(h->alloc_layoutT > 0 ? S.G * 64 : S.R) * std::max(Oqmax, 1));
+    h->alloc_sink = nullptr;
+    if (rc) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
         const Static &Z = h->S;
         const int ids2 = std::max(Z.max_tick_orders, 4 * Z.C);
@@ -840,10 +922,12 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     for (void *p : h->idle_allocs) (void)hipFree(p);
     h->idle_allocs.clear();
     h->alloc_sink = &h->idle_allocs;
-    const int rc = dev_alloc(h, &h->D.idle, (size_t)h->S.C * h->S.R * cap);
+    const size_t B0 = (size_t)h->S.C * h->S.R, BT0 = h->alloc_layoutT > 0 ? (size_t)h->S.C * h->S.G * 64 : B0;
+    const int rc = dev_alloc(h, &h->D.idle, std::max(B0 * cap, BT0 * cap / 2));
     h->alloc_sink = nullptr;
     if (rc) return rc;
     h->S.idle_cap = cap;
+    if (cap > 65532) h->S.layoutT = 0;       // k_tick_lanes carries list positions in 16 bits: the row-mapped kernel takes over
     h->idle_cap_grown = cap;
     // k_tick_replica2 addresses list positions with 15 bits
     if (cap > 32767) { h->dfs2_ok = false; h->dfs3_ok = false; }
@@ -1021,6 +1105,8 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
     if (n < 0 || !replica || !from_cluster || !idle_pos || !target_node) return fail(h, VDS_EINVAL, "vds_apply_dispatch: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const Static &S = h->S;
+    if (S.layoutT && (long long)h->dispatch_seq + n >= (1 << 26))
+        return fail(h, VDS_ECAPACITY, "vds_apply_dispatch: more than 2^26 dispatch actions in one episode (the lanes tick orders arrivals by 26-bit ids); vds_config.force_generic = 5 selects the row-mapped kernel");
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) {
         order[i] = i;
@@ -1189,7 +1275,13 @@ static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *stat
     if (rc) return rc;
     const int Oq = S.Oq, O = h->O;     // row strides: the longest day's (a shorter day leaves the tail of its row at 0 / -1)
     std::vector<int2> res((size_t)nr * std::max(Oq, 1));
-    if (Oq > 0 && nr > 0)
+    if (Oq > 0 && nr > 0 && S.layoutT) {
+        // [Oq][64 G]: columns r0 .. r0 + nr of every order's row, transposed on the host
+        std::vector<int2> cols((size_t)Oq * nr);
+        HIPCHK(h, hipMemcpy2D(cols.data(), (size_t)nr * sizeof(int2), h->D.out + r0, (size_t)S.G * 64 * sizeof(int2), (size_t)nr * sizeof(int2), Oq, hipMemcpyDeviceToHost));
+        for (int q = 0; q < Oq; ++q)
+            for (int r = 0; r < nr; ++r) res[(size_t)r * Oq + q] = cols[(size_t)q * nr + r];
+    } else if (Oq > 0 && nr > 0)
         HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)r0 * Oq, (size_t)nr * Oq * sizeof(int2), hipMemcpyDeviceToHost));
     for (int r = 0; r < nr; ++r) {
         const DayHost &H = h->days[h->replica_day[r0 + r]];
@@ -1229,6 +1321,14 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
     const bool want_arr = arr_off && arr_veh;
     if (want_idle) {
         std::vector<uint2> idle((size_t)C * S.idle_cap);
+        if (S.layoutT) {
+            // quads of four packed entries {veh << 8 | loc}: [C][G][idle_cap / 4][64][4]; this replica's column of every quad row
+            std::vector<unsigned> pk((size_t)C * S.idle_cap);
+            const size_t rows_per_c = (size_t)(S.idle_cap >> 2), pitch = 64 * 4 * sizeof(unsigned);
+            for (int c = 0; c < C; ++c)
+                HIPCHK(h, hipMemcpy2D(pk.data() + (size_t)c * S.idle_cap, 4 * sizeof(unsigned), reinterpret_cast<const unsigned *>(h->D.idle) + idleT_base(S, c, replica), pitch, 4 * sizeof(unsigned), rows_per_c, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < pk.size(); ++i) idle[i] = make_uint2(pk[i] >> 8, pk[i] & 0xFFu);
+        } else
         HIPCHK(h, hipMemcpy2D(idle.data(), S.idle_cap * sizeof(uint2), h->D.idle + (size_t)replica * S.idle_cap, (size_t)R * S.idle_cap * sizeof(uint2), S.idle_cap * sizeof(uint2), C, hipMemcpyDeviceToHost));
         int n = 0;
         idle_off[0] = 0;
@@ -1252,6 +1352,10 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
         std::vector<int> rcnt((size_t)H * C);
         HIPCHK(h, hipMemcpy2D(fl.data(), S.fl_cap * sizeof(int4), h->D.fl + (size_t)replica * S.fl_cap, (size_t)R * S.fl_cap * sizeof(int4), S.fl_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy2D(inb.data(), S.in_cap * sizeof(int4), h->D.inbox + ((size_t)np * C * R + replica) * S.in_cap, (size_t)R * S.in_cap * sizeof(int4), S.in_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
+        if (S.layoutT)      // [H][C][G][ring_cap][64]: this replica's column; rows = (slot, cluster, entry) after skipping the other groups
+            for (int sc = 0; sc < H * C; ++sc)
+                HIPCHK(h, hipMemcpy2D(ring.data() + (size_t)sc * S.ring_cap, sizeof(int4), h->D.ring + ringT_base(S, sc / C, sc % C, replica), 64 * sizeof(int4), sizeof(int4), S.ring_cap, hipMemcpyDeviceToHost));
+        else
         HIPCHK(h, hipMemcpy2D(ring.data(), S.ring_cap * sizeof(int4), h->D.ring + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(int4), S.ring_cap * sizeof(int4), (size_t)H * C, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy2D(rcnt.data(), sizeof(int), h->D.ring_cnt + replica, (size_t)R * sizeof(int), sizeof(int), (size_t)H * C, hipMemcpyDeviceToHost));
         int n = 0;
@@ -1290,6 +1394,14 @@ int vds_debug_ablate(vds_handle *h, int32_t flags) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     set_ablate(flags, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VDS_OK;
+}
+
+// Test hook (not part of the drop-in surface): overrides for the lanes tick, effective from the next vds_load_orders on -
+// lanes per bucket (log2: 0, 1, 2; -1 = by demand share), per-lane LDS capacities (0 = defaults), force the slow path.
+int vds_debug_lanes(vds_handle *h, int32_t log2_lanes, int32_t loc_slots, int32_t key_slots, int32_t force_slow) {
+    if (!h) return VDS_EINVAL;
+    h->dbg_lanes_lg = log2_lanes; h->dbg_lanes_loc = loc_slots; h->dbg_lanes_keys = key_slots; h->dbg_lanes_slow = force_slow;
     return VDS_OK;
 }
 
@@ -1366,6 +1478,8 @@ static int apply_dispatch_device_impl(vds_handle *h, int32_t K, const void *dev_
     if (K == 0) return VDS_OK;
     if (K < 0 || K > 64 || !dev_actions) return fail(h, VDS_EINVAL, "vds_apply_dispatch_device: K must be in [0, 64] and the action tensor non-null");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->S.layoutT && (long long)h->dispatch_seq + K >= (1 << 26))
+        return fail(h, VDS_ECAPACITY, "vds_apply_dispatch_device: more than 2^26 dispatch actions in one episode (the lanes tick orders arrivals by 26-bit ids); vds_config.force_generic = 5 selects the row-mapped kernel");
     launch_dispatch_dense(h->S, h->D, h->t, K, (const int *)dev_actions, h->dispatch_seq, h->stream);
     HIPCHK(h, hipGetLastError());
     h->dispatch_seq += K;

@@ -115,6 +115,21 @@ struct Static {
     int seq_pad;                     // longest visit sequence, rounded up to a multiple of 64
     const int *so_rank;              // [Oq] rank of the sorted position inside its slot, in id order (= cursor order of :912-973)
     int max_tick_orders;             // most orders processed in one tick
+    // ---- layout T ("lanes" tick, k_tick_lanes in vds_lanes.hip): lane = replica.  Per-replica tables are transposed inside
+    // groups of 64 replicas so that the 64 lanes of a wavefront - the same cluster in 64 consecutive replicas - touch
+    // consecutive addresses:
+    //   idle  u32 {veh << 8 | loc_local}   [C][G][idle_cap / 4][64][4]   (entry e of replica r: quad e / 4, column r % 64, element e % 4)
+    //   ring  int4 (unchanged entry)       [H][C][G][ring_cap][64]
+    //   out   int2 {veh, wait}             [Oq][64 G]
+    // hdr / cnt / ring_cnt / fl / inbox keep their [C][R] layouts.
+    int layoutT;                     // 1: the tables above are in layout T
+    int G;                           // groups of 64 replicas = ceil(R / 64)
+    const int4 *cdesc_lanes;         // [C] {n_c | log2(lanes per bucket) << 16, offset into blk8s, cluster, row stride n_c + 1}, heaviest first
+    const int2 *lane_blocks;         // [lane_nblocks] {index into cdesc_lanes, wavefront index inside the cluster}
+    int lane_nblocks;
+    const unsigned char *blk8s;      // per-cluster byte cost blocks with row stride n_c + 1; column n_c holds 0xFF (the cost of a taken / absent entry)
+    int lane_loc_slots, lane_key_slots;   // per-lane LDS capacities: idle entries / arrivals per lane (x lanes per bucket)
+    int lane_force_slow;             // testing: every wavefront takes the table-free slow path
 };
 
 struct State {
@@ -130,6 +145,39 @@ struct State {
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
 };
+
+// ---- layout T addressing (host and device)
+// idle entry e of (c, r): ((unsigned *)D.idle)[idleT_base + (e >> 2) * 256 + (e & 3)]
+__host__ __device__ inline size_t idleT_base(const Static &S, int c, int r) {
+    return ((((size_t)c * S.G + (size_t)(r >> 6)) * (size_t)(S.idle_cap >> 2)) * 64 + (size_t)(r & 63)) * 4;
+}
+__host__ __device__ inline size_t idleT_elem(int e) { return (size_t)(e >> 2) * 256 + (size_t)(e & 3); }
+// ring entry i of (slot, c, r): D.ring[ringT_base + i * 64]
+__host__ __device__ inline size_t ringT_base(const Static &S, int slot, int c, int r) {
+    return ((((size_t)slot * S.C + c) * S.G + (size_t)(r >> 6)) * (size_t)S.ring_cap) * 64 + (size_t)(r & 63);
+}
+__host__ __device__ inline unsigned idleT_pack(unsigned veh, unsigned loc) { return (veh << 8) | (loc & 0xFFu); }
+
+// One (cluster, replica) idle list in either layout: what the kernels shared by both layouts (reset, dispatch) go through.
+struct IdleRef {
+    uint2 *p;        // layout 0: {veh, loc_local} entries, contiguous
+    unsigned *q;     // layout T (non-null): packed entries, see Static
+    __device__ __forceinline__ uint2 get(int e) const {
+        if (!q) return p[e];
+        const unsigned v = q[idleT_elem(e)];
+        return make_uint2(v >> 8, v & 0xFFu);
+    }
+    __device__ __forceinline__ void set(int e, uint2 v) const {
+        if (!q) p[e] = v;
+        else q[idleT_elem(e)] = idleT_pack(v.x, v.y);
+    }
+};
+__device__ __forceinline__ IdleRef idle_ref(const Static &S, const State &D, int c, int r) {
+    IdleRef f;
+    if (S.layoutT) { f.p = nullptr; f.q = reinterpret_cast<unsigned *>(D.idle) + idleT_base(S, c, r); }
+    else { f.p = D.idle + ((size_t)c * S.R + r) * S.idle_cap; f.q = nullptr; }
+    return f;
+}
 
 __device__ __forceinline__ DayView day_view(const Static &S, int r) {
     if (S.n_days <= 1) return DayView{S.bkt_off, S.tick_off, S.now0, S.T, 0};

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_reset(Static S, State D, const int *veh
     if (r >= S.R) return;
     const int lane = lane_id();
     const size_t b = (size_t)c * S.R + r;
-    uint2 *idle = D.idle + b * S.idle_cap;
+    const IdleRef idle = idle_ref(S, D, c, r);
     const int *vn = veh_node + (size_t)r * S.V;
     int count = 0;
     for (int base = 0; base < S.V; base += WAVE) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_reset(Static S, State D, const int *veh
         unsigned long long bm = ballot(mine);
         if (mine) {
             int pos = count + popc64(bm & lanemask_lt());
-            if (pos < S.idle_cap) idle[pos] = make_uint2((unsigned)v, (unsigned)S.node_local[node]);
+            if (pos < S.idle_cap) idle.set(pos, make_uint2((unsigned)v, (unsigned)S.node_local[node]));
         }
         count += popc64(bm);
     }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
         if (valid) {
             const int bs = mine[cl];
             const int pos = bs + popc64(same & lanemask_lt());          // vehicle order is kept inside a cluster
-            if (pos < S.idle_cap) D.idle[((size_t)cl * S.R + r) * S.idle_cap + pos] = make_uint2((unsigned)v, nl);
+            if (pos < S.idle_cap) idle_ref(S, D, cl, r).set(pos, make_uint2((unsigned)v, nl));
             wave_fence();
             if ((same & lanemask_lt()) == 0) mine[cl] = bs + popc64(same);   // the cluster's first lane advances its cursor
         }
@@ -227,8 +227,9 @@ __device__ __forceinline__ void ring_post(const Static &S, const State &D, int d
     const size_t i = ((size_t)(tick & (S.H - 1)) * S.C + dc) * S.R + r;
     const int old = atomicAdd(&D.ring_cnt[i], meta_is_dispatch(e.w) ? 1 : 0x10001);   // high half: carries an order (:889)
     const int pos = old & 0xFFFF;
-    if (pos < S.ring_cap) D.ring[i * S.ring_cap + pos] = e;
-    else atomicOr(&D.err[0], ERR_RING_CAP);
+    if (pos >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
+    else if (S.layoutT) D.ring[ringT_base(S, tick & (S.H - 1), dc, r) + (size_t)pos * 64] = e;
+    else D.ring[i * S.ring_cap + pos] = e;
 }
 
 // ceil(rel / tick_minutes) for rel > 0.  SMALL: the caller guarantees rel < 2^25 (costs < 2^23), so the multiply-high form
@@ -3772,7 +3773,7 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
     const int now = day_view(S, r).now0 + t * S.tick_minutes;
     const size_t b = (size_t)c * S.R + r;
     int *hdr = D.hdr + b * HDR_WORDS;
-    uint2 *idle = D.idle + b * S.idle_cap;
+    const IdleRef idle = idle_ref(S, D, c, r);
     const int m = hdr[HDR_IDLE];
     long long cost_sum = 0;
     int ndone = 0, ncount = 0;
@@ -3783,7 +3784,7 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
         if (a < a1) {
             int pos = a_pos[a], tgt = a_target[a];
             if (pos >= 0 && pos < m) {
-                uint2 e = idle[pos];
+                uint2 e = idle.get(pos);
                 int tc = S.node2cluster[tgt];
                 cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
                 post_arrival(S, D, tc, r, t, now, (int)e.x, a_seq[a], a_arrive ? a_arrive[a] : now + cst, 1, S.node_local[tgt]);
@@ -3806,10 +3807,10 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
         bool keep = i < m;
         if (keep)
             for (int a = a0; a < a1; ++a) keep = keep && (a_pos[a] != i);
-        uint2 e = (i < m) ? idle[i] : make_uint2(0u, 0u);
+        uint2 e = (i < m) ? idle.get(i) : make_uint2(0u, 0u);
         unsigned long long kb = ballot(keep);
         wave_fence();
-        if (keep) idle[newm + popc64(kb & lanemask_lt())] = e;
+        if (keep) idle.set(newm + popc64(kb & lanemask_lt()), e);
         newm += popc64(kb);
         wave_fence();
     }
@@ -3929,7 +3930,7 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
             const int c = rdlane(cl, leader);
             const size_t b = (size_t)c * S.R + r;
             int *hdr = D.hdr + b * HDR_WORDS;
-            uint2 *idle = D.idle + b * S.idle_cap;
+            const IdleRef idle = idle_ref(S, D, c, r);
             const int m = hdr[HDR_IDLE];
             bool mine = (grp >> lane) & 1ull;
             {   // a position named twice: the first action (lowest slot) stands, the others are refused - nothing of
@@ -3946,7 +3947,7 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
             int cst = 0;
             if (mine) {
                 if (pos >= 0 && pos < m) {
-                    const uint2 e = idle[pos];
+                    const uint2 e = idle.get(pos);
                     cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
                     post_arrival(S, D, tc, r, t, now, (int)e.x, seq_base + k, now + cst, 1, S.node_local[tgt]);
                     ok = true;
@@ -3964,10 +3965,10 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
                 bool keep = i < m;
                 for (unsigned long long rest = grp; rest; rest &= rest - 1)
                     keep = keep && (rdlane(pos, __ffsll((long long)rest) - 1) != i);
-                const uint2 e = (i < m) ? idle[i] : make_uint2(0u, 0u);
+                const uint2 e = (i < m) ? idle.get(i) : make_uint2(0u, 0u);
                 const unsigned long long kb = ballot(keep);
                 wave_fence();
-                if (keep) idle[newm + popc64(kb & lanemask_lt())] = e;
+                if (keep) idle.set(newm + popc64(kb & lanemask_lt()), e);
                 newm += popc64(kb);
                 wave_fence();
             }
@@ -3995,8 +3996,11 @@ void launch_reset(const Static &S, const State &D, const int *veh_node, hipStrea
 
 static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_KEYS * 8 + lds_ints * 4; }
 
+void launch_tick_lanes(const Static &S, const State &D, int t, hipStream_t st);      // vds_lanes.hip
+
 // main kernel of a non-DFS tick (the one bench.py brackets with events)
 void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
+    if (S.layoutT) { launch_tick_lanes(S, D, t, st); return; }
     const int chunks = (S.R + 15) / 16;
     const int rchunks = ((S.rperm != nullptr ? S.rslots : S.R) + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
