@@ -157,6 +157,7 @@ MODES = {
     "lanes": {"force_generic": 6, "lanes_debug": (0, 0, 0, 0)},
     "lanes_l2": {"force_generic": 6, "lanes_debug": (1, 0, 0, 0)},
     "lanes_l4": {"force_generic": 6, "lanes_debug": (2, 0, 0, 0)},
+    "lanes_l8": {"force_generic": 6, "lanes_debug": (3, 0, 0, 0)},
     "lanes_auto": {"force_generic": 6},
     "lanes_tiny": {"force_generic": 6, "lanes_debug": (0, 8, 16, 0)},
     "lanes_tiny_l4": {"force_generic": 6, "lanes_debug": (2, 4, 16, 0)},

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -24,6 +25,7 @@ void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
 size_t lanes_lds_bytes(const Static &, int *);
 int lanes_prepare(const Static &);
+void lanes_read_prof(unsigned long long *, hipStream_t);
 size_t dfs_walk_lds(const Static &);
 int dfs_walk_pool(const Static &);
 size_t replica3_lds(const Static &);
@@ -786,14 +788,19 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     //      force_generic 0: from 32 replicas on; 6: at any replica count; 5 (and everything else): the row-mapped kernel.
     {
         S.G = (S.R + 63) / 64;
-        S.lane_loc_slots = h->dbg_lanes_loc > 0 ? round_up(h->dbg_lanes_loc, 4) : 64;
-        S.lane_key_slots = std::max(16, h->dbg_lanes_keys > 0 ? h->dbg_lanes_keys : 32);
+        // per-lane LDS tables: idle entries (4 B each) and arrival slots (8 B each); tuning knobs VDS_LANES_LOC / VDS_LANES_KEYS /
+        // VDS_LANES_LG (environment, read here) or vds_debug_lanes
+        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
+        S.lane_loc_slots = round_up(std::max(16, h->dbg_lanes_loc > 0 ? h->dbg_lanes_loc : env_int("VDS_LANES_LOC", 32)), 16);
+        S.lane_key_slots = std::max(8, h->dbg_lanes_keys > 0 ? h->dbg_lanes_keys : env_int("VDS_LANES_KEYS", 16));
         S.lane_force_slow = h->dbg_lanes_slow;
+        const int force_lg = h->dbg_lanes_lg >= 0 ? h->dbg_lanes_lg : env_int("VDS_LANES_LG", -1);
         const bool can = h->lanes_static_ok && n_days == 1 && Omax <= (1 << 26) && lanes_prepare(S) == 0;
-        S.layoutT = (can && ((h->cfg.force_generic == 0 && S.R >= LANES_AUTO_MIN_R) || h->cfg.force_generic == 6)) ? 1 : 0;
+        const int auto_min_r = env_int("VDS_LANES_AUTO_MIN_R", LANES_AUTO_MIN_R);
+        S.layoutT = (can && ((h->cfg.force_generic == 0 && S.R >= auto_min_r) || h->cfg.force_generic == 6)) ? 1 : 0;
         S.cdesc_lanes = nullptr; S.lane_blocks = nullptr; S.lane_nblocks = 0;
         if (S.layoutT) {
-            // lanes per bucket (1, 2, 4) by the cluster's share of the day: the per-lane LDS tables hold lane_loc_slots idle
+            // lanes per bucket (1, 2, 4, 8) by the cluster's share of the day: the per-lane LDS tables hold lane_loc_slots idle
             // entries and lane_key_slots arrivals, a bucket gets L times that; buckets that outgrow them take the slow path
             std::vector<long long> deliv(C, 0), pick(C, 0);
             for (const int4 &rr : so_rec) { deliv[rr.z & 0xFFFF]++; pick[(unsigned)rr.z >> 16]++; }
@@ -804,7 +811,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                 const double share = deliv[c] / nproc;
                 const double a_peak = share * mto, m_exp = share * S.V;
                 const double need = std::max((a_peak * 1.6 + 6.0) / S.lane_key_slots, (m_exp * 1.3 + a_peak + 8.0) / S.lane_loc_slots);
-                lg[c] = h->dbg_lanes_lg >= 0 ? std::min(h->dbg_lanes_lg, 2) : (need <= 1.0 ? 0 : need <= 2.0 ? 1 : 2);
+                lg[c] = force_lg >= 0 ? std::min(force_lg, 3) : (need <= 1.0 ? 0 : need <= 2.0 ? 1 : need <= 4.0 ? 2 : 3);
                 wgt[c] = ((double)pick[c] / nproc) * (m_exp + a_peak + 1.0) / (1 << lg[c]) + 1e-9 * (h->cl_off[c + 1] - h->cl_off[c]);
             }
             std::vector<int> ord(C);
@@ -1402,6 +1409,14 @@ int vds_debug_ablate(vds_handle *h, int32_t flags) {
 int vds_debug_lanes(vds_handle *h, int32_t log2_lanes, int32_t loc_slots, int32_t key_slots, int32_t force_slow) {
     if (!h) return VDS_EINVAL;
     h->dbg_lanes_lg = log2_lanes; h->dbg_lanes_loc = loc_slots; h->dbg_lanes_keys = key_slots; h->dbg_lanes_slow = force_slow;
+    return VDS_OK;
+}
+
+// instrumented build (make prof): [4][16] cycle sums per section of k_tick_lanes' fast path by lanes-per-bucket class
+int vds_debug_lanes_prof(vds_handle *h, uint64_t *out64) {
+    if (!h || !out64) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    lanes_read_prof((unsigned long long *)out64, h->stream);
     return VDS_OK;
 }
 

@@ -4,8 +4,8 @@
 //
 // Why.  With one order day shared by the replicas, the 64 replicas of a wavefront see THE SAME orders of a (tick, cluster)
 // bucket; only their idle lists differ.  k_tick_rows spends 16 lanes on one bucket (4 buckets per wavefront), ~53 VALU
-// instructions per order for 4 buckets whatever the list length.  Here every lane owns a bucket (or 1/2, 1/4 of one) and
-// walks ITS idle list serially: per candidate one LDS byte read of the cost (the cluster's cost block sits in LDS, row =
+// instructions per order for 4 buckets whatever the list length.  Here every lane owns a bucket (or 1/2, 1/4, 1/8 of one)
+// and walks ITS idle list serially: per candidate one LDS byte read of the cost (the cluster's cost block sits in LDS, row =
 // the order's pickup node, uniform), one shift-or into the key (cost << 16 | list position) and half a v_min3 - three
 // VALU instructions for 64 candidate evaluations.  "First strict minimum in list order" (:932) is the minimum key.
 //
@@ -14,23 +14,41 @@
 // wavefront instruction) and the posts of one order - same destination cluster in all replicas - land on neighbouring
 // ring counters and ring rows.
 //
-// Lanes per bucket (L = 1, 2, 4; chosen per cluster on the host from its share of the day's demand): a heavy cluster's
-// bucket is split over L lanes, entry e belongs to lane e % L; the L partial minima meet in a DPP quad reduction.  That
+// Lanes per bucket (L = 1, 2, 4, 8; chosen per cluster on the host from its share of the day's demand): a heavy cluster's
+// bucket is split over L lanes, entry e belongs to lane e % L; the L partial minima meet in a DPP reduction.  That
 // balances the wavefronts (a wavefront's time is its longest list x its orders) and scales the per-lane LDS tables.
 //
-// Per-lane LDS tables: loc bytes of the idle entries (a taken entry's byte becomes the index of the block's 0xFF column,
-// so it loses every comparison from then on), the 32-bit dict-insertion keys of this tick's arrivals, the per-order
-// results of a chunk.  A wavefront whose buckets do not fit them (or that owns far arrivals) takes the SLOW path: the same
-// code with the tables in HBM / L2 (template parameter FAST) - correct for any list length, only slower.
+// FAST path: the bucket lives in LDS for the tick.  The lane's idle entries {veh << 8 | loc} are fetched ONCE (the first
+// eight quads together with the header, before the list length is known), arrivals are ranked by 32-bit dict-insertion
+// keys in LDS and appended in LDS, a taken entry's loc byte becomes the index of the cost block's 0xFF column (it loses every
+// later comparison without a test in the loop), the survivors are packed in LDS and written back from the first change on.
+// HBM sees: header, list in, changed tail out, ring entries in, one atomic + one 16-byte entry per match, 8 bytes per order.
+// A wavefront whose buckets do not fit the tables (or that owns far arrivals) takes the SLOW path: the same steps against
+// HBM / L2 - correct for any list length, only slower.
 #include "vds_device.h"
+#include <cstring>
 
 namespace vds {
 
 namespace {
 
 #define WAVE 64
-#define LN_RS 16                 // result slots per lane: orders are matched in chunks of LN_RS * L
+#define LN_RS 8                  // result slots per lane: orders are matched in chunks of LN_RS * L
 #define LN_HIT 0x00FF0000u       // keys at or above: no candidate (cost byte 0xFF)
+#define LN_PQ 4                  // own quads (16 own entries) fetched together with the bucket header, and per batch after it
+#define LN_PE(LG) ((LG) == 0 ? 8 : (LG) == 1 ? 4 : 2)      // own ring entries fetched together with the header (more: in batches of 8)
+
+// instrumented build (make prof): cycles per section of the fast path, summed over the wavefronts of one class
+#ifdef VDS_PROF
+#define LN_PROF_SLOTS 16
+#define LN_PROF_WAVES 32768
+__device__ unsigned g_lanes_prof[LN_PROF_WAVES * LN_PROF_SLOTS];      // [block][slot] (a block's own row: no atomics); slot 14 = log2 L + 1, slot 15 = ticks recorded
+#define LPROF(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + (i)] += (unsigned)(t_ - lp_t); lp_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define LPROF_DECL unsigned long long lp_t = __builtin_amdgcn_s_memtime()
+#else
+#define LPROF(i) do { } while (0)
+#define LPROF_DECL do { } while (0)
+#endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 template <int CTRL>
@@ -56,29 +74,33 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     v = min(v, dppm<0x143, 0xC>(v, v));
     return __builtin_amdgcn_readlane(v, 63);
 }
-// reductions over the L = 1 << LG lanes of a bucket (aligned groups inside a quad); every lane receives the result
+// reductions over the L = 1 << LG lanes of a bucket (aligned groups of 2 / 4 / 8 lanes); every lane receives the result
 template <int LG>
 __device__ __forceinline__ unsigned grp_min_u32(unsigned v) {
     if (LG >= 1) v = min(v, (unsigned)dppx<0xB1>((int)v));
     if (LG >= 2) v = min(v, (unsigned)dppx<0x4E>((int)v));
+    if (LG >= 3) v = min(v, (unsigned)dppx<0x141>((int)v));
     return v;
 }
 template <int LG>
 __device__ __forceinline__ int grp_min_i32(int v) {
     if (LG >= 1) v = min(v, dppx<0xB1>(v));
     if (LG >= 2) v = min(v, dppx<0x4E>(v));
+    if (LG >= 3) v = min(v, dppx<0x141>(v));
     return v;
 }
 template <int LG>
 __device__ __forceinline__ int grp_sum_i32(int v) {
     if (LG >= 1) v += dppx<0xB1>(v);
     if (LG >= 2) v += dppx<0x4E>(v);
+    if (LG >= 3) v += dppx<0x141>(v);
     return v;
 }
 template <int LG>
 __device__ __forceinline__ unsigned grp_or_u32(unsigned v) {
     if (LG >= 1) v |= (unsigned)dppx<0xB1>((int)v);
     if (LG >= 2) v |= (unsigned)dppx<0x4E>((int)v);
+    if (LG >= 3) v |= (unsigned)dppx<0x141>((int)v);
     return v;
 }
 
@@ -110,15 +132,405 @@ struct LaneCtx {
     int t, now, q0, k;           // tick, RealExpTime, first sorted order of the (tick, cluster) bucket, orders in it
     int r, col;                  // replica, its column inside the group of 64
     bool valid;
-    int loc_q, key_slots;        // LDS capacities per lane: loc dwords (4 entries each), key slots
-    unsigned *locT;              // [loc_q][64] own entries' loc bytes, 4 per dword
+    int ent_q, key_slots;        // LDS capacities per lane: entry quads (4 own entries each), key slots
+    uint4 *entT;                 // [ent_q][64] own idle entries {veh << 8 | loc}, 4 per uint4
     unsigned *keyT;              // [key_slots][64] arrival keys; later [LN_RS][64] order results
+    unsigned *valT;              // [key_slots][64] arrival payloads {veh << 8 | loc}
     const unsigned char *blk;    // LDS cost block
 };
+// own slot s of lane l inside entT, as a dword index
+__device__ __forceinline__ int ent_word(int s, int l) { return (((s >> 2) * 64 + l) << 2) + (s & 3); }
 
-// One tick of the wavefront's 64 / L buckets.  FAST: per-lane tables in LDS; otherwise the same steps against HBM / L2.
-template <int LG, bool FAST>
-__device__ __forceinline__ void lanes_tick(const Static &S, const State &D, const LaneCtx &X, int m, int A, int4 h0, int4 h1) {
+__device__ __forceinline__ void lanes_finish(const Static &S, const State &D, size_t b, int p, bool writer, int4 h0, int mfin, int mnew, int k, int newfl,
+                                             bool inbox_reset, int A, int rej, int wsum, int vsum, long long evals) {
+    if (!writer) return;
+    if (h0.x != mfin || h0.y != mnew || h0.z != k || h0.w != newfl) *reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS) = make_int4(mfin, mnew, k, newfl);
+    if (inbox_reset) D.hdr[b * HDR_WORDS + HDR_INBOX0 + p] = 0;
+    unsigned long long *cu = reinterpret_cast<unsigned long long *>(D.cnt + b * CNT_WORDS);
+    if (k) atomicAdd(cu + CNT_ORDERS, (unsigned long long)k);
+    if (rej) atomicAdd(cu + CNT_REJECTS, (unsigned long long)rej);
+    if (wsum) atomicAdd(cu + CNT_WAIT, (unsigned long long)wsum);
+    if (vsum) atomicAdd(cu + CNT_VALUE, (unsigned long long)vsum);
+    if (evals) atomicAdd(cu + CNT_EVALS, (unsigned long long)evals);
+    if (A > 0) atomicAdd(cu + CNT_ARRIVALS, (unsigned long long)A);
+}
+
+// sorted order record of the chunk's order jj (lane jj of crec holds it)
+template <int LG>
+__device__ __forceinline__ int4 chunk_rec(int4 crec, int jj, int s) {
+    if (LG == 0) return make_int4(__builtin_amdgcn_readlane(crec.x, s), __builtin_amdgcn_readlane(crec.y, s), __builtin_amdgcn_readlane(crec.z, s), __builtin_amdgcn_readlane(crec.w, s));
+    return make_int4(__builtin_amdgcn_ds_bpermute(jj << 2, crec.x), __builtin_amdgcn_ds_bpermute(jj << 2, crec.y), __builtin_amdgcn_ds_bpermute(jj << 2, crec.z), __builtin_amdgcn_ds_bpermute(jj << 2, crec.w));
+}
+
+// result of one matched order: the ring-slot atomic (first half of post_arrival in vds_kernels.hip); returns the slot
+// position | ticks ahead << 16, or -1 when the trip went to the far inbox (complete) or the slot is full
+__device__ __forceinline__ int post_begin(const Static &S, const State &D, const LaneCtx &X, int dc, int veh, int id, int dest_local, int rel) {
+    const int t = X.t, r = X.r;
+    const int d = rel <= 0 ? 1 : ticks_until_small(S, rel);      // the next Update is at t + 1 at the earliest
+    if (d < S.H) {
+        const size_t i = ((size_t)((t + d) & (S.H - 1)) * S.C + dc) * S.R + r;
+        const int old = atomicAdd(&D.ring_cnt[i], 0x10001);      // high half: carries an order (:889)
+        const int pos = old & 0xFFFF;
+        if (pos >= S.ring_cap) { atomicOr(&D.err[0], ERR_RING_CAP); return -1; }
+        return pos | (d << 16);
+    }
+    const size_t db = (size_t)dc * S.R + r;
+    const int np = (t + 1) & 1;
+    const int sl = atomicAdd(&D.hdr[db * HDR_WORDS + HDR_INBOX0 + np], 1);
+    if (sl < S.in_cap) D.inbox[((size_t)np * S.C * S.R + db) * S.in_cap + sl] = make_int4(veh, id, X.now + rel, meta_pack(t, 0, dest_local));
+    else atomicOr(&D.err[0], ERR_INBOX_CAP);
+    return -1;
+}
+__device__ __forceinline__ void post_end(const Static &S, const State &D, const LaneCtx &X, int pd, int dc, int veh, int id, int dest_local, int rel) {
+    const int pos = pd & 0xFFFF, d = pd >> 16;
+    D.ring[ringT_base(S, (X.t + d) & (S.H - 1), dc, X.r) + (size_t)pos * 64] = make_int4(veh, id, X.now + rel, meta_pack(X.t, 0, dest_local));
+}
+
+// Own entries of a lane, four at a time ("own quad" gq = own slots 4 gq .. 4 gq + 3 = list entries (4 gq + u) L + sub).
+// L = 1: one 16-byte load (the list quad itself); L > 1: four 4-byte loads - the L lanes of a bucket read neighbouring words.
+// Raw: no length test (prefetch before the header is known; the words exist, idle_cap >= 8 L is checked by the caller).
+template <int LG>
+__device__ __forceinline__ uint4 load_own_quad_raw(const unsigned *idl, int gq, int sub) {
+    if (LG == 0) return *reinterpret_cast<const uint4 *>(idl + (size_t)gq * 256);
+    uint4 v;
+    v.x = idl[idleT_elem(((4 * gq + 0) << LG) + sub)];
+    v.y = idl[idleT_elem(((4 * gq + 1) << LG) + sub)];
+    v.z = idl[idleT_elem(((4 * gq + 2) << LG) + sub)];
+    v.w = idl[idleT_elem(((4 * gq + 3) << LG) + sub)];
+    return v;
+}
+template <int LG>
+__device__ __forceinline__ uint4 load_own_quad(const unsigned *idl, int gq, int sub, int m) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (LG == 0) {
+        if (4 * gq < m) v = *reinterpret_cast<const uint4 *>(idl + (size_t)gq * 256);
+        return v;
+    }
+    const int e0 = ((4 * gq) << LG) + sub;
+    if (e0 < m) v.x = idl[idleT_elem(e0)];
+    if (e0 + (1 << LG) < m) v.y = idl[idleT_elem(e0 + (1 << LG))];
+    if (e0 + (2 << LG) < m) v.z = idl[idleT_elem(e0 + (2 << LG))];
+    if (e0 + (3 << LG) < m) v.w = idl[idleT_elem(e0 + (3 << LG))];
+    return v;
+}
+// entries at or beyond the list length m become the sentinel entry (loc byte = index of the 0xFF column)
+template <int LG>
+__device__ __forceinline__ uint4 mask_own_quad(uint4 v, int gq, int sub, int m, unsigned sent) {
+    const int e0 = ((4 * gq) << LG) + sub;
+    if (e0 >= m) v.x = sent;
+    if (e0 + (1 << LG) >= m) v.y = sent;
+    if (e0 + (2 << LG) >= m) v.z = sent;
+    if (e0 + (3 << LG) >= m) v.w = sent;
+    return v;
+}
+
+// FAST path (see the file header).  pq: the lane's own quads 0 .. LN_PQ - 1, pe: the lane's first eight own ring entries - both
+// fetched by the caller together with the header.
+template <int LG>
+__device__ __forceinline__ void lanes_tick_fast(const Static &S, const State &D, const LaneCtx &X, int m, int A, int4 h0,
+                                                const uint4 (&pq)[LN_PQ], const int4 (&pe)[LN_PE(LG)], int4 crec0) {
+    constexpr int L = 1 << LG;
+    const int lane = lane_id();
+    const int sub = lane & (L - 1);
+    const int gbase = lane & ~(L - 1);
+    const int t = X.t, c = X.c, r = X.r, k = X.k;
+    const bool valid = X.valid;
+    const size_t b = (size_t)c * S.R + (valid ? r : 0);
+    const int slot = t & (S.H - 1);
+    unsigned *idl = reinterpret_cast<unsigned *>(D.idle) + idleT_base(S, c, valid ? r : 0);
+    const int4 *ring = D.ring + ringT_base(S, slot, c, valid ? r : 0);
+    const unsigned sent = (unsigned)X.nc;
+    unsigned *entW = reinterpret_cast<unsigned *>(X.entT);
+    const int mnew = m + A;
+    const int Amax = wave_max_i32(A);
+    const int mmax = wave_max_i32(mnew);
+    const int SM = (mmax + L - 1) >> LG;                  // own entry slots in use (longest bucket of the wavefront)
+    const int QS2 = (((SM + 3) >> 2) + 3) & ~3;           // own entry quads the match loop reads (16 candidates per step)
+    LPROF_DECL;
+
+    // ---- 1. the idle list -> LDS (own entries)
+    if (k > 0) {
+#pragma unroll
+        for (int gq = 0; gq < LN_PQ; ++gq)
+            if (gq < QS2) X.entT[gq * 64 + lane] = mask_own_quad<LG>(pq[gq], gq, sub, m, sent);
+        for (int g0 = LN_PQ; g0 < QS2; g0 += LN_PQ) {
+            uint4 q[LN_PQ];
+#pragma unroll
+            for (int i = 0; i < LN_PQ; ++i) q[i] = load_own_quad<LG>(idl, g0 + i, sub, m);
+#pragma unroll
+            for (int i = 0; i < LN_PQ; ++i)
+                if (g0 + i < QS2) X.entT[(g0 + i) * 64 + lane] = mask_own_quad<LG>(q[i], g0 + i, sub, m, sent);
+        }
+        lds_fence();
+    }
+    LPROF(2);
+
+    // ---- 2. arrivals of this tick (UpdateFunction :1014-1024): rank by dict-insertion key, append behind the list
+    if (Amax > 0) {
+        const int SA = (Amax + L - 1) >> LG;      // own arrival slots in use
+        bool oldk = false;
+#pragma unroll
+        for (int j = 0; j < LN_PE(LG); ++j) {
+            if (j < SA) {
+                const int i = (j << LG) + sub;
+                unsigned key = 0xFFFFFFFFu;
+                if (i < A) key = key32(pe[j].y, pe[j].w, t, oldk);
+                X.keyT[j * 64 + lane] = key;
+                X.valT[j * 64 + lane] = idleT_pack((unsigned)pe[j].x, (unsigned)meta_dest(pe[j].w));
+            }
+        }
+        for (int s8 = LN_PE(LG); s8 < SA; s8 += 8) {
+            int4 e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = ((s8 + j) << LG) + sub;
+                e[j] = make_int4(0, 0, 0, 0);
+                if (i < A) e[j] = ring[(size_t)i * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s = s8 + j;
+                if (s < SA) {
+                    const int i = (s << LG) + sub;
+                    unsigned key = 0xFFFFFFFFu;
+                    if (i < A) key = key32(e[j].y, e[j].w, t, oldk);
+                    X.keyT[s * 64 + lane] = key;
+                    X.valT[s * 64 + lane] = idleT_pack((unsigned)e[j].x, (unsigned)meta_dest(e[j].w));
+                }
+            }
+        }
+        lds_fence();
+        if (__ballot(oldk) == 0ull) {
+            for (int s0 = 0; s0 < SA; s0 += 4) {      // four own arrivals against every key of the bucket
+                unsigned ki[4];
+                int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) ki[a] = s0 + a < SA ? X.keyT[(s0 + a) * 64 + lane] : 0u;
+                for (int s2 = 0; s2 < SA; s2 += 4) {     // (slots beyond SA of this step hold ~0 from an earlier tick or garbage: masked)
+                    unsigned kk[4 * L];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int u = 0; u < L; ++u) kk[v * L + u] = s2 + v < SA ? X.keyT[(s2 + v) * 64 + gbase + u] : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int v = 0; v < 4 * L; ++v)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) rank[a] += kk[v] < ki[a] ? 1 : 0;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int s = s0 + a, i = (s << LG) + sub;
+                    if (s < SA && i < A) {
+                        const int pos = m + rank[a];
+                        const unsigned v = X.valT[s * 64 + lane];
+                        if (k > 0) entW[ent_word(pos >> LG, gbase + (pos & (L - 1)))] = v;
+                        else idl[idleT_elem(pos)] = v;
+                    }
+                }
+            }
+        } else {
+            // entries that came through the far tables may be older than the 32-bit key can tell: 64-bit keys from the ring
+            for (int s = 0; s < SA; ++s) {
+                const int i = (s << LG) + sub;
+                if (i < A) {
+                    const int4 e = ring[(size_t)i * 64];
+                    const unsigned long long key = entry_key(e.y, e.w);
+                    int rank = 0;
+                    for (int j = 0; j < A; ++j) {
+                        const int4 ej = ring[(size_t)j * 64];
+                        rank += entry_key(ej.y, ej.w) < key ? 1 : 0;
+                    }
+                    const int pos = m + rank;
+                    const unsigned v = idleT_pack((unsigned)e.x, (unsigned)meta_dest(e.w));
+                    if (k > 0) entW[ent_word(pos >> LG, gbase + (pos & (L - 1)))] = v;
+                    else idl[idleT_elem(pos)] = v;
+                }
+            }
+        }
+        lds_fence();
+        if (valid && sub == 0 && A > 0) D.ring_cnt[(size_t)slot * S.C * S.R + b] = 0;
+    }
+    LPROF(3);
+#ifdef VDS_PROF
+    if (k == 0 && lane == 0) { g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + 12] += 1u; g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + 14] = LG + 1; }
+#endif
+    if (k == 0) {
+        lanes_finish(S, D, b, t & 1, valid && sub == 0, h0, mnew, mnew, 0, h0.w, false, A, 0, 0, 0, 0);
+        return;
+    }
+
+    // ---- 3. MatchFunction :912-973 for the bucket's k orders (the same orders in every replica), in chunks of LN_RS * L
+    int navail = mnew;
+    long long evals = 0;
+    int wsum = 0, vsum = 0, rej = 0;
+    int firstdead = 0x7FFFFFFF;
+    unsigned *resT = X.keyT;
+    int2 *outp = D.out + (size_t)(valid ? r : 0);
+    const size_t Rpad = (size_t)S.G * 64;
+    unsigned res[LN_RS];
+    int pd[LN_RS];
+    int4 crec = make_int4(0, 0, 0, 0);
+    int j0 = 0, kc = 0;
+    for (;;) {
+        kc = min(k - j0, LN_RS * L);
+        crec = crec0;                     // (the first chunk's records came with the header)
+        if (j0 > 0) {
+            crec = make_int4(0, 0, 0, 0);
+            if (lane < kc) crec = S.so_rec[X.q0 + j0 + lane];
+        }
+        LPROF(4);
+        for (int jj = 0; jj < kc; ++jj) {
+            const int pick = __builtin_amdgcn_readlane(crec.y, jj) & 0xFFFF;
+            const unsigned char *row = X.blk + pick * X.nc1;
+            unsigned best = 0xFFFF0000u;            // (the low half stays free for `+ sub` below)
+            uint4 nx[4] = {X.entT[lane], X.entT[64 + lane], X.entT[128 + lane], X.entT[192 + lane]};
+            for (int gs = 0; gs < QS2; gs += 4) {
+                const uint4 cu[4] = {nx[0], nx[1], nx[2], nx[3]};
+                if (gs + 4 < QS2) {                 // next step's entries while this step's cost bytes are looked up
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) nx[g] = X.entT[(gs + 4 + g) * 64 + lane];
+                }
+                unsigned kk[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    kk[4 * g + 0] = (unsigned)row[cu[g].x & 0xFFu];
+                    kk[4 * g + 1] = (unsigned)row[cu[g].y & 0xFFu];
+                    kk[4 * g + 2] = (unsigned)row[cu[g].z & 0xFFu];
+                    kk[4 * g + 3] = (unsigned)row[cu[g].w & 0xFFu];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kk[i] = (kk[i] << 16) | (unsigned)(i << LG);
+                const unsigned m0 = min(min(min(kk[0], kk[1]), min(kk[2], kk[3])), min(min(kk[4], kk[5]), min(kk[6], kk[7])));
+                const unsigned m1 = min(min(min(kk[8], kk[9]), min(kk[10], kk[11])), min(min(kk[12], kk[13]), min(kk[14], kk[15])));
+                best = min(best, min(m0, m1) + (unsigned)((gs * 4) << LG));
+            }
+            best += (unsigned)sub;                          // list position of an own entry = slot * L + sub
+            best = grp_min_u32<LG>(best);
+            const bool hit = best < LN_HIT;
+            evals += navail;                                 // idle vehicles this order looked at (:928)
+            if (hit) {
+                const int wpos = (int)(best & 0xFFFFu);
+                navail--;
+                firstdead = min(firstdead, wpos);
+                if (sub == (wpos & (L - 1))) reinterpret_cast<unsigned char *>(entW + ent_word(wpos >> LG, lane))[0] = (unsigned char)sent;
+            }
+            if (sub == (jj & (L - 1))) resT[(jj >> LG) * 64 + lane] = best;
+        }
+        lds_fence();
+        LPROF(5);
+        // results of the chunk: lane `sub` of a bucket finishes orders jj = s * L + sub; all ring-slot atomics of the chunk
+        // are issued before any of their entry stores (the winners' vehicle ids come from LDS)
+        const int SR = (kc + L - 1) >> LG;
+#pragma unroll
+        for (int s = 0; s < LN_RS; ++s) {
+            res[s] = 0xFFFFFFFFu; pd[s] = -1;
+            if (s < SR) {
+                const int jj = (s << LG) + sub;
+                const int4 rec = chunk_rec<LG>(crec, jj, s);
+                if (valid && jj < kc) {
+                    const unsigned rv = resT[s * 64 + lane];
+                    const bool hit = rv < LN_HIT;
+                    const int wait = (int)(rv >> 16);
+                    int veh = -1;
+                    if (hit) {
+                        const int wpos = (int)(rv & 0xFFFFu);
+                        veh = (int)(entW[ent_word(wpos >> LG, gbase + (wpos & (L - 1)))] >> 8);
+                        wsum += wait; vsum += rec.w;
+                        pd[s] = post_begin(S, D, X, rec.z & 0xFFFF, veh, rec.x, (int)((unsigned)rec.y >> 16), wait + rec.w);
+                        res[s] = ((unsigned)veh << 8) | (unsigned)wait;
+                    } else {
+                        rej++;
+                    }
+                    outp[(size_t)(X.q0 + j0 + jj) * Rpad] = hit ? make_int2(veh, wait) : make_int2(-1, -1);
+                }
+            }
+        }
+        LPROF(6);
+        if (j0 + kc >= k) break;
+#pragma unroll
+        for (int s = 0; s < LN_RS; ++s) {
+            if (s < SR) {
+                const int jj = (s << LG) + sub;
+                const int4 rec = chunk_rec<LG>(crec, jj, s);          // (every lane takes part: the record comes from lane jj)
+                if (pd[s] >= 0) post_end(S, D, X, pd[s], rec.z & 0xFFFF, (int)(res[s] >> 8), rec.x, (int)((unsigned)rec.y >> 16), (int)(res[s] & 0xFFu) + rec.w);
+            }
+        }
+        lds_fence();          // the result slots are rewritten by the next chunk
+        j0 += kc;
+    }
+
+    // ---- 4. order-preserving removal of the matched vehicles (:963) in LDS, then the changed tail of the list goes back
+    //      to HBM; the atomics of the last chunk are in flight meanwhile
+    firstdead = grp_min_i32<LG>(firstdead);
+    const int fd = valid ? min(firstdead, mnew) : 0x7FFFFFFF;
+    {
+        const int qmin = (wave_min_i32(fd) >> LG) >> 2;
+        int wp = fd;                                         // next write position of the bucket
+        for (int q = qmin; 4 * q < SM; ++q) {                // four own slots per step: one 16-byte LDS read, up to four 4-byte writes
+            const uint4 vq = X.entT[q * 64 + lane];
+            const unsigned vv[4] = {vq.x, vq.y, vq.z, vq.w};
+            lds_fence();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = ((4 * q + u) << LG) + sub;
+                const bool alive = e >= fd && e < mnew && (vv[u] & 0xFFu) != sent;
+                if (LG == 0) {
+                    if (alive) { if (wp != e) entW[ent_word(wp, lane)] = vv[u]; wp++; }
+                } else {
+                    const unsigned mask = grp_or_u32<LG>(alive ? 1u << sub : 0u);
+                    if (alive) {
+                        const int dst = wp + __popc(mask & ((1u << sub) - 1u));
+                        if (dst != e) entW[ent_word(dst >> LG, gbase + (dst & (L - 1)))] = vv[u];
+                    }
+                    wp += __popc(mask);
+                }
+            }
+            lds_fence();
+        }
+    }
+    const int mfin = navail;
+    LPROF(7);
+    {
+        const int wb0 = valid ? min(fd, m) : 0x7FFFFFFF;    // first list position whose HBM copy is stale (or missing: arrivals)
+        const int mf = valid ? mfin : 0;
+        const int mfmax = wave_max_i32(mf);
+        if (LG == 0) {
+            const int g0 = wave_min_i32(wb0) >> 2;
+            for (int g = g0; 4 * g < mfmax; ++g)
+                if (4 * g + 3 >= wb0 && 4 * g < mf) *reinterpret_cast<uint4 *>(idl + (size_t)g * 256) = X.entT[g * 64 + lane];
+        } else {
+            const int s0 = wave_min_i32(wb0) >> LG;
+            for (int s = s0; (s << LG) < mfmax; ++s) {
+                const int e = (s << LG) + sub;
+                if (e >= wb0 && e < mf) idl[idleT_elem(e)] = entW[ent_word(s, lane)];
+            }
+        }
+    }
+    LPROF(8);
+    // ---- 5. the last chunk's entry stores, header, counters
+    {
+        const int SR = (kc + L - 1) >> LG;
+#pragma unroll
+        for (int s = 0; s < LN_RS; ++s) {
+            if (s < SR) {
+                const int jj = (s << LG) + sub;
+                const int4 rec = chunk_rec<LG>(crec, jj, s);          // (every lane takes part: the record comes from lane jj)
+                if (pd[s] >= 0) post_end(S, D, X, pd[s], rec.z & 0xFFFF, (int)(res[s] >> 8), rec.x, (int)((unsigned)rec.y >> 16), (int)(res[s] & 0xFFu) + rec.w);
+            }
+        }
+    }
+    wsum = grp_sum_i32<LG>(wsum); vsum = grp_sum_i32<LG>(vsum); rej = grp_sum_i32<LG>(rej);
+    lanes_finish(S, D, b, t & 1, valid && sub == 0, h0, mfin, mnew, k, h0.w, false, A, rej, wsum, vsum, evals);
+    LPROF(9);
+#ifdef VDS_PROF
+    if (lane == 0) { g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + 15] += 1u; g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + 14] = LG + 1; }
+#endif
+}
+
+// SLOW path: the same steps with every table in HBM / L2 - any list length, far arrivals, arrivals beyond the key table.
+// Nothing here is batched: it is the rare path.
+template <int LG>
+__device__ __forceinline__ void lanes_tick_slow(const Static &S, const State &D, const LaneCtx &X, int m, int A, int4 h0, int4 h1) {
     constexpr int L = 1 << LG;
     const int lane = lane_id();
     const int sub = lane & (L - 1);
@@ -131,11 +543,9 @@ __device__ __forceinline__ void lanes_tick(const Static &S, const State &D, cons
     unsigned *idl = reinterpret_cast<unsigned *>(D.idle) + idleT_base(S, c, valid ? r : 0);
     const int4 *ring = D.ring + ringT_base(S, slot, c, valid ? r : 0);
     const unsigned sent = (unsigned)X.nc;                 // loc byte of a taken / absent entry
-    const unsigned sent4 = sent * 0x01010101u;
     int newfl = h0.w;
     bool inbox_reset = false;
-
-    if (!FAST) {
+    {
         // ---- far arrivals (trips ending >= H ticks ahead, rare): those now near move into the ring, the rest stays (the
         //      lane-serial form of update_far in vds_kernels.hip)
         const int f = h0.w, qin = p ? h1.y : h1.x;
@@ -177,322 +587,155 @@ __device__ __forceinline__ void lanes_tick(const Static &S, const State &D, cons
         if (valid && A > S.ring_cap) A = S.ring_cap;            // (the overflow was flagged when it was posted)
     }
     int mnew = m + A;
-    if (!FAST && valid && mnew > S.idle_cap) {
+    if (valid && mnew > S.idle_cap) {
         if (sub == 0) atomicOr(&D.err[0], ERR_IDLE_CAP);
         mnew = S.idle_cap;
     }
     const int Amax = wave_max_i32(A);
     const int mmax = wave_max_i32(mnew);
     const int SM = (mmax + L - 1) >> LG;          // own entry slots in use (longest bucket of the wavefront)
-    const int QS = (SM + 3) >> 2;
 
-    // ---- 1. own loc bytes of the existing entries -> LDS (only when there are orders to match)
-    if (FAST && k > 0) {
-        for (int gs = 0; gs < QS; ++gs) {
-            unsigned locs = sent4;
-            if (LG == 0) {
-                if (4 * gs < m) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(idl + (size_t)gs * 256);
-                    const unsigned l0 = q.x & 0xFFu, l1 = 4 * gs + 1 < m ? q.y & 0xFFu : sent, l2 = 4 * gs + 2 < m ? q.z & 0xFFu : sent,
-                                   l3 = 4 * gs + 3 < m ? q.w & 0xFFu : sent;
-                    locs = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
-                }
-            } else if (LG == 1) {       // own slots 4gs..4gs+3 = entries 8gs + 2u + sub: elements sub, sub + 2 of quads 2gs, 2gs + 1
-                unsigned l[4] = {sent, sent, sent, sent};
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int g = 2 * gs + h;
-                    if (4 * g < m) {
-                        const uint4 q = *reinterpret_cast<const uint4 *>(idl + (size_t)g * 256);
-                        const unsigned a = sub ? q.y : q.x, bb = sub ? q.w : q.z;
-                        if (4 * g + sub < m) l[2 * h] = a & 0xFFu;
-                        if (4 * g + 2 + sub < m) l[2 * h + 1] = bb & 0xFFu;
-                    }
-                }
-                locs = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
-            } else {                    // own slot s = element sub of quad s
-                unsigned l[4] = {sent, sent, sent, sent};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = ((4 * gs + u) << LG) + sub;
-                    if (e < m) l[u] = idl[idleT_elem(e)] & 0xFFu;
-                }
-                locs = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
-            }
-            X.locT[gs * 64 + lane] = locs;
-        }
-        lds_fence();
-    }
-
-    // ---- 2. arrivals of this tick (UpdateFunction :1014-1024): rank by dict-insertion key, append behind the list
+    // ---- arrivals of this tick (UpdateFunction :1014-1024): rank by the 64-bit dict-insertion key, append behind the list
     if (Amax > 0) {
-        const int SA = (Amax + L - 1) >> LG;      // own arrival slots in use
-        bool oldk = false;
-        if (FAST) {
-            for (int s = 0; s < SA; ++s) {
-                const int i = (s << LG) + sub;
-                unsigned key = 0xFFFFFFFFu;
-                if (i < A) {
-                    const int4 e = ring[(size_t)i * 64];
-                    key = key32(e.y, e.w, t, oldk);
-                }
-                X.keyT[s * 64 + lane] = key;
-            }
-            lds_fence();
-        }
-        const bool rank32 = FAST && __ballot(oldk) == 0ull;
-        if (rank32) {
-            for (int s = 0; s < SA; ++s) {
-                const int i = (s << LG) + sub;
-                const unsigned ki = X.keyT[s * 64 + lane];
+        const int SA = (Amax + L - 1) >> LG;
+        for (int s = 0; s < SA; ++s) {
+            const int i = (s << LG) + sub;
+            if (i < A) {
+                const int4 e = ring[(size_t)i * 64];
+                const unsigned long long key = entry_key(e.y, e.w);
                 int rank = 0;
-                for (int s2 = 0; s2 < SA; ++s2) {
-#pragma unroll
-                    for (int u = 0; u < L; ++u) rank += X.keyT[s2 * 64 + gbase + u] < ki ? 1 : 0;
+                for (int j = 0; j < A; ++j) {
+                    const int4 ej = ring[(size_t)j * 64];
+                    rank += entry_key(ej.y, ej.w) < key ? 1 : 0;
                 }
-                if (i < A) {
-                    const int4 e = ring[(size_t)i * 64];
-                    const int pos = m + rank;
-                    const unsigned dest = (unsigned)meta_dest(e.w);
-                    idl[idleT_elem(pos)] = idleT_pack((unsigned)e.x, dest);
-                    if (k > 0) {
-                        const int so = pos >> LG, owner = gbase + (pos & (L - 1));
-                        reinterpret_cast<unsigned char *>(X.locT)[(((so >> 2) * 64 + owner) << 2) + (so & 3)] = (unsigned char)dest;
-                    }
-                }
+                const int pos = m + rank;
+                if (pos < S.idle_cap) idl[idleT_elem(pos)] = idleT_pack((unsigned)e.x, (unsigned)meta_dest(e.w));
             }
-            lds_fence();
-        } else {
-            for (int s = 0; s < SA; ++s) {
-                const int i = (s << LG) + sub;
-                if (i < A) {
-                    const int4 e = ring[(size_t)i * 64];
-                    const unsigned long long key = entry_key(e.y, e.w);
-                    int rank = 0;
-                    for (int j = 0; j < A; ++j) {
-                        const int4 ej = ring[(size_t)j * 64];
-                        rank += entry_key(ej.y, ej.w) < key ? 1 : 0;
-                    }
-                    const int pos = m + rank;
-                    const unsigned dest = (unsigned)meta_dest(e.w);
-                    if (pos < S.idle_cap) idl[idleT_elem(pos)] = idleT_pack((unsigned)e.x, dest);
-                    if (FAST && k > 0) {
-                        const int so = pos >> LG, owner = gbase + (pos & (L - 1));
-                        reinterpret_cast<unsigned char *>(X.locT)[(((so >> 2) * 64 + owner) << 2) + (so & 3)] = (unsigned char)dest;
-                    }
-                }
-            }
-            if (FAST) lds_fence();
         }
         if (valid && sub == 0 && A > 0) D.ring_cnt[(size_t)slot * S.C * S.R + b] = 0;
     }
-
-    long long *cnt = D.cnt + b * CNT_WORDS;
     if (k == 0) {
-        // no order in this (tick, cluster) bucket: the arrivals were appended, the list is not read
-        if (valid && sub == 0) {
-            if (h0.x != mnew || h0.y != mnew || h0.z != 0 || h0.w != newfl) *reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS) = make_int4(mnew, mnew, 0, newfl);
-            if (inbox_reset) D.hdr[b * HDR_WORDS + HDR_INBOX0 + p] = 0;
-            if (A > 0) atomicAdd(reinterpret_cast<unsigned long long *>(cnt + CNT_ARRIVALS), (unsigned long long)A);
-        }
+        lanes_finish(S, D, b, p, valid && sub == 0, h0, mnew, mnew, 0, newfl, inbox_reset, A, 0, 0, 0, 0);
         return;
     }
-
-    // ---- 3. MatchFunction :912-973 for the bucket's k orders (the same orders in every replica), in chunks of LN_RS * L
-    mem_fence();                  // the appended entries are read back below (winner's vehicle id, slow path: loc bytes)
+    mem_fence();
     int navail = mnew;
     long long evals = 0;
     int wsum = 0, vsum = 0, rej = 0;
     int firstdead = 0x7FFFFFFF;
     int2 *outp = D.out + (size_t)(valid ? r : 0);
     const size_t Rpad = (size_t)S.G * 64;
-    unsigned *resT = X.keyT;
-    for (int j0 = 0; j0 < k; j0 += LN_RS * L) {
-        const int kc = min(k - j0, LN_RS * L);
+    for (int j0 = 0; j0 < k; j0 += WAVE) {
+        const int kc = min(k - j0, WAVE);
+        int4 crec = make_int4(0, 0, 0, 0);
+        if (lane < kc) crec = S.so_rec[X.q0 + j0 + lane];
         for (int jj = 0; jj < kc; ++jj) {
-            const int4 rec = S.so_rec[X.q0 + j0 + jj];
+            const int4 rec = make_int4(__builtin_amdgcn_readlane(crec.x, jj), __builtin_amdgcn_readlane(crec.y, jj), __builtin_amdgcn_readlane(crec.z, jj), __builtin_amdgcn_readlane(crec.w, jj));
             const unsigned char *row = X.blk + (rec.y & 0xFFFF) * X.nc1;
-            unsigned best = 0xFFFF0000u;            // (the low half stays free for `+ sub` below)
-            for (int gs = 0; gs < QS; ++gs) {
-                unsigned locs;
-                if (FAST) {
-                    locs = X.locT[gs * 64 + lane];
-                } else {
-                    unsigned l[4] = {sent, sent, sent, sent};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = ((4 * gs + u) << LG) + sub;
-                        if (e < mnew) l[u] = idl[idleT_elem(e)] & 0xFFu;
-                    }
-                    locs = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
-                }
-                const unsigned pos0 = (unsigned)((4 * gs) << LG);
-                const unsigned k0 = ((unsigned)row[locs & 0xFFu] << 16) | pos0;
-                const unsigned k1 = ((unsigned)row[(locs >> 8) & 0xFFu] << 16) | (pos0 + L);
-                const unsigned k2 = ((unsigned)row[(locs >> 16) & 0xFFu] << 16) | (pos0 + 2 * L);
-                const unsigned k3 = ((unsigned)row[locs >> 24] << 16) | (pos0 + 3 * L);
-                best = min(min(best, k0), min(k1, min(k2, k3)));
+            unsigned best = 0xFFFF0000u;
+            for (int s = 0; s < SM; ++s) {
+                const int e = (s << LG) + sub;
+                unsigned lb = sent;
+                if (e < mnew) lb = idl[idleT_elem(e)] & 0xFFu;
+                best = min(best, ((unsigned)row[lb] << 16) | (unsigned)e);
             }
-            best += (unsigned)sub;                          // list position of an own entry = slot * L + sub
             best = grp_min_u32<LG>(best);
             const bool hit = best < LN_HIT;
-            evals += navail;                                 // idle vehicles this order looked at (:928)
+            evals += navail;
+            const int wpos = (int)(best & 0xFFFFu), wait = (int)(best >> 16);
+            int veh = -1;
             if (hit) {
-                const int wpos = (int)(best & 0xFFFFu);
                 navail--;
                 firstdead = min(firstdead, wpos);
-                if (sub == (wpos & (L - 1))) {
-                    const int so = wpos >> LG;
-                    if (FAST) reinterpret_cast<unsigned char *>(X.locT)[(((so >> 2) * 64 + lane) << 2) + (so & 3)] = (unsigned char)sent;
-                    else reinterpret_cast<unsigned char *>(idl + idleT_elem(wpos))[0] = (unsigned char)sent;
-                }
+                if (valid) veh = (int)(idl[idleT_elem(wpos)] >> 8);
+                if (sub == (wpos & (L - 1))) reinterpret_cast<unsigned char *>(idl + idleT_elem(wpos))[0] = (unsigned char)sent;
             }
-            if (sub == (jj & (L - 1))) resT[(jj >> LG) * 64 + lane] = best;
-            if (FAST) lds_fence(); else mem_fence();
-        }
-        // results of the chunk: lane `sub` of a bucket finishes orders jj = s * L + sub.  Three passes so that the
-        // vehicle-id gathers, the ring-slot atomics and the entry stores of up to LN_RS orders are in flight together.
-        lds_fence();
-        const int SR = (kc + L - 1) >> LG;
-        unsigned res[LN_RS], ent[LN_RS];
-        int old[LN_RS];
-#pragma unroll
-        for (int s = 0; s < LN_RS; ++s) {
-            res[s] = 0xFFFFFFFFu; ent[s] = 0u; old[s] = -1;
-            if (s < SR) {
-                const int jj = (s << LG) + sub;
-                res[s] = resT[s * 64 + lane];
-                if (!(valid && jj < kc)) res[s] = 0xFFFFFFFFu;
-                if (res[s] < LN_HIT) ent[s] = idl[idleT_elem((int)(res[s] & 0xFFFFu))];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < LN_RS; ++s) {
-            if (s < SR) {
-                const int jj = (s << LG) + sub;
-                if (valid && jj < kc) {
-                    const int j = j0 + jj;
-                    const int4 rec = S.so_rec[X.q0 + j];
-                    const bool hit = res[s] < LN_HIT;
-                    const int veh = (int)(ent[s] >> 8), wait = (int)(res[s] >> 16);
-                    outp[(size_t)(X.q0 + j) * Rpad] = hit ? make_int2(veh, wait) : make_int2(-1, -1);
-                    if (hit) {
-                        // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery); the next Update is at t + 1 at the earliest
-                        const int rel = wait + rec.w;
-                        const int d = rel <= 0 ? 1 : ticks_until_small(S, rel);
-                        wsum += wait; vsum += rec.w;
-                        const int dc = rec.z & 0xFFFF;
-                        if (d < S.H) {
-                            const size_t i = ((size_t)((t + d) & (S.H - 1)) * S.C + dc) * S.R + r;
-                            old[s] = atomicAdd(&D.ring_cnt[i], 0x10001);            // high half: carries an order (:889)
-                        } else {
-                            const size_t db = (size_t)dc * S.R + r;
-                            const int np = (t + 1) & 1;
-                            const int sl = atomicAdd(&D.hdr[db * HDR_WORDS + HDR_INBOX0 + np], 1);
-                            if (sl < S.in_cap) D.inbox[((size_t)np * S.C * S.R + db) * S.in_cap + sl] = make_int4(veh, rec.x, X.now + rel, meta_pack(t, 0, (int)((unsigned)rec.y >> 16)));
-                            else atomicOr(&D.err[0], ERR_INBOX_CAP);
-                        }
-                    } else {
-                        rej++;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < LN_RS; ++s) {
-            if (s < SR && old[s] >= 0) {
-                const int j = j0 + (s << LG) + sub;
-                const int4 rec = S.so_rec[X.q0 + j];
-                const int veh = (int)(ent[s] >> 8), wait = (int)(res[s] >> 16);
-                const int rel = wait + rec.w;
-                const int d = rel <= 0 ? 1 : ticks_until_small(S, rel);
-                const int pos = old[s] & 0xFFFF;
-                if (pos < S.ring_cap) D.ring[ringT_base(S, (t + d) & (S.H - 1), rec.z & 0xFFFF, r) + (size_t)pos * 64] = make_int4(veh, rec.x, X.now + rel, meta_pack(t, 0, (int)((unsigned)rec.y >> 16)));
-                else atomicOr(&D.err[0], ERR_RING_CAP);
-            }
-        }
-        lds_fence();          // the result slots are rewritten by the next chunk
-    }
-
-    // ---- 4. order-preserving removal of the matched vehicles (:963): the survivors from the first taken position on move up.
-    //      A quad of four consecutive entries per step; bit u of `mask` = entry 4g + u survives.
-    firstdead = grp_min_i32<LG>(firstdead);                  // (the same in the bucket's lanes already; cheap)
-    const int fd = valid ? min(firstdead, mnew) : 0x7FFFFFFF;
-    const int gmin = wave_min_i32(fd) >> 2;
-    int wp = fd;                                             // next write position of the bucket
-    for (int g = gmin; 4 * g < mmax; ++g) {
-        uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        if (valid && 4 * g < mnew) q = *reinterpret_cast<const uint4 *>(idl + (size_t)g * 256);
-        unsigned own = 0u;                                   // alive bits of the quad's entries this lane owns
-        const unsigned qv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = 4 * g + u;
-            if ((u & (L - 1)) == sub || L == 1) {
-                bool alive;
-                if (FAST) {
-                    const int so = e >> LG;
-                    alive = reinterpret_cast<const unsigned char *>(X.locT)[(((so >> 2) * 64 + lane) << 2) + (so & 3)] != (unsigned char)sent;
+            if (valid && sub == 0) {          // lane 0 of the bucket finishes the order
+                outp[(size_t)(X.q0 + j0 + jj) * Rpad] = hit ? make_int2(veh, wait) : make_int2(-1, -1);
+                if (hit) {
+                    wsum += wait; vsum += rec.w;
+                    const int pd = post_begin(S, D, X, rec.z & 0xFFFF, veh, rec.x, (int)((unsigned)rec.y >> 16), wait + rec.w);
+                    if (pd >= 0) post_end(S, D, X, pd, rec.z & 0xFFFF, veh, rec.x, (int)((unsigned)rec.y >> 16), wait + rec.w);
                 } else {
-                    alive = (qv[u] & 0xFFu) != sent;
+                    rej++;
                 }
-                if (alive && e >= fd && e < mnew) own |= 1u << u;
             }
+            mem_fence();
         }
-        const unsigned mask = grp_or_u32<LG>(own);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if ((own >> u) & 1u) {
-                const int dst = wp + __popc(mask & ((1u << u) - 1u));
-                if (dst != 4 * g + u) idl[idleT_elem(dst)] = qv[u];
-            }
+    }
+    // ---- order-preserving removal (:963), in place in HBM: the survivors from the first taken position on move up
+    firstdead = grp_min_i32<LG>(firstdead);
+    const int fd = valid ? min(firstdead, mnew) : 0x7FFFFFFF;
+    const int smin = wave_min_i32(fd) >> LG;
+    int wp = fd;
+    for (int s = smin; s < SM; ++s) {
+        const int e = (s << LG) + sub;
+        unsigned v = sent;
+        if (valid && e < mnew) v = idl[idleT_elem(e)];
+        const bool alive = e >= fd && e < mnew && (v & 0xFFu) != sent;
+        const unsigned mask = grp_or_u32<LG>(alive ? 1u << sub : 0u);
+        mem_fence();
+        if (alive) {
+            const int dst = wp + __popc(mask & ((1u << sub) - 1u));
+            if (dst != e) idl[idleT_elem(dst)] = v;
         }
         wp += __popc(mask);
     }
-    const int mfin = navail;
-
-    // ---- 5. header, counters
-    wsum = grp_sum_i32<LG>(wsum); vsum = grp_sum_i32<LG>(vsum); rej = grp_sum_i32<LG>(rej);
-    if (valid && sub == 0) {
-        *reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS) = make_int4(mfin, mnew, k, newfl);
-        if (inbox_reset) D.hdr[b * HDR_WORDS + HDR_INBOX0 + p] = 0;
-        unsigned long long *cu = reinterpret_cast<unsigned long long *>(cnt);
-        atomicAdd(cu + CNT_ORDERS, (unsigned long long)k);
-        if (rej) atomicAdd(cu + CNT_REJECTS, (unsigned long long)rej);
-        if (wsum) atomicAdd(cu + CNT_WAIT, (unsigned long long)wsum);
-        if (vsum) atomicAdd(cu + CNT_VALUE, (unsigned long long)vsum);
-        if (evals) atomicAdd(cu + CNT_EVALS, (unsigned long long)evals);
-        if (A > 0) atomicAdd(cu + CNT_ARRIVALS, (unsigned long long)A);
-    }
+    lanes_finish(S, D, b, p, valid && sub == 0, h0, navail, mnew, k, newfl, inbox_reset, A, rej, wsum, vsum, evals);
 }
 
 template <int LG>
 __device__ __forceinline__ void lanes_wave(const Static &S, const State &D, int t, int4 cd, int wi, unsigned *lds, int lds_blk_off) {
     constexpr int L = 1 << LG;
     const int lane = lane_id();
+    LPROF_DECL;
     const int per = 64 >> LG;                     // replicas (buckets) per wavefront
     const int grp = wi >> LG, part = wi & (L - 1);
     LaneCtx X;
     X.c = cd.z; X.nc = cd.x & 0xFFFF; X.nc1 = cd.w;
     X.t = t; X.now = S.now0 + t * S.tick_minutes;
-    X.q0 = S.bkt_off[(size_t)t * S.C + X.c];
-    X.k = S.bkt_off[(size_t)t * S.C + X.c + 1] - X.q0;
+    X.q0 = __builtin_amdgcn_readfirstlane(S.bkt_off[(size_t)t * S.C + X.c]);
+    X.k = __builtin_amdgcn_readfirstlane(S.bkt_off[(size_t)t * S.C + X.c + 1]) - X.q0;
     X.col = part * per + (lane >> LG);
     X.r = grp * 64 + X.col;
     X.valid = X.r < S.R;
-    X.loc_q = S.lane_loc_slots >> 2; X.key_slots = S.lane_key_slots;
-    X.locT = lds;
-    X.keyT = lds + X.loc_q * 64;
+    LPROF(0);
+    X.ent_q = S.lane_loc_slots >> 2; X.key_slots = S.lane_key_slots;
+    X.entT = reinterpret_cast<uint4 *>(lds);
+    X.keyT = lds + X.ent_q * 256;
+    X.valT = X.keyT + X.key_slots * 64;
     unsigned char *blk = reinterpret_cast<unsigned char *>(lds) + lds_blk_off;
     X.blk = blk;
-    // bucket header, arrival count of the slot that is due
-    const size_t b = (size_t)X.c * S.R + (X.valid ? X.r : 0);
+    // bucket header, arrival count of the slot that is due; together with them - before list length and arrival count
+    // are known - the first eight quads of the idle list and the lane's first eight own ring entries
+    const int rc = X.valid ? X.r : 0;
+    const size_t b = (size_t)X.c * S.R + rc;
     int4 h0 = make_int4(0, 0, 0, 0), h1 = h0;
     int A = 0;
     if (X.valid) {
         const int4 *h4 = reinterpret_cast<const int4 *>(D.hdr + b * HDR_WORDS);
         h0 = h4[0]; h1 = h4[1];
         A = D.ring_cnt[(size_t)(t & (S.H - 1)) * S.C * S.R + b] & 0xFFFF;
+    }
+    uint4 pq[LN_PQ];
+    int4 pe[LN_PE(LG)];
+    int4 crec0 = make_int4(0, 0, 0, 0);
+    if (lane < min(X.k, LN_RS * L)) crec0 = S.so_rec[X.q0 + lane];
+    const bool pre_ok = S.idle_cap >= (4 * LN_PQ << LG) && S.ring_cap >= (LN_PE(LG) << LG);
+    {
+        const unsigned *idl = reinterpret_cast<const unsigned *>(D.idle) + idleT_base(S, X.c, rc);
+        const int4 *ring = D.ring + ringT_base(S, t & (S.H - 1), X.c, rc);
+        const int sub = lane & (L - 1);
+#pragma unroll
+        for (int i = 0; i < LN_PQ; ++i) {
+            pq[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (pre_ok && X.k > 0) pq[i] = load_own_quad_raw<LG>(idl, i, sub);
+        }
+#pragma unroll
+        for (int j = 0; j < LN_PE(LG); ++j) {
+            pe[j] = make_int4(0, 0, 0, 0);
+            if (pre_ok) pe[j] = ring[(size_t)((j << LG) + sub) * 64];
+        }
     }
     // the cluster's cost block -> LDS (16-byte pieces; the host pads every block to 16 bytes)
     if (X.k > 0) {
@@ -502,28 +745,40 @@ __device__ __forceinline__ void lanes_wave(const Static &S, const State &D, int 
         for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
         lds_fence();
     }
+    LPROF(1);
     const int m = h0.x;
     const int far = h0.w | ((t & 1) ? h1.y : h1.x);
     const bool slow_lane = X.valid && (far != 0 || A > X.key_slots * L || m + A > S.lane_loc_slots * L || A > S.ring_cap || m + A > S.idle_cap);
-    const bool slow = S.lane_force_slow != 0 || __ballot(slow_lane) != 0ull;
-    if (!slow) lanes_tick<LG, true>(S, D, X, m, A, h0, h1);
-    else lanes_tick<LG, false>(S, D, X, m, A, h0, h1);
+    const bool slow = S.lane_force_slow != 0 || __ballot(slow_lane) != 0ull || !pre_ok;
+    if (!slow) lanes_tick_fast<LG>(S, D, X, m, A, h0, pq, pe, crec0);
+    else {
+        lanes_tick_slow<LG>(S, D, X, m, A, h0, h1);
+        LPROF(11);
+#ifdef VDS_PROF
+        if (lane == 0) { g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + 13] += 1u; g_lanes_prof[(blockIdx.x & (LN_PROF_WAVES - 1)) * LN_PROF_SLOTS + 14] = LG + 1; }
+#endif
+    }
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(WAVE) void k_tick_lanes(Static S, State D, int t, int lds_blk_off) {
+#ifndef LANES_MIN_WAVES
+#define LANES_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(WAVE, LANES_MIN_WAVES) void k_tick_lanes(Static S, State D, int t, int lds_blk_off) {
     extern __shared__ unsigned lds_dyn_lanes[];
     const int2 bw = S.lane_blocks[blockIdx.x];
     const int4 cd = S.cdesc_lanes[bw.x];
     const int lg = __builtin_amdgcn_readfirstlane(cd.x >> 16);
     if (lg == 0) lanes_wave<0>(S, D, t, cd, bw.y, lds_dyn_lanes, lds_blk_off);
     else if (lg == 1) lanes_wave<1>(S, D, t, cd, bw.y, lds_dyn_lanes, lds_blk_off);
-    else lanes_wave<2>(S, D, t, cd, bw.y, lds_dyn_lanes, lds_blk_off);
+    else if (lg == 2) lanes_wave<2>(S, D, t, cd, bw.y, lds_dyn_lanes, lds_blk_off);
+    else lanes_wave<3>(S, D, t, cd, bw.y, lds_dyn_lanes, lds_blk_off);
 }
 
 size_t lanes_lds_bytes(const Static &S, int *blk_off) {
-    const size_t tables = ((size_t)(S.lane_loc_slots >> 2) + (size_t)S.lane_key_slots) * 64 * 4;
+    // own idle entries (4 bytes each) | arrival keys (later: order results) | arrival payloads | cost block
+    const size_t tables = ((size_t)S.lane_loc_slots + 2 * (size_t)S.lane_key_slots) * 64 * 4;
     *blk_off = (int)tables;
     return tables + (((size_t)S.max_nc * (S.max_nc + 1) + 15) / 16) * 16;
 }
@@ -534,6 +789,24 @@ int lanes_prepare(const Static &S) {       // opt in to more than 64 KB of dynam
     if (need <= 64 * 1024) return 0;
     if (need > 160 * 1024 - 1024) return -1;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tick_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) == hipSuccess ? 0 : -1;
+}
+
+void lanes_read_prof(unsigned long long *out64, hipStream_t st) {       // instrumented build only: [4][16] section sums, then cleared
+    (void)hipStreamSynchronize(st);
+    for (int i = 0; i < 64; ++i) out64[i] = 0;
+#ifdef VDS_PROF
+    static unsigned host[LN_PROF_WAVES * LN_PROF_SLOTS];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lanes_prof), sizeof(host));
+    for (int w = 0; w < LN_PROF_WAVES; ++w) {
+        const unsigned *row = host + (size_t)w * LN_PROF_SLOTS;
+        if (!row[14]) continue;
+        const int lg = (int)row[14] - 1;
+        for (int i = 0; i < 14; ++i) out64[lg * LN_PROF_SLOTS + i] += row[i];
+        out64[lg * LN_PROF_SLOTS + 15] += row[15];
+    }
+    memset(host, 0, sizeof(host));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lanes_prof), host, sizeof(host));
+#endif
 }
 
 void launch_tick_lanes(const Static &S, const State &D, int t, hipStream_t st) {
