@@ -11,9 +11,10 @@ HBM.  Replicas shard across GPUs with no data-path collective (weak scaling: R p
 fixed); the only collective is an RCCL all-reduce of the int64[8] aggregate counters per day.
 
 The one JSON line printed by rank 0 also carries
-  roofline      dominant kernel: bytes its data layout moves through HBM per launch / average launch
-                duration (HIP events on the kernel's stream) vs 8 TB/s HBM; next to it the PMC-measured traffic,
-                SURVEY.md 8(d)'s accounting bytes, and the limiter the counters name (VALU issue);
+  roofline      dominant kernel: HBM bytes per launch (rocprofv3 PMC figure of the SAME build, profiles/traffic.json; else
+                the bytes the data layout has to move, and the line says which) / average launch duration (one HIP event
+                pair on the kernel's stream around a whole day / launches) vs 8 TB/s HBM; next to it SURVEY.md 8(d)'s
+                accounting bytes and the limiter the counters name;
   cpu_baseline  the CPU oracle (a C port of the reference algorithm, 1 thread) timed on this
                 host on a bounded sample of the same workload;
   cpu_baseline_all_cores  the same oracle as one independent single-replica process per host core.
@@ -185,12 +186,24 @@ def main():
     #      entries the kernel loaded: sum of PerMatchIdleVehicles over the (replica, cluster) buckets that had orders.
     roofline = None
     work = env.work()         # work of the last day on this rank
+    build_id = (env._lib.vds_build_id() or b"").decode()
     if rank == 0:
         env.reset_again()
         env.profile(True)
-        env.run(T)                                 # timing pass: nothing but the tick kernels on the stream
+        env.run(T)                                 # per-launch pass: HIP event pairs around every launch of the dominant kernel
         ms = env.profile_read(cap=T + 8)
         env.profile(False)
+        # whole-day pass: ONE event pair on the kernel's stream around the T launches (the hipGraph vds_run replays), nothing
+        # else on the stream in between; / launches = average launch duration incl. the kernel boundary, so that
+        # avg_launch_ms x launches <= ms_per_step by construction (event pairs per launch add their own record overhead)
+        env.reset_again()
+        env.run(T); env.reset_again()              # (graph captured / warm)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        env.run(T)
+        ev1.record(stream)
+        ev1.synchronize()
+        day_ms = ev0.elapsed_time(ev1)
         env.reset_again()                          # counting pass (untimed): the same day, observed slot by slot
         idle_loaded = torch.zeros((), dtype=torch.int64, device="cuda")
         busy_buckets = torch.zeros((), dtype=torch.int64, device="cuda")
@@ -203,35 +216,44 @@ def main():
             env.advance()
         if ms.size:
             kern = env.main_kernel()
-            avg_s = float(ms.mean()) * 1e-3
-            alg_bytes = workloads.algorithmic_bytes(work, w.vehicles) / ms.size
+            launches = int(ms.size)
+            avg_s = day_ms * 1e-3 / launches
+            alg_bytes = workloads.algorithmic_bytes(work, w.vehicles) / launches
             lay_bytes = workloads.layout_bytes(work, replicas=R, clusters=env.C, idle_loaded=int(idle_loaded.item()),
-                                               busy_buckets=int(busy_buckets.item())) / ms.size
+                                               busy_buckets=int(busy_buckets.item())) / launches
             side = workloads.profile_side_data(ROOT, a.workload, R, kern)
             traffic = side.get("hbm_bytes_per_launch")
-            roofline = {"bound": "hbm", "kernel": kern,
-                        # bytes this DATA LAYOUT has to move through HBM per launch (headers, counters,
-                        # 8 B idle entries, 16 B arrival entries, 8 B results; costs come from LDS) / launch time
-                        "achieved": lay_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": lay_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
-                        "layout_bytes_per_launch": lay_bytes,
-                        "traffic": traffic,
+            traffic_build = side.get("traffic_build")
+            same_build = traffic is not None and traffic_build == build_id
+            # frac: HBM bytes per launch / average launch duration / 8 TB/s.  The bytes are the rocprofv3 PMC figure
+            # (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes) when it was measured on THIS build
+            # (vds_build_id); otherwise the bytes the data layout has to move - a lower bound - and the line says so
+            basis_bytes = traffic if same_build else lay_bytes
+            roofline = {"bound": "hbm", "kernel": kern, "build": build_id,
+                        "achieved": basis_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": basis_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                        "frac_basis": "pmc-traffic (profiles/traffic.json, same build)" if same_build else "layout-bytes (no PMC figure for this build)",
+                        "traffic": traffic, "traffic_build": traffic_build, "traffic_build_matches": bool(same_build),
                         "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                        "layout_bytes_per_launch": lay_bytes, "layout_frac": lay_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
                         # SURVEY 8(d)'s accounting unit (16 B per evaluation as if cost / location / idle entry came
                         # from HBM every time): NOT a lower bound for this layout, quoted for comparability only
                         "algorithmic_bytes_per_launch": alg_bytes,
                         "algorithmic_gbs": alg_bytes / avg_s / 1e9,
-                        "avg_launch_ms": float(ms.mean()), "launches": int(ms.size),
-                        "match_evals_per_s": work["evals"] / (float(ms.sum()) * 1e-3)}
+                        "avg_launch_ms": avg_s * 1e3, "launches": launches, "day_kernel_ms": day_ms,
+                        "event_pair_avg_launch_ms": float(ms.mean()),
+                        "match_evals_per_s": work["evals"] / (day_ms * 1e-3)}
             lim = side.get("limiter")
             if lim:
-                # what the counters say bounds the kernel: VALU issue.  floor = wave-instructions x cycles each
+                # what the counters say bounds the kernel: floor = VALU wave-instructions x cycles each
                 # (profiles/ubench) / (SIMDs x clock); frac = floor / measured launch time
                 floor_s = lim["valu_insts_per_launch"] * lim["cycles_per_valu_inst"] / (lim["simds"] * lim["clock_hz"])
-                roofline["limiter"] = {"kind": "valu-issue", "floor_ms": floor_s * 1e3, "frac": floor_s / avg_s,
+                roofline["limiter"] = {"kind": "valu-issue + dependent-load latency (wavefronts wait %.0f %% of their cycles)" % (100 * (lim.get("wave_wait_frac") or 0)),
+                                       "valu_floor_ms": floor_s * 1e3, "valu_frac": floor_s / avg_s,
                                        "valu_insts_per_launch": lim["valu_insts_per_launch"],
                                        "cycles_per_valu_inst": lim["cycles_per_valu_inst"],
-                                       "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source")}
+                                       "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source"),
+                                       "build": lim.get("build"), "build_matches": lim.get("build") == build_id}
 
     # ---- per-replica order days (rank 0, N = 1): the headline replays ONE day in every replica, which lets 16 replicas
     #      share staged order records and keeps per-order control flow wave-uniform.  The same workload with D distinct
@@ -316,7 +338,7 @@ def main():
                        "parallelism": "replica-sharded x%d, RCCL all-reduce of int64[8] metrics per day" % world},
             "match_evals_per_s": float(work["evals"]) * world * a.steps / elapsed if work["evals"] else None,
             "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "build": build_id,
         }
         if dist is not None:
             out["collective"] = {"backend": dist.get_backend(), "world_size": world, "allreduce_calls": vdist.ALLREDUCE_CALLS,

@@ -99,6 +99,12 @@ struct vds_handle {
     size_t actions_cap = 0;
     int *d_selftest = nullptr;
     bool profiling = false;
+    // vds_run as one hipGraph: the launches of ticks [run_t0, run_t0 + run_n) captured once, replayed while nothing they
+    // depend on (tables, capacities, stream) has changed
+    hipGraphExec_t run_exec = nullptr;
+    int run_t0 = -1, run_n = 0;
+    hipStream_t run_stream = nullptr;
+    int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
 };
@@ -158,11 +164,31 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
 #define LANES_AUTO_MIN_R (1 << 30)
 #endif
 
+static void drop_run_graph(vds_handle *h) {
+    if (h->run_exec) { (void)hipGraphExecDestroy(h->run_exec); h->run_exec = nullptr; }
+    h->run_t0 = -1; h->run_n = 0;
+}
+
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" {
 
 int32_t vds_version(void) { return (1 << 16) | 0; }
+
+#ifndef VDS_SRC_HASH
+#define VDS_SRC_HASH "unknown"
+#endif
+const char *vds_build_id(void) {
+#ifdef VDS_PROF
+    return "src:" VDS_SRC_HASH "+prof";
+#elif defined(WKDEBUG)
+    return "src:" VDS_SRC_HASH "+dbg";
+#elif defined(VDS_CANARY)
+    return "src:" VDS_SRC_HASH "+canary";
+#else
+    return "src:" VDS_SRC_HASH;
+#endif
+}
 
 // MT19937 exactly as CPython's _random module drives it
 namespace {
@@ -275,12 +301,14 @@ int vds_destroy(vds_handle *h) {
     for (void *p : h->state_allocs) (void)hipFree(p);
     for (void *p : h->idle_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    drop_run_graph(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return VDS_OK;
 }
 
 int vds_set_stream(vds_handle *h, void *hip_stream) {
+    if (h) drop_run_graph(h);
     if (!h) return VDS_EINVAL;
     (void)hipStreamSynchronize(h->stream);
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
@@ -604,6 +632,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (void *p : h->order_allocs) (void)hipFree(p);
         h->order_allocs.clear();
+        drop_run_graph(h);
         h->have_orders = false; h->have_reset = false;
         h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
         h->err.clear();
@@ -923,6 +952,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     if (cap < 1) return fail(h, VDS_EINVAL, "vds_set_idle_cap: bad capacity %d", cap);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_run_graph(h);
     cap = std::min(round_up(cap, 64), round_up(std::max(h->S.V, 1), 64));
     if (cap > (1 << 24)) return fail(h, VDS_EINVAL, "vds_set_idle_cap: %d > 2^24 unsupported", cap);
     if (cap == h->S.idle_cap) return VDS_OK;
@@ -1065,13 +1095,46 @@ int vds_advance(vds_handle *h) {
     return VDS_OK;
 }
 
-int vds_run(vds_handle *h, int32_t n_ticks) {
+static int run_eager(vds_handle *h, int32_t n_ticks) {
     for (int i = 0; i < n_ticks; ++i) {
         int rc = vds_step(h);
         if (rc) return rc;
         rc = vds_advance(h);
         if (rc) return rc;
     }
+    return VDS_OK;
+}
+
+// SimCity's loop without hooks (:1048-1091) for n_ticks slots.  Runs of 8 slots and more are captured once as a hipGraph
+// (stream capture of the very launches vds_step issues) and replayed afterwards: one submission per day instead of 148 / 296.
+// VDS_RUN_GRAPH=0 keeps the eager loop.
+int vds_run(vds_handle *h, int32_t n_ticks) {
+    if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_run: call vds_reset first");
+    if (h->use_graph < 0) { const char *v = getenv("VDS_RUN_GRAPH"); h->use_graph = (v && *v == '0') ? 0 : 1; }
+    if (!h->use_graph || h->profiling || n_ticks < 8 || h->last_stepped == h->t || h->t + n_ticks > h->S.T) return run_eager(h, n_ticks);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!(h->run_exec && h->run_t0 == h->t && h->run_n == n_ticks && h->run_stream == h->stream)) {
+        drop_run_graph(h);
+        const int t0 = h->t, ls0 = h->last_stepped;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return run_eager(h, n_ticks); }
+        const int rc = run_eager(h, n_ticks);
+        const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+        h->t = t0; h->last_stepped = ls0;                       // nothing has run yet
+        if (rc || ec != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            if (rc) return rc;
+            return run_eager(h, n_ticks);
+        }
+        const hipError_t ei = hipGraphInstantiate(&h->run_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { h->run_exec = nullptr; (void)hipGetLastError(); return run_eager(h, n_ticks); }
+        h->run_t0 = t0; h->run_n = n_ticks; h->run_stream = h->stream;
+    }
+    HIPCHK(h, hipGraphLaunch(h->run_exec, h->stream));
+    h->t += n_ticks;
+    h->last_stepped = h->t - 1;
     return VDS_OK;
 }
 

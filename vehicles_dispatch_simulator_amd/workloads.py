@@ -158,6 +158,7 @@ def profile_side_data(root: str, workload: str, replicas: int, kernel: str) -> d
                 if e.get("workload") == workload and e.get("replicas") == replicas and e.get("kernel") == kernel:
                     if key is None:
                         out["hbm_bytes_per_launch"] = e.get("hbm_bytes_per_launch")
+                        out["traffic_build"] = e.get("build")
                     else:
                         out[key] = e
         except Exception:
