@@ -304,7 +304,7 @@ const char *vds_main_kernel(const vds_handle *h);
 /* Library/ABI version: (major << 16) | minor. */
 int32_t vds_version(void);
 
-/* Which sources this binary was built from: "src:<first 12 hex digits of sha1 over csrc/*.hip, vds_device.h, vds.h in
+/* Which sources this binary was built from: "src:<first 12 hex digits of sha1 over the .hip sources of csrc/, vds_device.h and vds.h in
  * Makefile order>" (`make -C vehicles_dispatch_simulator_amd/csrc srchash` prints the same for a checkout), with a
  * "+prof" / "+dbg" / "+canary" suffix for the instrumented builds.  bench.py prints it and compares it with the build the
  * committed rocprofv3 figures (profiles/traffic.json, limiter.json) were measured on.  Static string. */

@@ -1,0 +1,108 @@
+"""The instrumented builds of libvds run through parity workloads in subprocesses (``VDS_LIB`` selects the library):
+
+* ``make dbg`` (``-DWKDEBUG``): k_dfs_walk checks itself - bounds of every winner, evaluations of the dry orders counted a
+  second way - and prints ``k_dfs_walk check N failed`` when something is off;
+* ``make canary`` (``-DVDS_CANARY``): every device table sits between poisoned guard zones; an out-of-bounds write damages a
+  guard (``vds_debug_check_guards``, called by ``env.close()``), an out-of-bounds read returns the poison instead of a
+  neighbour's data and shows up as a wrong result.
+
+The libraries are built on demand into ``build/`` (about a minute each)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vehicles_dispatch_simulator_amd", "csrc")
+
+
+def build(target, name):
+    path = os.path.join(ROOT, "build", name)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "vds.h")]
+    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", CSRC, target])
+    return path
+
+
+WORKER = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle.oracle import Oracle
+from vehicles_dispatch_simulator_amd import workloads, _lib
+assert _lib.load().vds_build_id().decode().endswith(%r), _lib.load().vds_build_id()
+for neighbor, fg, R, veh in %r:
+    w = workloads.tiny(neighbor=neighbor, vehicles=veh, orders=4000)
+    init = w.vehicle_nodes(R)
+    env = w.make_env(R, force_generic=fg)
+    env.reset(init)
+    env.run(env.T)
+    got, cn = env.orders(), env.counters()
+    for r in range(0, R, max(1, R // 6)):
+        o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, w.release_min, w.pickup, w.delivery, w.vehicles)
+        o.reset(init[r]); o.run_day()
+        exp, oc = o.orders(), o.counters()
+        for k in ("status", "vehicle", "wait"):
+            assert np.array_equal(got[k][r], exp[k]), (neighbor, fg, r, k)
+        assert cn[r, 7] == oc["evals"] and cn[r, 1] == oc["reject_num"]
+    print("ok", neighbor, fg, env.main_kernel())
+    env.close()          # guarded build: raises when a guard zone was written
+print("WORKER DONE")
+"""
+
+
+def run_worker(lib, suffix, cases):
+    env = dict(os.environ, VDS_LIB=lib)
+    p = subprocess.run([sys.executable, "-c", WORKER % (ROOT, suffix, cases)], env=env, capture_output=True, text=True, timeout=900)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "WORKER DONE" in out, out[-3000:]
+    return out
+
+
+def test_self_checking_walk_build():
+    lib = build("dbg", "libvds_dbg.so")
+    # scarce vehicles: most orders run dry, redo chains and rejects; two replica counts
+    out = run_worker(lib, "+dbg", [(True, 0, 8, 40), (True, 0, 37, 25), (True, 0, 5, 90)])
+    assert "k_dfs_hybrid" in out
+    assert "check" not in out.replace("vds_debug_check", ""), out[-3000:]
+
+
+def test_guarded_build_all_tick_paths():
+    lib = build("canary", "libvds_canary.so")
+    cases = [(False, 0, 19, 150), (False, 1, 5, 150), (False, 5, 37, 150), (False, 6, 70, 150), (True, 0, 9, 40), (True, 2, 4, 40), (True, 3, 6, 40), (True, 4, 6, 40)]
+    out = run_worker(lib, "+canary", cases)
+    assert out.count("ok ") == len(cases)
+
+
+def test_guarded_build_replica_days_and_dispatch():
+    """The parity files that move the most tables, run whole under the guarded library."""
+    lib = build("canary", "libvds_canary.so")
+    env = dict(os.environ, VDS_LIB=lib)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_replica_days.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "replica or dispatch or ragged or burst"],
+                       env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+
+
+def test_guard_check_finds_a_damaged_guard():
+    lib = build("canary", "libvds_canary.so")
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from vehicles_dispatch_simulator_amd import workloads
+w = workloads.tiny()
+env = w.make_env(3)
+env.reset(w.vehicle_nodes(3))
+env.run(5)
+assert env._lib.vds_debug_check_guards(env._h) == 0
+assert env._lib.vds_debug_poke_guard(env._h) == 0
+try:
+    env.close()
+except Exception as e:
+    assert "guard zones damaged" in str(e), e
+    print("GUARD FOUND")
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VDS_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert "GUARD FOUND" in p.stdout, (p.stdout + p.stderr)[-2000:]

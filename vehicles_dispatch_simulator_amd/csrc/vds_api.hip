@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -126,12 +127,43 @@ static int fail(vds_handle *h, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(h, VDS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// Guarded build (make canary, -DVDS_CANARY): every device table sits between two guard zones filled with a poison pattern
+// (GUARD_FRONT bytes before, GUARD_BACK after).  An out-of-bounds WRITE damages a guard - vds_debug_check_guards finds it at
+// the next check - and an out-of-bounds READ returns the poison (0xA5A5A5A5: a negative count / index), which the parity tests
+// then see as a wrong result or a fault at a far-away address, instead of whatever the neighbouring table happened to hold.
+#ifdef VDS_CANARY
+static const size_t GUARD_FRONT = 64u << 10, GUARD_BACK = 1u << 20;
+static const bool GUARDED = true;
+#else
+static const size_t GUARD_FRONT = 0, GUARD_BACK = 0;
+static const bool GUARDED = false;
+#endif
+struct GuardRec { void *base; size_t bytes; };
+static std::map<void *, GuardRec> g_guards;      // user pointer -> allocation (guarded build only)
+
+static void dev_free(void *p) {
+    if (!p) return;
+    if (GUARDED) {
+        auto it = g_guards.find(p);
+        if (it != g_guards.end()) { (void)hipFree(it->second.base); g_guards.erase(it); return; }
+    }
+    (void)hipFree(p);
+}
+
 template <typename T>
 static int dev_alloc(vds_handle *h, T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
-    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
-    if (e != hipSuccess) return fail(h, VDS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    const size_t bytes = n * sizeof(T);
+    char *base = nullptr;
+    hipError_t e = hipMalloc((void **)&base, bytes + GUARD_FRONT + GUARD_BACK);
+    if (e != hipSuccess) return fail(h, VDS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (GUARDED) {
+        (void)hipMemset(base, 0xA5, GUARD_FRONT);
+        (void)hipMemset(base + GUARD_FRONT + bytes, 0xA5, GUARD_BACK);
+        g_guards[(void *)(base + GUARD_FRONT)] = GuardRec{(void *)base, bytes};
+    }
+    *p = reinterpret_cast<T *>(base + GUARD_FRONT);
     (h->alloc_sink ? *h->alloc_sink : h->dev_allocs).push_back((void *)*p);
     return VDS_OK;
 }
@@ -296,10 +328,10 @@ int vds_destroy(vds_handle *h) {
     if (!h) return VDS_OK;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
-    for (void *p : h->dev_allocs) (void)hipFree(p);
-    for (void *p : h->order_allocs) (void)hipFree(p);
-    for (void *p : h->state_allocs) (void)hipFree(p);
-    for (void *p : h->idle_allocs) (void)hipFree(p);
+    for (void *p : h->dev_allocs) dev_free(p);
+    for (void *p : h->order_allocs) dev_free(p);
+    for (void *p : h->state_allocs) dev_free(p);
+    for (void *p : h->idle_allocs) dev_free(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     drop_run_graph(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -582,7 +614,7 @@ static int alloc_state(vds_handle *h, int O) {
     if (S.layoutT && (std::max(idle_cap, S.idle_cap) > 65532 || H > 32)) S.layoutT = 0;      // list positions travel in 16 bits, insert ticks in 5
     if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_layoutT >= S.layoutT)
         return VDS_OK;                                   // another day on the same handle: the state tables still fit
-    for (void *p : h->state_allocs) (void)hipFree(p);
+    for (void *p : h->state_allocs) dev_free(p);
     h->state_allocs.clear();
     S.idle_cap = idle_cap; S.fl_cap = far_cap; S.in_cap = far_cap; S.H = H; S.ring_cap = ring_cap;
     const size_t B = (size_t)C * R;
@@ -597,7 +629,7 @@ static int alloc_state(vds_handle *h, int O) {
     {   // the idle table lives in its own allocation list: vds_reset / vds_set_idle_cap may replace it alone
         std::vector<void *> *keep = h->alloc_sink;
         h->alloc_sink = &h->idle_allocs;
-        for (void *p : h->idle_allocs) (void)hipFree(p);
+        for (void *p : h->idle_allocs) dev_free(p);
         h->idle_allocs.clear();
         rc = dev_alloc(h, &D.idle, std::max(B * idle_cap, BT * idle_cap / 2));      // (layout T: 4-byte entries)
         h->alloc_sink = keep;
@@ -630,7 +662,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         // another day on the same handle (Reload, :130-212): the previous day's tables go, the static tables stay,
         // the state tables stay while their capacities still fit; vds_reset must follow
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (void *p : h->order_allocs) (void)hipFree(p);
+        for (void *p : h->order_allocs) dev_free(p);
         h->order_allocs.clear();
         drop_run_graph(h);
         h->have_orders = false; h->have_reset = false;
@@ -956,7 +988,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     cap = std::min(round_up(cap, 64), round_up(std::max(h->S.V, 1), 64));
     if (cap > (1 << 24)) return fail(h, VDS_EINVAL, "vds_set_idle_cap: %d > 2^24 unsupported", cap);
     if (cap == h->S.idle_cap) return VDS_OK;
-    for (void *p : h->idle_allocs) (void)hipFree(p);
+    for (void *p : h->idle_allocs) dev_free(p);
     h->idle_allocs.clear();
     h->alloc_sink = &h->idle_allocs;
     const size_t B0 = (size_t)h->S.C * h->S.R, BT0 = h->alloc_layoutT > 0 ? (size_t)h->S.C * h->S.G * 64 : B0;
@@ -1480,6 +1512,37 @@ int vds_debug_lanes_prof(vds_handle *h, uint64_t *out64) {
     if (!h || !out64) return VDS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     lanes_read_prof((unsigned long long *)out64, h->stream);
+    return VDS_OK;
+}
+
+// Guarded build (make canary): number of device tables of this process whose guard zones no longer hold the poison pattern
+// (0 in every other build).  Synchronises the handle's stream.
+int vds_debug_check_guards(vds_handle *h) {
+    if (!h) return VDS_EINVAL;
+    if (!GUARDED) return 0;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int bad = 0;
+    std::vector<unsigned char> buf(std::max<size_t>(GUARD_FRONT, GUARD_BACK));
+    for (const auto &kv : g_guards) {
+        const char *base = (const char *)kv.second.base;
+        bool ok = true;
+        if (hipMemcpy(buf.data(), base, GUARD_FRONT, hipMemcpyDeviceToHost) != hipSuccess) return VDS_EHIP;
+        for (size_t i = 0; i < GUARD_FRONT && ok; ++i) ok = buf[i] == 0xA5;
+        if (hipMemcpy(buf.data(), base + GUARD_FRONT + kv.second.bytes, GUARD_BACK, hipMemcpyDeviceToHost) != hipSuccess) return VDS_EHIP;
+        for (size_t i = 0; i < GUARD_BACK && ok; ++i) ok = buf[i] == 0xA5;
+        if (!ok) { ++bad; fprintf(stderr, "libvds guard: table of %zu bytes at %p was written out of bounds\n", kv.second.bytes, (void *)(base + GUARD_FRONT)); }
+    }
+    return bad;
+}
+
+// Guarded build only: damages one guard zone on purpose (one byte behind the header table), so that the test of the guard
+// check itself has something to find.  Other builds: VDS_EINVAL.
+int vds_debug_poke_guard(vds_handle *h) {
+    if (!h || !GUARDED || !h->D.hdr) return VDS_EINVAL;
+    auto it = g_guards.find((void *)h->D.hdr);
+    if (it == g_guards.end()) return VDS_EINVAL;
+    HIPCHK(h, hipMemset((char *)it->second.base + GUARD_FRONT + it->second.bytes + 5, 0, 1));
     return VDS_OK;
 }
 

@@ -113,11 +113,13 @@ __device__ __forceinline__ int popc64(unsigned long long x) { return __popcll(x)
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-// ordering point for LDS traffic inside one wavefront: the DS instructions of a wavefront execute in order and the compiler keeps
-// may-alias LDS accesses in program order, so nothing has to be waited for - this only stops the scheduler from moving code across
-// (wave_fence() above, and an empty asm with a memory clobber too, are lowered to s_waitcnt vmcnt(0): they wait for every HBM
-// access in flight - a round trip per use)
-__device__ __forceinline__ void wave_order() { __builtin_amdgcn_sched_barrier(0); }
+// Ordering points for LDS traffic.  Both are release + acquire fences RESTRICTED TO THE LDS ADDRESS SPACE ("local"): the
+// language-level ordering the protocols below need, and - unlike an unrestricted fence, which is lowered to s_waitcnt vmcnt(0),
+// a full HBM round trip per use - nothing waits for the global loads / stores in flight (the ISA shows at most
+// s_waitcnt lgkmcnt(0)).  wave_order(): between accesses of different lanes of ONE wavefront to its own scratch;
+// wg_order(): between the wavefronts of a workgroup (k_dfs_walk's flags, records and stamps).
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
+__device__ __forceinline__ void wg_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); }
 
 // ---------------------------------------------------------------------------------------
 // Self-test kernel for the DPP primitives (tests/test_gpu_primitives.py).
@@ -2844,22 +2846,22 @@ __device__ __forceinline__ int pick_lane(const int (&a)[JB], int jb, int l) {
     return v;
 }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// flags between the wavefronts of a workgroup, all in LDS: the DS instructions of a wavefront execute in order, so a flag store
-// after the data stores (a flag load before the data loads) needs compiler ordering only.  (Workgroup-scope release / acquire
-// would also wait for the wavefront's outstanding HBM stores - a full round trip per served order.)
+// flags between the wavefronts of a workgroup, all in LDS: acquire / release at workgroup scope on the LDS address space only
+// (a flag store after the data stores, a flag load before the data loads).  An unrestricted workgroup-scope release / acquire
+// would also wait for the wavefront's outstanding HBM stores - a full round trip per served order.
 __device__ __forceinline__ int lds_acquire(const int *p) {
     const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wave_order();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     return v;
 }
 __device__ __forceinline__ void lds_release(int *p, int v) {
-    wave_order();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
-    wave_order();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     const bool ok = __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wave_order();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     return ok;
 }
 
@@ -3250,7 +3252,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 rec = pool_l + slot * WK_REC;
             } else {
                 dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
-                wave_order();
+                wg_order();
 #ifdef VDS_PROF
                 p_cnt[2] += 1;
 #endif
@@ -3261,13 +3263,13 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             int ra0 = (int)rec[4 * WK_K + 1], rr1 = (int)rec[4 * WK_K + 2], rr2 = (int)rec[4 * WK_K + 3], rcomp = (int)rec[4 * WK_K + 4];
             int stv = lane < nl ? (int)st_l[e.y] : -1;
             if (slot >= 0) {
-                wave_order();
+                wg_order();
                 if (lane == 0) lds_release(&s_slot[slot], 0);
             }
             unsigned long long okb = ballot(stv > rho);
             if (nl > 0 && okb == 0ull) {           // every kept candidate has been taken since: scan again, on the state as it is
                 dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
-                wave_order();
+                wg_order();
                 e = make_int4(IMAX, 0, 0, 0);
                 if (lane < WK_K) e = reinterpret_cast<const int4 *>(slot_l)[lane];
                 nl = (int)slot_l[4 * WK_K];
@@ -3312,7 +3314,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                     ++nlog;
                     if ((nlog & (WAVE - 1)) == 0)
                         slog[nlog - WAVE + lane] = make_int4(lg_l[4 * lane], lg_l[4 * lane + 1], lg_l[4 * lane + 2], lg_l[4 * lane + 3]);
-                    wave_order();
+                    wg_order();
 #ifdef VDS_PROF
                     p_cnt[0] += 1; if (a != (int)WK_FREE) p_cnt[1] += 1;
 #endif
@@ -3349,7 +3351,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                                     st_l[mo + pk] = (unsigned short)a;
                                     out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)pk), (s1 > a ? rr1 : rr2) >> 16);
                                 }
-                                wave_order();
+                                wg_order();
                                 if (bst == (int)WK_FREE) chain = false; else a = bst;
                             } else if (rcomp) {
                                 const int y = tq0 + (int)qr_l[a];
@@ -3390,12 +3392,12 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                             }
                             const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
                             const int bst = (int)st_l[mo + minp];
-                            wave_order();
+                            wg_order();
                             if (lane == 0) {
                                 st_l[mo + minp] = (unsigned short)a;
                                 out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
                             }
-                            wave_order();
+                            wg_order();
                             if (bst == (int)WK_FREE) break;
                             a = bst;
                         }
@@ -3404,7 +3406,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                     if (prof) { __builtin_amdgcn_s_waitcnt(0); p_chain += __builtin_amdgcn_s_memtime() - p_c0; }
 #endif
                     // own matches << 16 | steals of the cluster: one update once the order is served (what the scans read)
-                    wave_order();
+                    wg_order();
                     if (lane == 0) atomicAdd(&ls_l[wcl], 1 - (exhausted << 16));
                 }
             }
@@ -3412,7 +3414,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (prof) p_ts = __builtin_amdgcn_s_memtime();
             p_cnt[3] += 1;
 #endif
-            wave_order();
+            wg_order();
             rho = next_dry(rho + 1);
             PSEG(2);
         }
@@ -3493,7 +3495,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                                     , prof ? p_acc : nullptr
 #endif
                                     );
-                wave_order();
+                wg_order();
                 if (lane == 0) { lds_release(&s_slot[slot], (b << 2) | 2); lds_release(&s_slot[slot2], (b2nd << 2) | 2); }
 #ifdef VDS_PROF
                 if (prof) p_acc[6] += 1;
@@ -3504,7 +3506,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                                  , prof ? p_acc : nullptr
 #endif
                                  );
-                wave_order();
+                wg_order();
                 if (lane == 0) lds_release(&s_slot[slot], (b << 2) | 2);
             }
 #ifdef VDS_PROF
@@ -3610,10 +3612,10 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 for (int u = 0; u < 4; ++u) {
                     if (qd4[u] >= qe4[u]) continue;
                     for (int w = lane; w < bmw; w += WAVE) bm[w] = 0u;
-                    wave_order();
+                    wg_order();
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) if (jb * WAVE + lane < n4[u]) atomicOr(&bm[cjs[u][jb] >> 5], 1u << (cjs[u][jb] & 31));
-                    wave_order();
+                    wg_order();
                     for (int i0 = 0; i0 < nlog; i0 += WAVE) {
                         int2 sl = sl0;
                         if (i0 > 0) { sl = make_int2(IMAX, 0); if (i0 + lane < nlog) { const int4 s4 = slog[i0 + lane]; sl = make_int2(s4.x, s4.y); } }
@@ -3629,7 +3631,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                             }
                         }
                     }
-                    wave_order();
+                    wg_order();
                 }
             }
         }

@@ -80,8 +80,11 @@ class BatchedDispatchEnv:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            bad = self._lib.vds_debug_check_guards(self._h) if hasattr(self._lib, "vds_debug_check_guards") else 0
             self._lib.vds_destroy(self._h)
             self._h = C.c_void_p()
+            if bad:           # guarded build (make canary) only: some kernel wrote outside its table
+                raise Exception("libvds guard zones damaged: %d table(s) written out of bounds (see stderr)" % bad)
 
     def __del__(self):
         try:
