@@ -186,6 +186,53 @@ def test_full_size_distinct_days_config2():
     env.close()
 
 
+@pytest.mark.parametrize("layout", ["interleaved", "blocked"])
+def test_full_size_distinct_days_config4_neighbour_search(layout):
+    """configs[3] (neighbour DFS depth 2, the hybrid tick) at bench size with 8 distinct days over 1024 replicas: 16 replicas
+    - every day twice, batch positions far apart - against the oracle of THEIR day (per-order results, counters), and for ALL
+    1024 replicas the size-independent invariants: rejects + matched = processed orders of the replica's day, every vehicle
+    either idle or in flight, identical results for replicas with the same day and the same start nodes."""
+    R, D = 1024, 8
+    w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
+    days = workloads.distinct_days(w, D)
+    init = w.vehicle_nodes(R)
+    rmap = (np.arange(R) % D) if layout == "interleaved" else (np.arange(R) * D // R)
+    twin = int(np.flatnonzero((rmap == rmap[777]) & (np.arange(R) != 777))[5])
+    init[777] = init[twin]
+    env = w.make_env(R, load=False)
+    env.load_order_days(days, rmap.astype(np.int32))
+    assert env.main_kernel() == "k_dfs_hybrid"
+    env.reset(init)
+    env.run(env.T)
+    env.sync()
+    cn = env.counters()
+    ob = env.obs()
+    # invariants, every replica
+    proc = np.array([int(env.replica_ticks(r)[1]) for r in range(R)])
+    assert np.array_equal(cn[:, 0], cn[:, 1] + cn[:, 2])
+    assert (cn[:, 0] <= proc).all() and (cn[:, 0] >= proc - 1).all()          # the last order is never processed (:914-915)
+    assert np.array_equal(ob["idle_now"].sum(axis=1) + ob["inflight"].sum(axis=1), np.full(R, w.vehicles))
+    np.testing.assert_array_equal(cn[777], cn[twin])
+    a, b2 = env.orders(777, 1), env.orders(twin, 1)
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(a[k], b2[k])
+    # oracle anchors: each day twice
+    picks = []
+    for d in range(D):
+        rr = np.flatnonzero(rmap == d)
+        picks += [int(rr[0]), int(rr[-1])]
+    for r in picks:
+        d = days[rmap[r]]
+        o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, d[0], d[1], d[2], w.vehicles)
+        o.reset(init[r]); o.run_day()
+        exp, oc, got = o.orders(), o.counters(), env.orders(r, 1)
+        n = exp["status"].size
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][0][:n], exp[k], err_msg="%s: replica %d %s" % (layout, r, k))
+        assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
+    env.close()
+
+
 @pytest.mark.parametrize("name,layout", [("tiny_kmeans", "blocks"), ("tiny_grid", "blocks"), ("tiny_kmeans", "interleaved"),
                                          ("tiny_kmeans_dfs2", "interleaved"), ("tiny_kmeans_dfs2", "blocks")])
 def test_days_in_blocks_of_sixteen_replicas_take_the_workgroup_uniform_path(name, layout):
