@@ -172,3 +172,81 @@ def test_drop_in_from_data_directory_with_focus_region_and_reload(tmp_path):
     o.reset(sim._init_nodes[0]); o.run_day()
     oc = o.counters()
     assert (sim.RejectNum, sim.TotallyWaitTime, sim.SumOrderValue) == (oc["reject_num"], oc["wait_sum"], oc["sum_order_value"])
+
+
+class BatchedPolicySim(Simulation):
+    """A policy over ALL replicas at once (``BatchedHooks=True``): every third slot, each replica sends the head of the idle
+    lists of its three fullest clusters towards the cluster with the most waiting supply deficit - pure torch on the GPU."""
+
+    def RewardFunction(self):
+        self.reward_calls += 1
+        self.last_rejects = self.BatchedCounters()[:, 1].clone()
+
+    def DispatchFunction(self):
+        import torch
+        ob = self.BatchedObs
+        idle = ob["idle_now"]                                  # [R, C]
+        R, C = idle.shape
+        self.action_log.append(None)
+        if self.step % 3 != 0:
+            return None
+        K = 3
+        cnt, src = torch.topk(idle, K, dim=1)                  # fullest clusters
+        deficit = ob["cl_orders"] - idle + torch.arange(C, device=idle.device)[None, :] % 3   # (ties broken by id, deterministic)
+        tgt_cluster = torch.argmax(deficit, dim=1)             # [R]
+        tgt_node = self.first_node[tgt_cluster]                # [R]
+        acts = torch.full((R, K + 2, 3), -1, dtype=torch.int32, device=idle.device)           # (with empty slots)
+        ok = (cnt >= 2) & (src != tgt_cluster[:, None])
+        acts[:, 1:K + 1, 0] = torch.where(ok, src, torch.full_like(src, -1)).to(torch.int32)
+        acts[:, 1:K + 1, 1] = 0
+        acts[:, 1:K + 1, 2] = tgt_node[:, None].to(torch.int32)
+        self.action_log[-1] = acts.cpu().numpy()
+        return acts
+
+
+def test_batched_hooks_policy_over_all_replicas_matches_oracle_replay():
+    """``BatchedHooks``: hook order as SimCity's, observations / policy / actions on the device for 64 cities; every
+    replica equals a CPU oracle that replays ITS action log (vehicle = head of the named idle list at that moment)."""
+    import torch
+    g = load_golden("tiny_kmeans")
+    R = 64
+    sim = make_sim(g, BatchedPolicySim, Replicas=R, VehicleSeed=4242, BatchedHooks=True)
+    sim.reward_calls, sim.action_log = 0, []
+    n2c = g["node2cluster"]
+    C = int(g["C"])
+    sim.first_node = torch.tensor([int(np.flatnonzero(n2c == c)[0]) if (n2c == c).any() else 0 for c in range(C)], device="cuda")
+    init = sim._init_nodes.copy()
+    sim.SimCity()
+    T = sim.env.T
+    assert sim.reward_calls == T and len(sim.action_log) == T and sim.step == T
+    assert sum(a is not None for a in sim.action_log) == (T + 2) // 3
+    got, cn = sim.env.orders(), sim.env.counters()
+    n_dispatched = 0
+    for r in range(R):
+        o = make_oracle(g)
+        o.reset(init[r])
+        for t in range(T):
+            o.begin_tick()
+            a = sim.action_log[t]
+            if a is not None:
+                L = o.lists()
+                vehs, tgts = [], []
+                for cl, pos, tg in a[r]:
+                    if cl >= 0:
+                        vehs.append(int(L["idle_veh"][L["idle_off"][cl] + pos])); tgts.append(int(tg))
+                if vehs:
+                    o.dispatch(np.array(vehs), np.array(tgts))
+                    n_dispatched += len(vehs)
+            o.end_tick()
+        exp, oc = o.orders(), o.counters()
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(got[k][r], exp[k], err_msg="replica %d %s" % (r, k))
+        assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 4], cn[r, 5], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["dispatch_num"], oc["dispatch_cost"], oc["evals"]), r
+    assert n_dispatched > R * 20
+    # the shell's own fields describe replica `Replica` (0), its views were refreshed after the day
+    assert sim.RejectNum == cn[0, 1] and sim.DispatchNum == cn[0, 4] and sim.TotallyDispatchCost == cn[0, 5]
+    idle_total = sum(len(c.IdleVehicles) for c in sim.Clusters)
+    fly_total = sum(len(c.VehiclesArrivetime) for c in sim.Clusters)
+    assert idle_total + fly_total == len(sim.Vehicles)
+    assert int((sim.last_rejects.cpu().numpy() == cn[:, 1]).sum()) >= 1     # (counters of the last slot, read inside the hook)
+    sim.env.close()

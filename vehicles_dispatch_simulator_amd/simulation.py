@@ -17,7 +17,14 @@ What a maintainer should know (also in INTEGRATION.md):
     is the one-call form of the same thing;
   * ``UpdateFunction`` / ``MatchFunction`` / ``SupplyExpectFunction`` are ONE fused device launch: overriding them is
     refused with a clear error instead of being silently ignored;
-  * extra optional keywords: ``Replicas``, ``Replica``, ``Device``, ``VehicleSeed``, ``DataDir``.
+  * extra optional keywords: ``Replicas``, ``Replica``, ``Device``, ``VehicleSeed``, ``DataDir``, ``BatchedHooks``;
+  * ``BatchedHooks=True``: the hooks see ALL ``Replicas`` cities at once.  Same hook names and the same order per slot as
+    ``SimCity`` (:1050-1087); ``self.BatchedObs`` holds the slot's observations as CUDA int32 tensors ``[Replicas, clusters]``
+    (``idle_pre`` = PerMatchIdleVehicles, ``idle_now``, ``supply`` = SupplyExpect, ``cl_orders`` = len(Cluster.Orders),
+    ``inflight`` = len(VehiclesArrivetime)), ``self.BatchedCounters()`` the per-replica counters ``[Replicas, 8]``, and
+    ``DispatchFunction`` may RETURN an int32 CUDA tensor ``[Replicas, K, 3]`` of ``(from_cluster, idle_pos, target_node)``
+    actions (``from_cluster < 0``: none), applied on the device (``vds_apply_dispatch_device``) - nothing leaves the GPU.
+    The object views (``Clusters`` / ``Vehicles`` / ``Orders``) of replica ``Replica`` are refreshed once, after the day.
 """
 from __future__ import annotations
 
@@ -68,7 +75,7 @@ class _RoadCostMap(object):
 class Simulation(object):
     def __init__(self, ClusterMode, DemandPredictionMode, DispatchMode, VehiclesNumber, TimePeriods, LocalRegionBound,
                  SideLengthMeter, VehiclesServiceMeter, NeighborCanServer, FocusOnLocalRegion,
-                 Replicas=1, Replica=0, Device=0, VehicleSeed=None, DataDir=None, Quiet=False, **device_kwargs):
+                 Replicas=1, Replica=0, Device=0, VehicleSeed=None, DataDir=None, Quiet=False, BatchedHooks=False, **device_kwargs):
         # components (simulator.py:44-45)
         self.DispatchModule = None
         self.DemandPredictorModule = None
@@ -118,6 +125,11 @@ class Simulation(object):
         self.Replicas, self.Replica, self.Device, self.VehicleSeed = int(Replicas), int(Replica), int(Device), VehicleSeed
         self.DataDir = DataDir
         self.Quiet = Quiet
+        self.BatchedHooks = bool(BatchedHooks)
+        self.BatchedObs = None
+        if self.BatchedHooks and "stream" not in device_kwargs:
+            import torch          # the policy's tensors and the engine's launches share torch's current stream
+            device_kwargs = dict(device_kwargs, stream=torch.cuda.current_stream(int(Device)).cuda_stream)
         self._device_kwargs = device_kwargs
         self.env = None
         self._version = 0
@@ -559,6 +571,11 @@ class Simulation(object):
         self._advance_mirror()
         self._refresh_containers()
 
+    def BatchedCounters(self):
+        """``BatchedHooks``: per-replica counters as a CUDA int64 tensor ``[Replicas, 8]`` in device order (orders,
+        rejects, wait_sum, matched_value_sum, evals, arrivals, dispatch_num, dispatch_cost); valid until the next call."""
+        return self.env.counters_torch()
+
     def _hooks_overridden(self):
         fused = [h for h in _FUSED if getattr(type(self), h, None) is not getattr(Simulation, h, None)]
         if fused:
@@ -598,6 +615,17 @@ class Simulation(object):
         loc[av] = origin_of_order[ordr[av]]
         self._mirror_state = dict(loc=loc, cluster=W.node2cluster[loc].astype(np.int64), dest=dest, order=ordr, arr=arr)
 
+    def _rebuild_mirror_from_device(self):
+        """Vehicle views after a ``BatchedHooks`` day (dispatches happened on the device): idle vehicles stand where the idle
+        lists say; a vehicle on the way reports its destination, arrival time and order - its ``LocationNode`` / ``Cluster``
+        (the trip ORIGIN in the reference until it arrives, ``objects.py:84-89``) is not tracked on the device: -1."""
+        v = self.env.vehicles(self.Replica)
+        idle = v["state"] == 0
+        loc = np.where(idle, v["node"], -1).astype(np.int64)
+        cluster = np.where(idle, v["cluster"], -1).astype(np.int64)
+        dest = np.where(idle, -1, v["node"]).astype(np.int64)
+        self._mirror_state = dict(loc=loc, cluster=cluster, dest=dest, order=v["order"].astype(np.int64), arr=v["arrive_min"].astype(np.int64))
+
     def SimCity(self, FastForward=None):
         """``:1036-1130``.  With no hook overridden (``FastForward``), the whole day is issued to
         the device without per-slot host synchronisation."""
@@ -608,6 +636,8 @@ class Simulation(object):
         self.step = 0
         self._stepped_current = False
         fast = (not self._hooks_overridden()) if FastForward is None else FastForward
+        if self.BatchedHooks and self.DispatchModule is not None:
+            raise Exception("BatchedHooks: a LoadDispatchComponent module works on one city's objects; override DispatchFunction instead")
         EpisodeStartTime = dt.datetime.now()
         self._say("Start experiment")
         self._say("----------------------------")
@@ -635,6 +665,32 @@ class Simulation(object):
             self.step = T
             self.RealExpTime = self.RealExpTime + T * pd.Timedelta(minutes=tm)
             self.TotallyMatchTime += dt.datetime.now() - t0
+        elif self.BatchedHooks:
+            # the reference's slot loop (:1048-1091) for all replicas at once: observations, policy and actions stay on the GPU
+            names = ("idle_pre", "idle_now", "supply", "cl_orders", "inflight")
+            T = self.env.T
+            for _ in range(T):
+                t = dt.datetime.now(); self.env.step(); self.TotallyMatchTime += dt.datetime.now() - t     # Update + Match + SupplyExpect
+                ob = self.env.obs_torch()
+                self.BatchedObs = {k: ob[i] for i, k in enumerate(names)}
+                t = dt.datetime.now(); self.RewardFunction(); self.TotallyRewardTime += dt.datetime.now() - t
+                t = dt.datetime.now(); self.GetNextStateFunction(); self.TotallyNextStateTime += dt.datetime.now() - t
+                t = dt.datetime.now(); self.LearningFunction(); self.TotallyLearningTime += dt.datetime.now() - t
+                t = dt.datetime.now(); self.DemandPredictFunction(); self.TotallyDemandPredictTime += dt.datetime.now() - t
+                t = dt.datetime.now()
+                acts = self.DispatchFunction()
+                if acts is not None:
+                    self.env.apply_dispatch_torch(acts)
+                self.TotallyDispatchTime += dt.datetime.now() - t
+                self.step += 1
+                self.RealExpTime += self.TimePeriods
+                self.env.advance()
+            self.env.sync()
+            self._stepped_current = False
+            self._touch()
+            self._pull_counters()
+            self._rebuild_mirror_from_device()
+            self._refresh_containers()
         else:
             while self.RealExpTime <= EndTime:
                 t = dt.datetime.now(); self.UpdateFunction(); self.TotallyUpdateTime += dt.datetime.now() - t
