@@ -290,3 +290,54 @@ def test_reloading_days_on_one_handle_neighbour_search():
                 np.testing.assert_array_equal(got[k][r][:exp[k].size], exp[k], err_msg="day %d replica %d %s" % (d, r, k))
             assert cn[r, 7] == oc["evals"] and cn[r, 1] == oc["reject_num"]
     env.close()
+
+
+def test_dispatch_on_a_replica_whose_day_is_over_is_refused():
+    """A replica past its last slot stands still (``:1048``): moving one of its vehicles would strand it (nobody drains the
+    arrival tables of a finished city).  The host-list call refuses the whole call, the device-tensor call skips that
+    replica's actions and reports it at the next sync; live replicas are served in both."""
+    import torch
+    g = load_golden("tiny_kmeans")
+    V, N, R = int(g["V"]), int(g["N"]), 4
+    days = synth_days(g, 3, seed=77)            # day 2 ends after five hours
+    replica_day = np.array([0, 2, 1, 2], dtype=np.int32)
+    valid = g["node2cluster"] >= 0
+    init = np.stack([synth.init_vehicle_nodes(random.Random(9 + r), N, V, valid) for r in range(R)]).astype(np.int32)
+    env = mk_env(g, R, stream=torch.cuda.current_stream().cuda_stream)
+    env.load_order_days(days, replica_day)
+    env.reset(init)
+    T_short = env.replica_ticks(1)[0]
+    assert T_short < env.T - 3
+    for _ in range(T_short + 2):
+        env.step(); env.advance()
+    env.step()
+    ob = env.obs()
+    tgt = int(np.flatnonzero(valid)[0])
+    cl_live = int(np.argmax(ob["idle_now"][0])); cl_done = int(np.argmax(ob["idle_now"][1]))
+    before = env.counters().copy()
+    with pytest.raises(Exception, match="day of replica 1 is over"):
+        env.apply_dispatch([0, 1], [cl_live, cl_done], [0, 0], [tgt, tgt])
+    np.testing.assert_array_equal(env.counters(), before)            # nothing of the refused call was applied
+    env.apply_dispatch([0], [cl_live], [0], [tgt])
+    acts = np.full((R, 2, 3), -1, dtype=np.int32)
+    acts[2, 0] = (int(np.argmax(ob["idle_now"][2])), 0, tgt)
+    acts[3, 1] = (int(np.argmax(ob["idle_now"][3])), 0, tgt)           # replica 3 replays the short day too
+    env.apply_dispatch_torch(torch.from_numpy(acts).cuda())
+    with pytest.raises(Exception, match="dispatch"):
+        env.sync()
+    cn = env.counters()
+    assert cn[0, 4] == before[0, 4] + 1 and cn[2, 4] == before[2, 4] + 1 and cn[1, 4] == before[1, 4] and cn[3, 4] == before[3, 4]
+    assert env.obs()["inflight"][3].sum() == ob["inflight"][3].sum()
+    env.close()
+
+
+def test_loader_wrappers_check_array_lengths():
+    g = load_golden("tiny_kmeans")
+    env = mk_env(g, 3)
+    rel, pk, dl = g["o_release_min"], g["o_pickup"], g["o_delivery"]
+    O = rel.size
+    with pytest.raises(Exception, match="equal length"):
+        env.load_order_days([(rel, pk, dl), (rel, pk[:-1], dl)])
+    with pytest.raises(Exception, match="need .* elements"):
+        env.load_orders_strided(np.tile(rel, 2), np.tile(pk, 2), np.tile(dl, 2), O, O)      # 3 replicas need 3 * O
+    env.close()

@@ -1177,7 +1177,7 @@ int vds_sync(vds_handle *h) {
     if (!h->have_static) return VDS_OK;
     int err[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpy(err, h->D.err, sizeof(err), hipMemcpyDeviceToHost));
-    if (err[0] & ERR_IDLE_CAP) return fail(h, VDS_ECAPACITY, "idle table overflow: more than idle_cap=%d idle vehicles in one (replica, cluster); raise vds_config.idle_cap", h->S.idle_cap);
+    if (err[0] & ERR_IDLE_CAP) return fail(h, VDS_ECAPACITY, "idle table overflow: more than idle_cap=%d idle vehicles in one (replica, cluster); raise it: vds_config.idle_cap / vds_set_idle_cap + vds_reset_again (Simulation(..., idle_cap=N), BatchedDispatchEnv.set_idle_cap)", h->S.idle_cap);
     if (err[0] & ERR_FL_CAP) return fail(h, VDS_ECAPACITY, "far-arrival table overflow: more than far_cap=%d vehicles on trips longer than the ring horizon to one (replica, cluster); raise vds_config.far_cap", h->S.fl_cap);
     if (err[0] & ERR_INBOX_CAP) return fail(h, VDS_ECAPACITY, "far-arrival inbox overflow: more than far_cap=%d long trips sent to one (replica, cluster) in one tick; raise vds_config.far_cap", h->S.in_cap);
     if (err[0] & ERR_RING_CAP) return fail(h, VDS_ECAPACITY, "arrival ring overflow: more than ring_cap=%d vehicles due in one (replica, cluster) in one tick; raise vds_config.ring_cap", h->S.ring_cap);
@@ -1216,6 +1216,8 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
             return fail(h, VDS_EINVAL, "vds_apply_dispatch: action %d: replica/cluster out of range", i);
         if (target_node[i] < 0 || target_node[i] >= S.N || h->node2cluster[target_node[i]] < 0)
             return fail(h, VDS_ESTATE, "vds_apply_dispatch: action %d: target node %d is in no cluster", i, target_node[i]);
+        if (h->t >= h->days[h->replica_day[replica[i]]].T)     // its SimCity loop has ended (:1048): nothing would ever collect the vehicle
+            return fail(h, VDS_ESTATE, "vds_apply_dispatch: action %d: the day of replica %d is over (%d ticks), its city stands still", i, replica[i], h->days[h->replica_day[replica[i]]].T);
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (replica[a] != replica[b]) return replica[a] < replica[b];

@@ -3907,8 +3907,16 @@ __global__ void k_total_counters(int R, const long long *per, long long *tot) {
 __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t, int K, const int *actions, int seq_base) {
     const int r = blockIdx.x;
     const int lane = lane_id();
-    const int now = day_view(S, r).now0 + t * S.tick_minutes;
+    const DayView dvw = day_view(S, r);
+    const int now = dvw.now0 + t * S.tick_minutes;
     const int *act = actions + (size_t)r * K * 3;
+    if (t >= dvw.T) {
+        // the replica's day is over (:1048), its city stands still: actions are refused (reported by the next vds_sync)
+        bool any = false;
+        for (int k = lane; k < K; k += WAVE) any = any || act[k * 3] >= 0;
+        if (any) atomicOr(&D.err[0], ERR_DISPATCH);
+        return;
+    }
     for (int k0 = 0; k0 < K; k0 += WAVE) {
         // one pass = up to 64 consecutive actions; passes see the lists left by the earlier ones, so an action's
         // position must refer to the list before the CALL only within its pass: the host wrapper requires K <= 64

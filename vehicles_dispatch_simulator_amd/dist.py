@@ -43,6 +43,8 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return value
+    if device is None and dist.get_backend() == "nccl":
+        device = "cuda"               # RCCL reduces device tensors only
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

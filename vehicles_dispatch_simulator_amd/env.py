@@ -110,6 +110,10 @@ class BatchedDispatchEnv:
         keep every aligned group of 16 replicas on one day for the fast path) - one
         ``Simulation`` = one city = its own ``Orders`` in the reference (``simulator.py:325-342``).  ``T`` is the
         longest day; a replica whose day is over stands still."""
+        for i, d in enumerate(days):
+            n = [np.asarray(x).size for x in d[:3]]
+            if len(d) < 3 or n[0] != n[1] or n[0] != n[2] or n[0] < 1:
+                raise Exception("load_order_days: day %d needs three non-empty arrays of equal length (release_min, pickup, delivery), got %s" % (i, n))
         rel = np.concatenate([_i32(d[0]).reshape(-1) for d in days])
         pk = np.concatenate([_i32(d[1]).reshape(-1) for d in days])
         dl = np.concatenate([_i32(d[2]).reshape(-1) for d in days])
@@ -124,6 +128,10 @@ class BatchedDispatchEnv:
     def load_orders_strided(self, release_min, pickup, delivery, O: int, replica_stride: int):
         """SURVEY 8(b) form: replica ``r``'s day starts at element ``r * replica_stride`` (0 = one shared day)."""
         r, p, d = _i32(release_min).reshape(-1), _i32(pickup).reshape(-1), _i32(delivery).reshape(-1)
+        need = int(O) if int(replica_stride) == 0 else (self.R - 1) * int(replica_stride) + int(O)
+        if not (r.size == p.size == d.size) or r.size < need:
+            raise Exception("load_orders_strided: the three arrays need %d elements each ((R - 1) * replica_stride + O), got %d / %d / %d"
+                            % (need, r.size, p.size, d.size))
         self._chk(self._lib.vds_load_orders_strided(self._h, _p(r), _p(p), _p(d), int(O), int(replica_stride)))
         self._after_load(int(O))
 

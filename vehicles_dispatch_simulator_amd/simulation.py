@@ -704,7 +704,9 @@ class Simulation(object):
                 self.TotallyDemandPredictTime += dt.datetime.now() - t
                 idle_now = self._obs()["idle_now"]
                 for c in self.Clusters:
-                    c.PerDispatchIdleVehicles = int(idle_now[c.ID])
+                    # len(IdleVehicles) (:1067-1068): a container an earlier hook of this slot has touched counts as it stands
+                    ent = self._idle_objs.get(c.ID)
+                    c.PerDispatchIdleVehicles = len(ent[0]) if ent is not None and ent[1] == self._version else int(idle_now[c.ID])
                 t = dt.datetime.now(); self.DispatchFunction(); self._flush_dispatch()
                 self.TotallyDispatchTime += dt.datetime.now() - t
                 idle_now = self._obs()["idle_now"]

@@ -74,6 +74,7 @@ def read_orders(path: str, node_index: dict) -> Tuple[np.ndarray, np.ndarray, np
     import pandas as pd
     from datetime import datetime
 
+    _check_tie_order()
     df = pd.read_csv(path)
     minute = np.array([np.datetime64(datetime.fromtimestamp(int(v)).replace(second=0, microsecond=0), "m")
                        for v in df["Start_time"].values])
@@ -81,6 +82,29 @@ def read_orders(path: str, node_index: dict) -> Tuple[np.ndarray, np.ndarray, np
     pick = np.array([node_index[int(v)] for v in df["NodeS"].values[order]], dtype=np.int32)
     dele = np.array([node_index[int(v)] for v in df["NodeE"].values[order]], dtype=np.int32)
     return minute[order], pick, dele
+
+
+_TIE_ORDER_SHA = "d858ce873d6da629"      # numpy 2.2.x: argsort(datetime64[ns], "quicksort") of the probe below
+_tie_checked = False
+
+
+def _check_tie_order():
+    """``read_orders`` reproduces the reference's order ids only while numpy orders TIES of a ``datetime64`` quicksort the way
+    the numpy the reference was captured with did (an implementation detail, not a promise).  A 200-element probe with many
+    ties is sorted once per process; if its permutation differs from the pinned one, say so loudly: days loaded from a CSV
+    would then number same-minute orders differently from the reference (everything downstream stays self-consistent)."""
+    global _tie_checked
+    if _tie_checked:
+        return
+    _tie_checked = True
+    import hashlib
+    import warnings
+    v = (np.arange(200) * 7919 % 13).astype("int64").astype("datetime64[m]").astype("datetime64[ns]")
+    got = hashlib.sha1(np.argsort(v, kind="quicksort").astype(np.int64).tobytes()).hexdigest()[:16]
+    if got != _TIE_ORDER_SHA:
+        warnings.warn("numpy %s orders ties of an unstable datetime64 sort differently from the numpy the reference's ReadOrder was "
+                      "pinned with (2.2.x): orders released in the same minute will be numbered differently from the reference's "
+                      "order ids (tests/test_world_loader.py::tiny_sort_ties shows it)" % np.__version__, RuntimeWarning)
 
 
 def _grid_assignment(lon, lat, bound, gw, gh):
@@ -170,7 +194,11 @@ def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_len
             table = synth.neighbor_table_from_sums(sums, sizes)
             neighbors = synth.neighbors_from_table(table)
             if write_neighbor_cache:
-                write_neighbor_csv(nb_path, table)
+                try:
+                    write_neighbor_csv(nb_path, table)
+                except OSError as e:        # read-only data directory: the table is simply recomputed next time
+                    import warnings
+                    warnings.warn("could not cache %s (%s)" % (nb_path, e), RuntimeWarning)
     cluster_nodes = [np.flatnonzero(node2cluster == c).tolist() for c in range(C)]
 
     minute, pick, dele = read_orders(order_path or os.path.join(data_dir, "order_2016" + str(order_file_date) + ".csv"), index)
