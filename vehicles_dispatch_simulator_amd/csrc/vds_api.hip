@@ -855,6 +855,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         S.lane_loc_slots = round_up(std::max(16, h->dbg_lanes_loc > 0 ? h->dbg_lanes_loc : env_int("VDS_LANES_LOC", 32)), 16);
         S.lane_key_slots = std::max(8, h->dbg_lanes_keys > 0 ? h->dbg_lanes_keys : env_int("VDS_LANES_KEYS", 16));
         S.lane_force_slow = h->dbg_lanes_slow;
+        S.lane_ablate = env_int("VDS_LANES_ABLATE", 0);
         const int force_lg = h->dbg_lanes_lg >= 0 ? h->dbg_lanes_lg : env_int("VDS_LANES_LG", -1);
         const bool can = h->lanes_static_ok && n_days == 1 && Omax <= (1 << 26) && lanes_prepare(S) == 0;
         const int auto_min_r = env_int("VDS_LANES_AUTO_MIN_R", LANES_AUTO_MIN_R);
@@ -1506,6 +1507,14 @@ int vds_debug_ablate(vds_handle *h, int32_t flags) {
 int vds_debug_lanes(vds_handle *h, int32_t log2_lanes, int32_t loc_slots, int32_t key_slots, int32_t force_slow) {
     if (!h) return VDS_EINVAL;
     h->dbg_lanes_lg = log2_lanes; h->dbg_lanes_loc = loc_slots; h->dbg_lanes_keys = key_slots; h->dbg_lanes_slow = force_slow;
+    return VDS_OK;
+}
+
+// Timing experiments (results INVALID while non-zero): Static.lane_ablate of k_tick_lanes, effective from the next launch.
+int vds_debug_lanes_ablate(vds_handle *h, int32_t flags) {
+    if (!h) return VDS_EINVAL;
+    drop_run_graph(h);
+    h->S.lane_ablate = flags;
     return VDS_OK;
 }
 

@@ -130,6 +130,8 @@ struct Static {
     const unsigned char *blk8s;      // per-cluster byte cost blocks with row stride n_c + 1; column n_c holds 0xFF (the cost of a taken / absent entry)
     int lane_loc_slots, lane_key_slots;   // per-lane LDS capacities: idle entries / arrivals per lane (x lanes per bucket)
     int lane_force_slow;             // testing: every wavefront takes the table-free slow path
+    int lane_ablate;                 // timing experiments only (results INVALID when non-zero): bit0 no counter atomics, bit1 no result
+                                     // stores, bit2 no arrival posts, bit3 no list write-back, bit4 no header store
 };
 
 struct State {

@@ -26,6 +26,7 @@
 // A wavefront whose buckets do not fit the tables (or that owns far arrivals) takes the SLOW path: the same steps against
 // HBM / L2 - correct for any list length, only slower.
 #include "vds_device.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace vds {
@@ -144,8 +145,9 @@ __device__ __forceinline__ int ent_word(int s, int l) { return (((s >> 2) * 64 +
 __device__ __forceinline__ void lanes_finish(const Static &S, const State &D, size_t b, int p, bool writer, int4 h0, int mfin, int mnew, int k, int newfl,
                                              bool inbox_reset, int A, int rej, int wsum, int vsum, long long evals) {
     if (!writer) return;
-    if (h0.x != mfin || h0.y != mnew || h0.z != k || h0.w != newfl) *reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS) = make_int4(mfin, mnew, k, newfl);
+    if (!(S.lane_ablate & 16) && (h0.x != mfin || h0.y != mnew || h0.z != k || h0.w != newfl)) *reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS) = make_int4(mfin, mnew, k, newfl);
     if (inbox_reset) D.hdr[b * HDR_WORDS + HDR_INBOX0 + p] = 0;
+    if (S.lane_ablate & 1) return;
     unsigned long long *cu = reinterpret_cast<unsigned long long *>(D.cnt + b * CNT_WORDS);
     if (k) atomicAdd(cu + CNT_ORDERS, (unsigned long long)k);
     if (rej) atomicAdd(cu + CNT_REJECTS, (unsigned long long)rej);
@@ -436,12 +438,12 @@ __device__ __forceinline__ void lanes_tick_fast(const Static &S, const State &D,
                         const int wpos = (int)(rv & 0xFFFFu);
                         veh = (int)(entW[ent_word(wpos >> LG, gbase + (wpos & (L - 1)))] >> 8);
                         wsum += wait; vsum += rec.w;
-                        pd[s] = post_begin(S, D, X, rec.z & 0xFFFF, veh, rec.x, (int)((unsigned)rec.y >> 16), wait + rec.w);
+                        if (!(S.lane_ablate & 4)) pd[s] = post_begin(S, D, X, rec.z & 0xFFFF, veh, rec.x, (int)((unsigned)rec.y >> 16), wait + rec.w);
                         res[s] = ((unsigned)veh << 8) | (unsigned)wait;
                     } else {
                         rej++;
                     }
-                    outp[(size_t)(X.q0 + j0 + jj) * Rpad] = hit ? make_int2(veh, wait) : make_int2(-1, -1);
+                    if (!(S.lane_ablate & 2)) outp[(size_t)(X.q0 + j0 + jj) * Rpad] = hit ? make_int2(veh, wait) : make_int2(-1, -1);
                 }
             }
         }
@@ -490,7 +492,7 @@ __device__ __forceinline__ void lanes_tick_fast(const Static &S, const State &D,
     }
     const int mfin = navail;
     LPROF(7);
-    {
+    if (!(S.lane_ablate & 8)) {
         const int wb0 = valid ? min(fd, m) : 0x7FFFFFFF;    // first list position whose HBM copy is stale (or missing: arrivals)
         const int mf = valid ? mfin : 0;
         const int mfmax = wave_max_i32(mf);
@@ -780,7 +782,8 @@ size_t lanes_lds_bytes(const Static &S, int *blk_off) {
     // own idle entries (4 bytes each) | arrival keys (later: order results) | arrival payloads | cost block
     const size_t tables = ((size_t)S.lane_loc_slots + 2 * (size_t)S.lane_key_slots) * 64 * 4;
     *blk_off = (int)tables;
-    return tables + (((size_t)S.max_nc * (S.max_nc + 1) + 15) / 16) * 16;
+    static const size_t pad = [] { const char *v = getenv("VDS_LANES_LDS_PAD"); return v && *v ? (size_t)atoi(v) : (size_t)0; }();     // occupancy experiments
+    return tables + (((size_t)S.max_nc * (S.max_nc + 1) + 15) / 16) * 16 + pad;
 }
 
 int lanes_prepare(const Static &S) {       // opt in to more than 64 KB of dynamic LDS when the biggest cost block needs it

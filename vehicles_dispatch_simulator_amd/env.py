@@ -112,8 +112,8 @@ class BatchedDispatchEnv:
         longest day; a replica whose day is over stands still."""
         for i, d in enumerate(days):
             n = [np.asarray(x).size for x in d[:3]]
-            if len(d) < 3 or n[0] != n[1] or n[0] != n[2] or n[0] < 1:
-                raise Exception("load_order_days: day %d needs three non-empty arrays of equal length (release_min, pickup, delivery), got %s" % (i, n))
+            if len(d) < 3 or n[0] != n[1] or n[0] != n[2]:
+                raise Exception("load_order_days: day %d needs three arrays of equal length (release_min, pickup, delivery), got %s" % (i, n))
         rel = np.concatenate([_i32(d[0]).reshape(-1) for d in days])
         pk = np.concatenate([_i32(d[1]).reshape(-1) for d in days])
         dl = np.concatenate([_i32(d[2]).reshape(-1) for d in days])
