@@ -337,6 +337,7 @@ def main():
                        "step": "one simulated day (T ticks) of all replicas incl. episode reset and counter all-reduce",
                        "parallelism": "replica-sharded x%d, RCCL all-reduce of int64[8] metrics per day" % world},
             "match_evals_per_s": float(work["evals"]) * world * a.steps / elapsed if work["evals"] else None,
+            "slow_path_buckets_last_day": int(work.get("slow_path_buckets", 0)),      # buckets the fast kernel handed to a slower path (rank 0)
             "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
             "roofline": roofline, "cpu_baseline": cpu, "build": build_id,
         }

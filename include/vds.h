@@ -261,7 +261,10 @@ int vds_read_vehicles(vds_handle *h, int32_t replica, uint8_t *state, int32_t *n
 
 /* Work model of the last vds_step / vds_run call sequence since vds_reset, for roofline
  * accounting (DESIGN.md "algorithmic bytes"): int64 [8] = {ticks, orders processed, matches,
- * evaluations, arrivals, dispatches, 0, 0} summed over replicas. */
+ * evaluations, arrivals, dispatches, slow-path buckets, 0} summed over replicas.  Slow-path buckets: (replica, cluster, tick)
+ * buckets the fast tick kernel (k_tick_rows / k_tick_lanes) had to hand to a slower path since vds_reset - idle list beyond
+ * its register / LDS tables, arrivals through the far tables, an oversize arrival slot, a cost block beyond LDS (INTEGRATION.md
+ * "Limits"): 0 in the generic and neighbour-search kernels, which have no such split. */
 int vds_read_work(vds_handle *h, int64_t *out);
 
 /* Kernel timing for roofline accounting: while enabled, every vds_step brackets its main tick

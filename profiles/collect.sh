@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collect rocprofv3 evidence for bench.py on the GPU box (run through gpurun).
 #   bash profiles/collect.sh <tag> [bench args...]        (DISTINCT=16 ... : also run the per-replica-days leg)
-# Writes raw CSVs under gpurun_out/prof_<tag>/ ; summarise with profiles/summarise.py
+# Writes raw CSVs under gpurun_out/prof_<tag>/ ; summarise with profiles/summarise.py, then profiles/refresh_side_data.py
 export TMPDIR=/tmp
 TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
+python -c "from vehicles_dispatch_simulator_amd import _lib; print(_lib.load().vds_build_id().decode())" > $O/build_id.txt 2>/dev/null
 B="python bench.py --no-cpu-baseline --no-neighbour-leg --distinct-days ${DISTINCT:-0} $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1

@@ -34,6 +34,9 @@ for name in ("fetch", "write", "sq", "sq2"):
         # -Rpass-analysis=kernel-resource-usage says 72 for k_tick_rows<true, false>, this column 36) and
         # LDS_Block_Size shows the static part only (the kernels use dynamic LDS: 18 KB per workgroup for k_tick_rows)
         out["_dispatch"] = {c: int(k[c].iloc[0]) for c in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size")}
+bid = os.path.join(src, "build_id.txt")
+if os.path.exists(bid):
+    out["_build"] = open(bid).read().strip()
 import re
 json.dump(out, open(os.path.join(dst, "pmc_%s.json" % re.sub(r"[^A-Za-z0-9_]+", "_", kern).strip("_")), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_stats.csv")).read()[:1500])

@@ -236,3 +236,29 @@ def test_round2_entry_points_refuse_bad_arguments():
     assert lib.vds_cluster_cost_sums(0, None, 4, p(n2c), 3, p(sums), None) == -1
     assert lib.vds_cluster_cost_sums(99, p(cost), 4, p(n2c), 3, p(sums), None) == -1
     assert b"bad device" in lib.vds_cluster_cost_sums_error()
+
+
+def make_env(g, R, **kw):
+    env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=int(g["V"]), **kw)
+    env.load_orders(g["o_release_min"], g["o_pickup"], g["o_delivery"])
+    return env
+
+
+@pytest.mark.parametrize("fg", [0, 6])
+def test_slow_path_buckets_are_counted(fg):
+    """vds_read_work[6]: buckets the fast kernel hands to a slower path.  None on an ordinary day; every tick of the crowded
+    cluster when 600 vehicles sit in one cluster (beyond the register / LDS tables of both fast kernels)."""
+    g = load_golden("tiny_kmeans")
+    env = make_env(g, 2, force_generic=fg)
+    env.reset(np.tile(g["veh_node"], (2, 1)))
+    env.run(env.T)
+    assert env.work()["slow_path_buckets"] == 0 and env.main_kernel() == ("k_tick_lanes" if fg == 6 else "k_tick_rows")
+    env.close()
+    g = dict(g); g["V"] = np.int64(600)
+    nodes5 = np.flatnonzero(g["node2cluster"] == 5)
+    init = nodes5[np.arange(600) % nodes5.size].astype(np.int32)[None, :].repeat(2, axis=0)
+    env = make_env(g, 2, idle_cap=640, force_generic=fg)
+    env.reset(init)
+    env.run(20)
+    assert env.work()["slow_path_buckets"] >= 2 * 15
+    env.close()

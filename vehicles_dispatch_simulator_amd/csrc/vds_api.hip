@@ -1367,7 +1367,13 @@ static int read_work_impl(vds_handle *h, int64_t *out) {
     out[0] = 0;
     for (int r = 0; r < h->S.R; ++r) out[0] += std::min(h->last_stepped + 1, h->days[h->replica_day[r]].T);
     out[1] = raw[CNT_ORDERS]; out[2] = raw[CNT_ORDERS] - raw[CNT_REJECTS]; out[3] = raw[CNT_EVALS];
-    out[4] = raw[CNT_ARRIVALS]; out[5] = raw[CNT_DISPATCH]; out[6] = 0; out[7] = 0;
+    out[4] = raw[CNT_ARRIVALS]; out[5] = raw[CNT_DISPATCH]; out[7] = 0;
+    {   // (replica, cluster, tick) buckets the fast kernel handed to a slower path since vds_reset (list beyond the register /
+        // LDS tables, far arrivals, oversize arrival slot, cost block beyond LDS)
+        int e[4] = {0, 0, 0, 0};
+        HIPCHK(h, hipMemcpy(e, h->D.err, sizeof(e), hipMemcpyDeviceToHost));
+        out[6] = e[2];
+    }
     return VDS_OK;
 }
 

@@ -987,6 +987,10 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
         D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
     }
     const unsigned long long badrows = blk_in_lds ? ballot(bad && l16 == 0) : 0ull;
+    {   // buckets that leave the fast path (set aside / deferred): err[2], reported by vds_read_work
+        const unsigned long long offp = ballot(bad && l16 == 0);
+        if (offp != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(offp));
+    }
     if (bad) { rowvalid = false; m = 0; A = 0; }
     const bool any = ballot(rowvalid) != 0;
     const bool big = ballot(m + A > 64) != 0;

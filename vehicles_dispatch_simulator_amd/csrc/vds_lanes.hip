@@ -754,6 +754,10 @@ __device__ __forceinline__ void lanes_wave(const Static &S, const State &D, int 
     const bool slow = S.lane_force_slow != 0 || __ballot(slow_lane) != 0ull || !pre_ok;
     if (!slow) lanes_tick_fast<LG>(S, D, X, m, A, h0, pq, pe, crec0);
     else {
+        {   // buckets that leave the fast path: err[2], reported by vds_read_work
+            const unsigned long long vb = __ballot(X.valid && (lane & (L - 1)) == 0);
+            if (lane == 0) atomicAdd(&D.err[2], __popcll(vb));
+        }
         lanes_tick_slow<LG>(S, D, X, m, A, h0, h1);
         LPROF(11);
 #ifdef VDS_PROF

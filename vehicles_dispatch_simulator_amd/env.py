@@ -289,7 +289,7 @@ class BatchedDispatchEnv:
     def work(self) -> Dict[str, int]:
         out = np.zeros(8, dtype=np.int64)
         self._chk(self._lib.vds_read_work(self._h, _p(out)))
-        return dict(zip(("ticks", "orders", "matches", "evals", "arrivals", "dispatches"), out.tolist()))
+        return dict(zip(("ticks", "orders", "matches", "evals", "arrivals", "dispatches", "slow_path_buckets"), out.tolist()))
 
     def orders(self, r0: int = 0, nr: Optional[int] = None) -> Dict[str, np.ndarray]:
         nr = self.R - r0 if nr is None else nr
