@@ -262,9 +262,9 @@ def main():
     if rank == 0 and world == 1 and a.distinct_days > 1 and a.workload != "cfg5":
         days = workloads.distinct_days(w, a.distinct_days)
         per_days = {"distinct_days": a.distinct_days, "unit": "env-steps*replicas/s",
-                    "note": "same city / vehicles / order count; interleaved: replica r replays day r %% %d (the library regroups: workgroups "
-                            "of 16 replicas of one day through a row -> replica permutation); blocked: day r // %d (the 16 replicas of a workgroup on "
-                            "one day: shared-day code, day looked up per workgroup)" % (a.distinct_days, max(1, R // a.distinct_days))}
+                    "note": "same city / vehicles / order count; interleaved: replica r replays day r %% %d (the library STORES the replicas "
+                            "regrouped by day, every entry point maps the caller's replica index); blocked: day r // %d (the 16 replicas of a "
+                            "workgroup on one day as given: shared-day code, day looked up per workgroup)" % (a.distinct_days, max(1, R // a.distinct_days))}
         for label, rmap in (("interleaved", np.arange(R) % a.distinct_days), ("blocked", np.minimum(np.arange(R) // max(1, R // a.distinct_days), a.distinct_days - 1))):
             env2 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
             env2.load_order_days(days, rmap.astype(np.int32))

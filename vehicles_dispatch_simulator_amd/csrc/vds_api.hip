@@ -85,7 +85,14 @@ struct vds_handle {
     // host mirrors
     std::vector<int> node2cluster, node_local, cl_off, cl_nodes, cost_host;
     std::vector<DayHost> days;         // the loaded order days
-    std::vector<int> replica_day;        // [R]
+    std::vector<int> replica_day;        // [R_ext] by the caller's replica index
+    // Order days per replica with a map that mixes days inside aligned groups of 16: the replicas are stored REGROUPED by day
+    // (state index = "internal" replica; every day's last group of 16 padded with dummy replicas that never run), so that
+    // every workgroup of the fast kernel and every cache line of the [C][R] tables belongs to one day.  Callers keep their
+    // own numbering: every entry point maps.  Empty vectors: identity.
+    int R_ext = 0;                       // vds_config.replicas
+    std::vector<int> int2ext, ext2int;
+    int alloc_R = 0;                     // replica count the state tables were allocated for
     std::vector<void *> dev_allocs;          // static tables, scratch
     std::vector<void *> order_allocs;        // tables of the loaded day (replaced by the next vds_load_orders)
     std::vector<void *> state_allocs;        // per-replica state (kept across days while the capacities still fit)
@@ -401,6 +408,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     HIPCHK(h, hipSetDevice(h->cfg.device));
     Static &S = h->S;
     S.N = N; S.C = C; S.V = h->cfg.vehicles; S.R = h->cfg.replicas;
+    h->R_ext = h->cfg.replicas; S.R_ext = h->R_ext; S.int2ext = nullptr;
     S.tick_minutes = h->cfg.tick_minutes;
     {   // division by the slot length without the ~28-instruction integer-division sequence
         const unsigned long long tk = (unsigned long long)S.tick_minutes;
@@ -612,7 +620,7 @@ static int alloc_state(vds_handle *h, int O) {
     int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
     S.G = (R + 63) / 64;
     if (S.layoutT && (std::max(idle_cap, S.idle_cap) > 65532 || H > 32)) S.layoutT = 0;      // list positions travel in 16 bits, insert ticks in 5
-    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_layoutT >= S.layoutT)
+    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_layoutT >= S.layoutT && h->alloc_R == R)
         return VDS_OK;                                   // another day on the same handle: the state tables still fit
     for (void *p : h->state_allocs) dev_free(p);
     h->state_allocs.clear();
@@ -621,6 +629,7 @@ static int alloc_state(vds_handle *h, int O) {
     // layout T pads the replica dimension of idle / ring to whole groups of 64 (vds_device.h); its tables also hold layout 0
     const size_t BT = S.layoutT ? (size_t)C * S.G * 64 : B;
     h->alloc_layoutT = S.layoutT;
+    h->alloc_R = R;
     int rc;
     struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
     h->alloc_sink = &h->state_allocs;
@@ -671,11 +680,13 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     }
     Static &S = h->S;
     const int N = S.N, C = S.C, tick = S.tick_minutes;
-    h->replica_day.assign(S.R, 0);
-    for (int r = 0; r < S.R; ++r) {
+    const int RX = h->R_ext;
+    S.R = RX; S.int2ext = nullptr; h->int2ext.clear(); h->ext2int.clear();
+    h->replica_day.assign(RX, 0);
+    for (int r = 0; r < RX; ++r) {
         // default map: contiguous blocks of replicas per day - when the blocks are multiples of 16 replicas every workgroup of
-        // the fast kernel sees one day (day mode 1, the shared-day code); an interleaved map costs the per-row variant
-        const int d = replica_day ? replica_day[r] : (int)((long long)r * n_days / S.R);
+        // the fast kernel sees one day (day mode 1, the shared-day code)
+        const int d = replica_day ? replica_day[r] : (int)((long long)r * n_days / RX);
         if (d < 0 || d >= n_days) return fail(h, VDS_EINVAL, "vds_load_order_days: replica %d is mapped to day %d of %d", r, d, n_days);
         h->replica_day[r] = d;
     }
@@ -762,24 +773,41 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         Ototal += O;
     }
     Tmax = 0;                                   // the batch steps as long as its longest day that some replica replays
-    for (int r = 0; r < S.R; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
+    for (int r = 0; r < RX; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
     S.now0 = h->days[0].now0; S.T = Tmax; S.Oq = Oqmax; h->O = Omax;
     S.n_days = n_days;
     S.chunk_days = n_days > 1 ? 1 : 0;
-    for (int r = 0; r < S.R && S.chunk_days; ++r)
+    for (int r = 0; r < RX && S.chunk_days; ++r)
         if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
-    // a map that mixes days inside aligned groups of 16 replicas: k_tick_rows forms its workgroups from the replicas of ONE day
-    // (row slot -> replica permutation, every day's last group padded) instead of giving every 16-lane row its own order stream
-    std::vector<int> rperm;
+    // a map that mixes days inside aligned groups of 16 replicas: the replicas are STORED regrouped by day (see vds_handle),
+    // every day's last group padded with dummy replicas, when the padding stays under a quarter; otherwise every 16-lane row
+    // of the fast kernel gets its own order stream (day mode 2)
+    std::vector<int> rperm;          // row slot -> internal replica, -1 for a dummy (k_tick_rows skips those rows)
+    std::vector<int> day_of_internal;
     if (n_days > 1 && !S.chunk_days && h->cfg.force_generic == 0) {
         std::vector<std::vector<int>> by_day(n_days);
-        for (int r = 0; r < S.R; ++r) by_day[h->replica_day[r]].push_back(r);
+        for (int r = 0; r < RX; ++r) by_day[h->replica_day[r]].push_back(r);
+        std::vector<int> i2e;
         for (int dd = 0; dd < n_days; ++dd) {
-            for (int r : by_day[dd]) rperm.push_back(r);
-            while (rperm.size() % 16) rperm.push_back(-1);
+            for (int r : by_day[dd]) { i2e.push_back(r); day_of_internal.push_back(dd); }
+            while (i2e.size() % 16) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // dummy: replays the empty day
         }
-        if (rperm.size() * 4 <= (size_t)S.R * 5) S.chunk_days = 1;      // at most a quarter of padding; else per-row order streams
-        else rperm.clear();
+        if (i2e.size() * 4 <= (size_t)RX * 5) {
+            S.chunk_days = 1;
+            S.R = (int)i2e.size();
+            h->int2ext = i2e;
+            h->ext2int.assign(RX, -1);
+            for (int i = 0; i < S.R; ++i) if (i2e[i] >= 0) h->ext2int[i2e[i]] = i;
+            rperm.resize(S.R);
+            for (int i = 0; i < S.R; ++i) rperm[i] = i2e[i] >= 0 ? i : -1;
+        } else {
+            day_of_internal.clear();
+        }
+    }
+    if (day_of_internal.empty()) day_of_internal = h->replica_day;
+    if (!h->int2ext.empty()) {       // the empty day of the dummy replicas: over before its first slot
+        DayDesc e{}; e.bkt_base = 0; e.tick_base = 0; e.now0 = h->days[0].now0; e.T = 0; e.q_base = 0; e.Oq = 0; e.max_tick_orders = 0; e.pad = 0;
+        ddesc.push_back(e);
     }
     S.max_tick_orders = mto;
     int rc;
@@ -839,10 +867,11 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         if (!so_lb.empty()) { unsigned char *dl; if ((rc = upload(h, &dl, so_lb))) return rc; S.so_lb = dl; }
     }
     { DayDesc *dd; if ((rc = upload(h, &dd, ddesc))) return rc; S.day = dd; }
-    if ((rc = upload(h, &d, h->replica_day))) return rc; S.replica_day = d;
+    if ((rc = upload(h, &d, day_of_internal))) return rc; S.replica_day = d;
+    if (!h->int2ext.empty()) { if ((rc = upload(h, &d, h->int2ext))) return rc; S.int2ext = d; }
     {
         std::vector<int4> rdesc(S.R);
-        for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[h->replica_day[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
+        for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[day_of_internal[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
         int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
     }
     // ---- lanes tick (k_tick_lanes, layout T: lane = replica): one shared order day, byte costs <= 254, no neighbour search.
@@ -1010,7 +1039,7 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
     if (!veh_init_node && h->S.V > 0) return fail(h, VDS_EINVAL, "vds_reset: null veh_init_node");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const Static &S = h->S;
-    const size_t n = (size_t)S.R * S.V;
+    const size_t n = (size_t)h->R_ext * S.V;
     for (size_t i = 0; i < n; ++i) {
         int node = veh_init_node[i];
         if (node < 0 || node >= S.N || h->node2cluster[node] < 0)
@@ -1021,7 +1050,7 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
         // An explicit vds_config.idle_cap is taken as given (overflow is then reported, never silently grown).
         std::vector<int> cnt((size_t)S.C);
         int fullest = 0;
-        for (int r = 0; r < S.R; ++r) {
+        for (int r = 0; r < h->R_ext; ++r) {
             std::fill(cnt.begin(), cnt.end(), 0);
             const int32_t *vn = veh_init_node + (size_t)r * S.V;
             for (int v = 0; v < S.V; ++v) fullest = std::max(fullest, ++cnt[h->node2cluster[vn[v]]]);
@@ -1213,7 +1242,7 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) {
         order[i] = i;
-        if (replica[i] < 0 || replica[i] >= S.R || from_cluster[i] < 0 || from_cluster[i] >= S.C)
+        if (replica[i] < 0 || replica[i] >= h->R_ext || from_cluster[i] < 0 || from_cluster[i] >= S.C)
             return fail(h, VDS_EINVAL, "vds_apply_dispatch: action %d: replica/cluster out of range", i);
         if (target_node[i] < 0 || target_node[i] >= S.N || h->node2cluster[target_node[i]] < 0)
             return fail(h, VDS_ESTATE, "vds_apply_dispatch: action %d: target node %d is in no cluster", i, target_node[i]);
@@ -1239,7 +1268,7 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
     for (int k = 0; k < n; ++k) {
         int i = order[k];
         if (k == 0 || replica[i] != replica[order[k - 1]] || from_cluster[i] != from_cluster[order[k - 1]]) grp_off.push_back(k);
-        pack[k] = replica[i]; pack[(size_t)n + k] = from_cluster[i]; pack[(size_t)2 * n + k] = idle_pos[i];
+        pack[k] = h->ext2int.empty() ? replica[i] : h->ext2int[replica[i]]; pack[(size_t)n + k] = from_cluster[i]; pack[(size_t)2 * n + k] = idle_pos[i];
         pack[(size_t)3 * n + k] = target_node[i]; pack[(size_t)4 * n + k] = h->dispatch_seq + i;   // dict insertion order = action order
         pack[(size_t)5 * n + k] = arrive_min ? arrive_min[i] : 0; pack[(size_t)6 * n + k] = counted ? counted[i] : 1;
     }
@@ -1275,7 +1304,7 @@ int vds_obs_device(vds_handle *h, void **dev_ptr) {
 static int read_obs_impl(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {
     int rc = vds_obs_device(h, nullptr);
     if (rc) return rc;
-    const size_t RC = (size_t)h->S.R * h->S.C;
+    const size_t RC = (size_t)h->R_ext * h->S.C;
     int32_t *dst[5] = {idle_pre, idle_now, supply, cl_orders, inflight};
     for (int k = 0; k < 5; ++k)
         if (dst[k]) HIPCHK(h, hipMemcpyAsync(dst[k], h->d_obs + k * RC, RC * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1317,11 +1346,11 @@ static int read_counters_impl(vds_handle *h, int64_t *out) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     launch_reduce_counters(h->S, h->D, h->d_cnt_per, h->d_cnt_tot, h->stream);
     HIPCHK(h, hipGetLastError());
-    std::vector<long long> raw((size_t)h->S.R * CNT_WORDS);
+    std::vector<long long> raw((size_t)h->R_ext * CNT_WORDS);
     HIPCHK(h, hipMemcpyAsync(raw.data(), h->d_cnt_per, raw.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     int rc = vds_sync(h);
     if (rc) return rc;
-    for (int r = 0; r < h->S.R; ++r) finish_counters(h, r, raw.data() + (size_t)r * CNT_WORDS, out + (size_t)r * VDS_NUM_COUNTERS);
+    for (int r = 0; r < h->R_ext; ++r) finish_counters(h, r, raw.data() + (size_t)r * CNT_WORDS, out + (size_t)r * VDS_NUM_COUNTERS);
     return VDS_OK;
 }
 
@@ -1340,7 +1369,7 @@ static int reduce_counters_impl(vds_handle *h, int64_t *out, void **dev_ptr) {
         int64_t tmp[VDS_NUM_COUNTERS];
         finish_counters(h, 0, raw, tmp);
         long long rest = 0;
-        for (int r = 0; r < h->S.R; ++r) rest += unprocessed_value(h, r);
+        for (int r = 0; r < h->R_ext; ++r) rest += unprocessed_value(h, r);
         tmp[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + rest;
         memcpy(out, tmp, sizeof(tmp));
     }
@@ -1365,7 +1394,7 @@ static int read_work_impl(vds_handle *h, int64_t *out) {
     int rc = vds_sync(h);
     if (rc) return rc;
     out[0] = 0;
-    for (int r = 0; r < h->S.R; ++r) out[0] += std::min(h->last_stepped + 1, h->days[h->replica_day[r]].T);
+    for (int r = 0; r < h->R_ext; ++r) out[0] += std::min(h->last_stepped + 1, h->days[h->replica_day[r]].T);
     out[1] = raw[CNT_ORDERS]; out[2] = raw[CNT_ORDERS] - raw[CNT_REJECTS]; out[3] = raw[CNT_EVALS];
     out[4] = raw[CNT_ARRIVALS]; out[5] = raw[CNT_DISPATCH]; out[7] = 0;
     {   // (replica, cluster, tick) buckets the fast kernel handed to a slower path since vds_reset (list beyond the register /
@@ -1380,7 +1409,7 @@ static int read_work_impl(vds_handle *h, int64_t *out) {
 static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *status, int32_t *vehicle, int32_t *wait) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_read_orders: call vds_reset first");
     const Static &S = h->S;
-    if (r0 < 0 || nr < 0 || r0 + nr > S.R) return fail(h, VDS_EINVAL, "vds_read_orders: replica range out of bounds");
+    if (r0 < 0 || nr < 0 || r0 + nr > h->R_ext) return fail(h, VDS_EINVAL, "vds_read_orders: replica range out of bounds");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = vds_sync(h);
     if (rc) return rc;
@@ -1392,6 +1421,9 @@ static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *stat
         HIPCHK(h, hipMemcpy2D(cols.data(), (size_t)nr * sizeof(int2), h->D.out + r0, (size_t)S.G * 64 * sizeof(int2), (size_t)nr * sizeof(int2), Oq, hipMemcpyDeviceToHost));
         for (int q = 0; q < Oq; ++q)
             for (int r = 0; r < nr; ++r) res[(size_t)r * Oq + q] = cols[(size_t)q * nr + r];
+    } else if (Oq > 0 && nr > 0 && !h->ext2int.empty()) {
+        for (int r = 0; r < nr; ++r)       // regrouped storage: the caller's replica r0 + r lives in row ext2int[r0 + r]
+            HIPCHK(h, hipMemcpy(res.data() + (size_t)r * Oq, h->D.out + (size_t)h->ext2int[r0 + r] * Oq, (size_t)Oq * sizeof(int2), hipMemcpyDeviceToHost));
     } else if (Oq > 0 && nr > 0)
         HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)r0 * Oq, (size_t)nr * Oq * sizeof(int2), hipMemcpyDeviceToHost));
     for (int r = 0; r < nr; ++r) {
@@ -1421,7 +1453,9 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
                    int32_t *arr_off, int32_t *arr_veh, int32_t *arr_min, int32_t *arr_order, int32_t *arr_node) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_read_lists: call vds_reset first");
     const Static &S = h->S;
-    if (replica < 0 || replica >= S.R) return fail(h, VDS_EINVAL, "vds_read_lists: replica out of range");
+    if (replica < 0 || replica >= h->R_ext) return fail(h, VDS_EINVAL, "vds_read_lists: replica out of range");
+    const int replica_ext = replica;
+    if (!h->ext2int.empty()) replica = h->ext2int[replica];          // row of the regrouped tables
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = vds_sync(h);
     if (rc) return rc;
@@ -1456,7 +1490,7 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
     }
     if (want_arr) {
         // parity holding far posts not yet drained; a replica whose day is over stopped at ITS last tick
-        const int last = std::min(h->last_stepped, h->days[h->replica_day[replica]].T - 1);
+        const int last = std::min(h->last_stepped, h->days[h->replica_day[replica_ext]].T - 1);
         const int np = (last + 1) & 1;
         const int H = S.H;
         std::vector<int4> fl((size_t)C * S.fl_cap), inb((size_t)C * S.in_cap), ring((size_t)H * C * S.ring_cap);
@@ -1676,7 +1710,7 @@ int vds_load_orders_strided(vds_handle *h, const int32_t *release_min, const int
 }
 
 int vds_replica_ticks(const vds_handle *h, int32_t replica, int32_t *T, int32_t *n_orders) {
-    if (!h || !h->have_orders || replica < 0 || replica >= h->S.R) return VDS_EINVAL;
+    if (!h || !h->have_orders || replica < 0 || replica >= h->R_ext) return VDS_EINVAL;
     const DayHost &H = h->days[h->replica_day[replica]];
     if (T) *T = H.T;
     if (n_orders) *n_orders = H.O;

@@ -70,7 +70,11 @@ struct DayDesc {
 struct DayView { const int *bkt_off; const int *tick_off; int now0, T, q_base; };
 
 struct Static {
-    int N, C, V, R, Oq, T;           // Oq: result slots per replica (max over days); T: longest day
+    int N, C, V, R, Oq, T;           // R: replicas the tables hold; Oq: result slots per replica (max over days); T: longest day
+    int R_ext;                       // replicas the caller sees (vds_config.replicas); R >= R_ext when the replicas are stored regrouped
+    const int *int2ext;              // [R] stored ("internal") replica -> the caller's replica index, -1 for a padding replica that
+                                     // never runs; null: identity.  Order days per replica with a map that mixes days inside aligned
+                                     // groups of 16 replicas: the library stores the replicas grouped by day (vds_api.hip)
     int n_days;                      // 1: one order stream shared by every replica (the fast path of k_tick_rows)
     const int *rperm;                // [rslots] k_tick_rows row slot -> replica, grouped by order day in groups of 16 (-1 padding); null: identity
     int rslots;

@@ -153,9 +153,10 @@ __global__ __launch_bounds__(256) void k_reset(Static S, State D, const int *veh
     const int lane = lane_id();
     const size_t b = (size_t)c * S.R + r;
     const IdleRef idle = idle_ref(S, D, c, r);
-    const int *vn = veh_node + (size_t)r * S.V;
+    const int ext = S.int2ext ? S.int2ext[r] : r;          // the caller's replica: its row of start nodes (padding replica: no vehicles)
+    const int *vn = veh_node + (size_t)(ext < 0 ? 0 : ext) * S.V;
     int count = 0;
-    for (int base = 0; base < S.V; base += WAVE) {
+    for (int base = 0; base < (ext < 0 ? 0 : S.V); base += WAVE) {
         int v = base + lane;
         int node = v < S.V ? vn[v] : -1;
         bool mine = node >= 0 && S.node2cluster[node] == c;
@@ -186,8 +187,10 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();   // wave-uniform: keep it scalar
     const int C = S.C;
     const int seg = (((S.V + RESET_WAVES - 1) / RESET_WAVES) + WAVE - 1) / WAVE * WAVE;
-    const int v0 = min(S.V, wave * seg), v1 = min(S.V, v0 + seg);
-    const int *vn = veh_node + (size_t)r * S.V;
+    const int ext = S.int2ext ? S.int2ext[r] : r;          // the caller's replica: its row of start nodes (padding replica: no vehicles)
+    const int nveh = ext < 0 ? 0 : S.V;
+    const int v0 = min(nveh, wave * seg), v1 = min(nveh, v0 + seg);
+    const int *vn = veh_node + (size_t)(ext < 0 ? 0 : ext) * S.V;
     int *mine = lds_dyn + wave * C;
     for (int i = threadIdx.x; i < RESET_WAVES * C; i += blockDim.x) lds_dyn[i] = 0;
     __syncthreads();
@@ -3903,6 +3906,7 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
     const size_t RC = (size_t)S.R * S.C;
+    const size_t RCX = (size_t)S.R_ext * S.C;      // the block is laid out by the caller's replica index
     {
         const int r = r0 + tx, c = c0 + ty;
         if (r < S.R && c < S.C) {
@@ -3922,10 +3926,11 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
     __syncthreads();
     {
         const int r = r0 + ty, c = c0 + tx;
-        if (r < S.R && c < S.C) {
-            const size_t i = (size_t)r * S.C + c;
+        const int ext = (r < S.R && S.int2ext) ? S.int2ext[r] : r;
+        if (r < S.R && c < S.C && ext >= 0) {
+            const size_t i = (size_t)ext * S.C + c;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) obs[k * RC + i] = tile[k][tx][ty];
+            for (int k = 0; k < 5; ++k) obs[k * RCX + i] = tile[k][tx][ty];
         }
     }
 }
@@ -3951,7 +3956,10 @@ __global__ __launch_bounds__(256) void k_reduce_counters(Static S, State D, long
     }
     part[slice][threadIdx.x & 63] = s;
     __syncthreads();
-    if (slice == 0 && i < n) out[i] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (slice == 0 && i < n) {
+        const int ext = S.int2ext ? S.int2ext[i / CNT_WORDS] : i / CNT_WORDS;       // per-replica rows in the caller's order
+        if (ext >= 0) out[(size_t)ext * CNT_WORDS + (i % CNT_WORDS)] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    }
 }
 
 __global__ void k_total_counters(int R, const long long *per, long long *tot) {
@@ -3977,7 +3985,9 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
     const int lane = lane_id();
     const DayView dvw = day_view(S, r);
     const int now = dvw.now0 + t * S.tick_minutes;
-    const int *act = actions + (size_t)r * K * 3;
+    const int ext = S.int2ext ? S.int2ext[r] : r;          // the action tensor is indexed by the caller's replica
+    if (ext < 0) return;
+    const int *act = actions + (size_t)ext * K * 3;
     if (t >= dvw.T) {
         // the replica's day is over (:1048), its city stands still: actions are refused (reported by the next vds_sync)
         bool any = false;
@@ -4184,7 +4194,7 @@ void launch_pack_obs(const Static &S, const State &D, int t, int *obs, hipStream
 void launch_reduce_counters(const Static &S, const State &D, long long *per, long long *tot, hipStream_t st) {
     int n = S.R * CNT_WORDS;
     hipLaunchKernelGGL(k_reduce_counters, dim3((n + 63) / 64), dim3(256), 0, st, S, D, per);
-    hipLaunchKernelGGL(k_total_counters, dim3(CNT_WORDS), dim3(64), 0, st, S.R, per, tot);
+    hipLaunchKernelGGL(k_total_counters, dim3(CNT_WORDS), dim3(64), 0, st, S.R_ext, per, tot);
 }
 
 void launch_selftest_dpp(const int *in, int *o0, int *o1, int *o2, int *o3, int nwaves, hipStream_t st) {
