@@ -128,7 +128,11 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 // a full HBM round trip per use - nothing waits for the global loads / stores in flight (the ISA shows at most
 // s_waitcnt lgkmcnt(0)).  wave_order(): between accesses of different lanes of ONE wavefront to its own scratch;
 // wg_order(): between the wavefronts of a workgroup (k_dfs_walk's flags, records and stamps).
+#ifdef EXP_WO
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_sched_barrier(0); }
+#else
 __device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
+#endif
 __device__ __forceinline__ void wg_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); }
 
 // ---------------------------------------------------------------------------------------
@@ -238,12 +242,15 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
 // ---------------------------------------------------------------------------------------
 // Arrival posting.  An entry goes to the ring slot of the tick at which UpdateFunction will see
 // `arrive <= RealExpTime` (:1016) - or, when that is >= H ticks away, to the destination's far inbox.
+// LT: the caller may run on layout T tables (reset / dispatch kernels, shared by both layouts); the tick kernels of this file
+// only ever see layout 0 and leave the branch out (k_tick_rows sits exactly at its 72-VGPR budget)
+template <bool LT = false>
 __device__ __forceinline__ void ring_post(const Static &S, const State &D, int dc, int r, int tick, int4 e) {
     const size_t i = ((size_t)(tick & (S.H - 1)) * S.C + dc) * S.R + r;
     const int old = atomicAdd(&D.ring_cnt[i], meta_is_dispatch(e.w) ? 1 : 0x10001);   // high half: carries an order (:889)
     const int pos = old & 0xFFFF;
     if (pos >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
-    else if (S.layoutT) D.ring[ringT_base(S, tick & (S.H - 1), dc, r) + (size_t)pos * 64] = e;
+    else if (LT && S.layoutT) D.ring[ringT_base(S, tick & (S.H - 1), dc, r) + (size_t)pos * 64] = e;
     else D.ring[i * S.ring_cap + pos] = e;
 }
 
@@ -256,14 +263,14 @@ __device__ __forceinline__ int ticks_until(const Static &S, int rel) {
     return n / S.tick_minutes;
 }
 
-template <bool SMALL = false>
+template <bool SMALL = false, bool LT = false>
 __device__ __forceinline__ void post_arrival(const Static &S, const State &D, int dc, int r, int t, int now,
                                              int veh, int id, int arrive, int is_dispatch, int dest_local) {
     const int rel = arrive - now;
     const int d = rel <= 0 ? 1 : ticks_until<SMALL>(S, rel);   // next Update is at t+1 at the earliest
     const int4 e = make_int4(veh, id, arrive, meta_pack(t, is_dispatch, dest_local));
     if (d < S.H) {
-        ring_post(S, D, dc, r, t + d, e);
+        ring_post<LT>(S, D, dc, r, t + d, e);
     } else {
         const size_t db = (size_t)dc * S.R + r;
         const int np = (t + 1) & 1;
@@ -733,7 +740,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
                 if (abl & 32) { int o = atomicAdd(&D.ring_cnt[i], 0); if (o == 0x7FFFFFF1) D.err[1] = o; }
                 if (abl & 64) D.ring[i * S.ring_cap + (rr.x & 7)] = make_int4(vid, rr.x, now + rel, 0);
             } else {
-                post_arrival<true>(S, D, rr.z & 0xFFFF, r, t, now, vid, rr.x, now + wait + rr.w, 0, (int)((unsigned)rr.y >> 16));
+                post_arrival<true, false>(S, D, rr.z & 0xFFFF, r, t, now, vid, rr.x, now + wait + rr.w, 0, (int)((unsigned)rr.y >> 16));
             }
         }
         wsum += matched ? wait : 0;
@@ -808,14 +815,19 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
             if (a * 16 < Amax) {           // wave-uniform: usually only the first 16 arrival slots exist
                 if (idx < A) e[a] = (a == 0 && pf_ring) ? pf_ring[grow * 16 + l16] : ring[idx];
                 key[a] = entry_key(e[a].y, e[a].w);
+#ifdef EXP_KEYMERGE
+                if (idx < A) key_row[idx] = key[a];
+#endif
             }
         }
+#ifndef EXP_KEYMERGE
         wave_order();            // (the prefetched entries sit in the key scratch: every row has read its own before keys are written)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int idx = a * 16 + l16;
             if (a * 16 < Amax && idx < A) key_row[idx] = key[a];
         }
+#endif
         wave_order();
         int rank[4] = {0, 0, 0, 0};
         if (Amax <= 16) {           // common case: one arrival per lane
@@ -990,10 +1002,12 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
         D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
     }
     const unsigned long long badrows = blk_in_lds ? ballot(bad && l16 == 0) : 0ull;
+#ifndef EXP_NOCNT
     {   // buckets that leave the fast path (set aside / deferred): err[2], reported by vds_read_work
         const unsigned long long offp = ballot(bad && l16 == 0);
         if (offp != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(offp));
     }
+#endif
     if (bad) { rowvalid = false; m = 0; A = 0; }
     const bool any = ballot(rowvalid) != 0;
     const bool big = ballot(m + A > 64) != 0;
@@ -3860,7 +3874,7 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
                 uint2 e = idle.get(pos);
                 int tc = S.node2cluster[tgt];
                 cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
-                post_arrival(S, D, tc, r, t, now, (int)e.x, a_seq[a], a_arrive ? a_arrive[a] : now + cst, 1, S.node_local[tgt]);
+                post_arrival<false, true>(S, D, tc, r, t, now, (int)e.x, a_seq[a], a_arrive ? a_arrive[a] : now + cst, 1, S.node_local[tgt]);
                 ok = true;
                 counted = !(a_counted && !a_counted[a]);
             } else {
@@ -4037,7 +4051,7 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
                 if (pos >= 0 && pos < m) {
                     const uint2 e = idle.get(pos);
                     cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
-                    post_arrival(S, D, tc, r, t, now, (int)e.x, seq_base + k, now + cst, 1, S.node_local[tgt]);
+                    post_arrival<false, true>(S, D, tc, r, t, now, (int)e.x, seq_base + k, now + cst, 1, S.node_local[tgt]);
                     ok = true;
                 } else {
                     atomicOr(&D.err[0], ERR_DISPATCH);
