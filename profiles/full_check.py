@@ -1,5 +1,5 @@
 """Full-scale parity: EVERY replica of the bench workload against the CPU oracle (per-order status / vehicle / wait
-and counters, bit-exact).   python profiles/full_check.py [cfg2|cfg4] [replicas] [distinct days] [interleaved|blocked]"""
+and counters, bit-exact).   python profiles/full_check.py [cfg2|cfg4] [replicas] [distinct days] [interleaved|blocked] [force_generic]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -13,11 +13,12 @@ D = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 mapping = sys.argv[4] if len(sys.argv) > 4 else "interleaved"
 days = workloads.distinct_days(w, D)
 rd = (np.arange(R) % D) if mapping == "interleaved" else (np.arange(R) * D // R)
+FG = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 if D > 1:
-    env = w.make_env(R, load=False)
+    env = w.make_env(R, load=False, force_generic=FG)
     env.load_order_days(days, rd.astype(np.int32))
 else:
-    env = w.make_env(R)
+    env = w.make_env(R, force_generic=FG)
 env.reset(init)
 env.run(env.T)
 cn = env.counters()

@@ -100,9 +100,17 @@ def run_case(seed, case, idle_cap=None):
     R, N = cfg["R"], cost.shape[0]
     rng = np.random.default_rng(1000 + seed)
     init = rng.choice(valid_nodes, size=(R, V)).astype(np.int32) if V else np.zeros((R, 0), np.int32)
+    # half of the cases that would run the default kernels take the lanes tick (k_tick_lanes) instead, with random lanes per
+    # bucket / LDS table sizes / forced slow path (its own random stream: the cases above stay what they were); with neighbour
+    # search or costs beyond a byte the library falls back to its usual choice
+    lr = np.random.default_rng(90_000 + seed)
+    fg, kw = cfg["force_generic"], {}
+    if fg == 0 and lr.random() < 0.5:
+        fg = 6
+        kw["lanes_debug"] = (int(lr.integers(-1, 4)), int(lr.choice([0, 16, 32])), int(lr.choice([0, 8, 16])), int(lr.random() < 0.15))
     env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
                              tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
-                             force_generic=cfg["force_generic"], idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V))
+                             force_generic=fg, idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V), **kw)
     env.load_orders(rel, pick, dele)
     env.reset(init)
     oracles = []
