@@ -139,7 +139,7 @@ static int fail(vds_handle *h, int code, const char *fmt, ...) {
 // the next check - and an out-of-bounds READ returns the poison (0xA5A5A5A5: a negative count / index), which the parity tests
 // then see as a wrong result or a fault at a far-away address, instead of whatever the neighbouring table happened to hold.
 #ifdef VDS_CANARY
-static const size_t GUARD_FRONT = 64u << 10, GUARD_BACK = 1u << 20;
+static const size_t GUARD_FRONT = 64u << 10, GUARD_BACK = 256u << 10;
 static const bool GUARDED = true;
 #else
 static const size_t GUARD_FRONT = 0, GUARD_BACK = 0;
@@ -1468,11 +1468,14 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
         std::vector<uint2> idle((size_t)C * S.idle_cap);
         if (S.layoutT) {
             // quads of four packed entries {veh << 8 | loc}: [C][G][idle_cap / 4][64][4]; this replica's column of every quad row
-            std::vector<unsigned> pk((size_t)C * S.idle_cap);
-            const size_t rows_per_c = (size_t)(S.idle_cap >> 2), pitch = 64 * 4 * sizeof(unsigned);
-            for (int c = 0; c < C; ++c)
-                HIPCHK(h, hipMemcpy2D(pk.data() + (size_t)c * S.idle_cap, 4 * sizeof(unsigned), reinterpret_cast<const unsigned *>(h->D.idle) + idleT_base(S, c, replica), pitch, 4 * sizeof(unsigned), rows_per_c, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < pk.size(); ++i) idle[i] = make_uint2(pk[i] >> 8, pk[i] & 0xFFu);
+            // one strided copy of the replica's column over every (cluster, group, quad) row, then its group's rows are picked
+            const size_t rows_per_c = (size_t)(S.idle_cap >> 2), pitch = 64 * 4 * sizeof(unsigned), rows = (size_t)C * S.G * rows_per_c;
+            std::vector<unsigned> col(rows * 4);
+            HIPCHK(h, hipMemcpy2D(col.data(), 4 * sizeof(unsigned), reinterpret_cast<const unsigned *>(h->D.idle) + (size_t)(replica & 63) * 4, pitch, 4 * sizeof(unsigned), rows, hipMemcpyDeviceToHost));
+            for (int c = 0; c < C; ++c) {
+                const unsigned *src = col.data() + ((size_t)c * S.G + (size_t)(replica >> 6)) * rows_per_c * 4;
+                for (int e = 0; e < S.idle_cap; ++e) idle[(size_t)c * S.idle_cap + e] = make_uint2(src[e] >> 8, src[e] & 0xFFu);
+            }
         } else
         HIPCHK(h, hipMemcpy2D(idle.data(), S.idle_cap * sizeof(uint2), h->D.idle + (size_t)replica * S.idle_cap, (size_t)R * S.idle_cap * sizeof(uint2), S.idle_cap * sizeof(uint2), C, hipMemcpyDeviceToHost));
         int n = 0;
@@ -1497,10 +1500,13 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
         std::vector<int> rcnt((size_t)H * C);
         HIPCHK(h, hipMemcpy2D(fl.data(), S.fl_cap * sizeof(int4), h->D.fl + (size_t)replica * S.fl_cap, (size_t)R * S.fl_cap * sizeof(int4), S.fl_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy2D(inb.data(), S.in_cap * sizeof(int4), h->D.inbox + ((size_t)np * C * R + replica) * S.in_cap, (size_t)R * S.in_cap * sizeof(int4), S.in_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
-        if (S.layoutT)      // [H][C][G][ring_cap][64]: this replica's column; rows = (slot, cluster, entry) after skipping the other groups
+        if (S.layoutT) {    // [H][C][G][ring_cap][64]: one strided copy of the replica's column over every row, its group's rows picked
+            const size_t rows = (size_t)H * C * S.G * S.ring_cap;
+            std::vector<int4> col(rows);
+            HIPCHK(h, hipMemcpy2D(col.data(), sizeof(int4), h->D.ring + (replica & 63), 64 * sizeof(int4), sizeof(int4), rows, hipMemcpyDeviceToHost));
             for (int sc = 0; sc < H * C; ++sc)
-                HIPCHK(h, hipMemcpy2D(ring.data() + (size_t)sc * S.ring_cap, sizeof(int4), h->D.ring + ringT_base(S, sc / C, sc % C, replica), 64 * sizeof(int4), sizeof(int4), S.ring_cap, hipMemcpyDeviceToHost));
-        else
+                memcpy(ring.data() + (size_t)sc * S.ring_cap, col.data() + ((size_t)sc * S.G + (size_t)(replica >> 6)) * S.ring_cap, (size_t)S.ring_cap * sizeof(int4));
+        } else
         HIPCHK(h, hipMemcpy2D(ring.data(), S.ring_cap * sizeof(int4), h->D.ring + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(int4), S.ring_cap * sizeof(int4), (size_t)H * C, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy2D(rcnt.data(), sizeof(int), h->D.ring_cnt + replica, (size_t)R * sizeof(int), sizeof(int), (size_t)H * C, hipMemcpyDeviceToHost));
         int n = 0;
