@@ -64,6 +64,8 @@ SYMBOLS = {
     "vds_apply_dispatch_device": (C.c_int, [_VP, _I32, _VP]),
     "vds_advance": (C.c_int, [_VP]),
     "vds_run": (C.c_int, [_VP, _I32]),
+    "vds_set_run_groups": (C.c_int, [_VP, _I32, _I32]),
+    "vds_get_run_groups": (C.c_int, [_VP]),
     "vds_sync": (C.c_int, [_VP]),
     "vds_clock": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
     "vds_read_obs": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <exception>
 #include <map>
 #include <new>
@@ -24,6 +25,8 @@ void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
+void emit_hybrid_rows(const Emit &, const Static &, const State &, int, int, int, int);
+void emit_hybrid_walk(const Emit &, const Static &, const State &, int, int, int);
 size_t lanes_lds_bytes(const Static &, int *);
 int lanes_prepare(const Static &);
 void lanes_read_prof(unsigned long long *, hipStream_t);
@@ -110,11 +113,14 @@ struct vds_handle {
     // vds_run as one hipGraph: the launches of ticks [run_t0, run_t0 + run_n) captured once, replayed while nothing they
     // depend on (tables, capacities, stream) has changed
     hipGraphExec_t run_exec = nullptr;
-    int run_t0 = -1, run_n = 0;
+    int run_t0 = -1, run_n = 0, run_G = 1;
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    // vds_run of the hybrid neighbour-search tick: replica GROUPS on streams (run_grouped)
+    int run_groups = -1;                     // -1: ask VDS_RUN_GROUPS (default: by replica count, run_group_count)
+    int run_stagger = -1;                    // -1: ask VDS_RUN_STAGGER (default 1)
 };
 
 static int fail(vds_handle *h, int code, const char *fmt, ...) {
@@ -203,9 +209,34 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
 #define LANES_AUTO_MIN_R (1 << 30)
 #endif
 
+// replica groups of vds_run in hybrid neighbour-search mode (see run_grouped)
+// defaults (measured at configs[3], one box: R = 1024 272 -> 249 us per tick with 3 groups, 2 groups 257; R = 512 197 -> 188
+// with 2 groups.  4 groups collapse to 378 us: the runtime gives every branch of the graph a stream next to the launching one,
+// and from five streams on they share hardware queues - captured from forked streams, where one branch stays on the launching
+// stream, 4 groups ran at 244 us and 6 collapsed: profiles/r03_run_groups/notes.md)
+#ifndef RUN_GROUPS_MIN_R
+#define RUN_GROUPS_MIN_R 512
+#endif
+#ifndef RUN_GROUPS_BIG_R
+#define RUN_GROUPS_BIG_R 1024
+#endif
+#define RUN_GROUPS_MAX 16
+
+// hipGraphExecDestroy of a graph WITH PARALLEL BRANCHES (the replica groups of vds_run) needs a quiet device and a quiet
+// runtime: destroyed right after hipStreamSynchronize - or later, while another such graph runs - it races with the runtime's
+// completion handler (ROCm 7.0 libamdhip64: the HSA signal-handler thread is still releasing commands: abort / SIGSEGV in
+// free() under amd::roc::VirtualGPU::updateCommandsState, 5 of 6 runs of profiles/r03_run_groups/crash_probe.py; captured and
+// explicitly built graphs alike; hipDeviceSynchronize alone does not help: profiles/r03_run_groups/notes.md).  What held in every run: device synchronised, then
+// a pause, then the destruction.  It happens once per re-built day graph (new order tables, new run shape, vds_destroy).
+#define GRAPH_QUIET_US 50000
 static void drop_run_graph(vds_handle *h) {
-    if (h->run_exec) { (void)hipGraphExecDestroy(h->run_exec); h->run_exec = nullptr; }
-    h->run_t0 = -1; h->run_n = 0;
+    if (h->run_exec) {
+        if (h->run_stream) (void)hipStreamSynchronize(h->run_stream);      // (it may still be running)
+        if (h->run_G > 1) { (void)hipDeviceSynchronize(); usleep(GRAPH_QUIET_US); }
+        (void)hipGraphExecDestroy(h->run_exec);
+        h->run_exec = nullptr;
+    }
+    h->run_t0 = -1; h->run_n = 0; h->run_G = 1;
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1167,21 +1198,99 @@ static int run_eager(vds_handle *h, int32_t n_ticks) {
     return VDS_OK;
 }
 
+// ---- vds_run of the hybrid neighbour-search tick: replica groups as parallel branches of the day graph.
+// One hybrid tick = k_tick_rows in stamp mode (VALU-bound, fills the chip) + k_dfs_walk (one workgroup per replica, a
+// dependency chain of ~50 dry orders: ~150 us whatever the replica count, the CUs mostly idle).  Replicas never interact, so
+// the replicas are split into G groups (boundaries at multiples of 16 = one k_tick_rows workgroup) and every group runs its own
+// chain rows(t) -> walk(t) -> rows(t + 1) -> ... as a branch of the graph: the rows kernel of one group executes under the
+// walks of the others.  stagger 2: the rows kernels are serialised round-robin over the groups by extra edges (rows of group
+// g after the rows of group g - 1; group 0 after the last group's rows of the previous tick); 1 (default): only the first
+// tick is staggered that way, then the groups run free; 0: free-running from the start.  (Measured: 1 = 0 >= 2.)
+// Hooked stepping (vds_step) stays one launch pair over all replicas: the hook needs every replica at the same slot.
+static int run_group_count(vds_handle *h) {
+    if (!(h->dfs_mode && h->hybrid_ok && h->cfg.force_generic == 0) || h->S.rperm != nullptr) return 1;
+    if (h->run_groups < 0) {
+        const char *v = getenv("VDS_RUN_GROUPS");
+        h->run_groups = (v && *v) ? atoi(v) : 0;
+    }
+    if (h->run_stagger < 0) {
+        const char *v = getenv("VDS_RUN_STAGGER");
+        h->run_stagger = (v && *v) ? atoi(v) : 1;
+    }
+    if (!h->use_graph) return 1;             // (groups only as branches of the day's graph: see vds_run)
+    // default: 3 groups from 1024 replicas on, 2 from 512 on
+    int G = h->run_groups > 0 ? h->run_groups : (h->S.R >= RUN_GROUPS_BIG_R ? 3 : (h->S.R >= RUN_GROUPS_MIN_R ? 2 : 1));
+    const int chunks = (h->S.R + 15) / 16;
+    if (G > chunks) G = chunks;
+    if (G > RUN_GROUPS_MAX) G = RUN_GROUPS_MAX;
+    return G < 1 ? 1 : G;
+}
+
+// the day graph with the replica groups as parallel branches, built node by node (kernel nodes with explicit dependencies; no
+// streams or events are involved)
+static int build_group_graph(vds_handle *h, int32_t n_ticks, int G, hipGraph_t *out) {
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipGraphCreate(&g, 0));
+    const int chunks = (h->S.R + 15) / 16;
+    std::vector<hipGraphNode_t> last(G, nullptr);       // the group's latest walk
+    hipGraphNode_t prev_rows = nullptr;
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < n_ticks && err == hipSuccess; ++i) {
+        const int t = h->t + i;
+        for (int gi = 0; gi < G && err == hipSuccess; ++gi) {
+            const int c0 = (int)((long long)chunks * gi / G), c1 = (int)((long long)chunks * (gi + 1) / G);
+            const int r_lo = c0 * 16, r_n = (c1 * 16 < h->S.R ? c1 * 16 : h->S.R) - r_lo;
+            if (r_n <= 0) continue;
+            const bool stag = h->run_stagger == 2 || (h->run_stagger == 1 && i == 0);
+            hipGraphNode_t deps[2];
+            size_t nd = 0;
+            if (last[gi]) deps[nd++] = last[gi];
+            if (stag && prev_rows) deps[nd++] = prev_rows;
+            hipGraphNode_t rows = nullptr, walk = nullptr;
+            Emit e;
+            e.graph = g; e.deps = deps; e.ndeps = nd; e.node = &rows; e.err = &err;
+            emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+            if (err != hipSuccess) break;
+            prev_rows = rows;
+            e.deps = &rows; e.ndeps = 1; e.node = &walk;
+            emit_hybrid_walk(e, h->S, h->D, t, r_lo, r_n);
+            last[gi] = walk;
+        }
+    }
+    if (err != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return fail(h, VDS_EHIP, "vds_run: hipGraphAddKernelNode failed: %s", hipGetErrorString(err));
+    }
+    *out = g;
+    return VDS_OK;
+}
+
 // SimCity's loop without hooks (:1048-1091) for n_ticks slots.  Runs of 8 slots and more are captured once as a hipGraph
-// (stream capture of the very launches vds_step issues) and replayed afterwards: one submission per day instead of 148 / 296.
-// VDS_RUN_GRAPH=0 keeps the eager loop.
+// (stream capture of the launches) and replayed afterwards: one submission per day instead of 148 / 296.
+// VDS_RUN_GRAPH=0 keeps the eager loop.  Hybrid neighbour-search mode: the replica groups are parallel branches of that graph
+// (build_group_graph) and exist ONLY there: issued eagerly on streams, the cross-stream event waits of a grouped day made the
+// HIP runtime of this image abort in free() (profiles/r03_run_groups/notes.md), so the eager path keeps one launch pair per
+// tick over all replicas.
 int vds_run(vds_handle *h, int32_t n_ticks) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_run: call vds_reset first");
     if (h->use_graph < 0) { const char *v = getenv("VDS_RUN_GRAPH"); h->use_graph = (v && *v == '0') ? 0 : 1; }
     if (!h->use_graph || h->profiling || n_ticks < 8 || h->last_stepped == h->t || h->t + n_ticks > h->S.T) return run_eager(h, n_ticks);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (!(h->run_exec && h->run_t0 == h->t && h->run_n == n_ticks && h->run_stream == h->stream)) {
+    const int G = run_group_count(h);
+    if (!(h->run_exec && h->run_t0 == h->t && h->run_n == n_ticks && h->run_stream == h->stream && h->run_G == G)) {
         drop_run_graph(h);
         const int t0 = h->t, ls0 = h->last_stepped;
         hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return run_eager(h, n_ticks); }
-        const int rc = run_eager(h, n_ticks);
-        const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+        int rc;
+        hipError_t ec = hipSuccess;
+        if (G > 1) {
+            rc = build_group_graph(h, n_ticks, G, &g);
+        } else {
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return run_eager(h, n_ticks); }
+            rc = run_eager(h, n_ticks);
+            ec = hipStreamEndCapture(h->stream, &g);
+        }
         h->t = t0; h->last_stepped = ls0;                       // nothing has run yet
         if (rc || ec != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
@@ -1192,11 +1301,28 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
         const hipError_t ei = hipGraphInstantiate(&h->run_exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (ei != hipSuccess) { h->run_exec = nullptr; (void)hipGetLastError(); return run_eager(h, n_ticks); }
-        h->run_t0 = t0; h->run_n = n_ticks; h->run_stream = h->stream;
+        h->run_t0 = t0; h->run_n = n_ticks; h->run_stream = h->stream; h->run_G = G;
     }
     HIPCHK(h, hipGraphLaunch(h->run_exec, h->stream));
     h->t += n_ticks;
     h->last_stepped = h->t - 1;
+    return VDS_OK;
+}
+
+// the group count vds_run uses for this handle as it stands (1: one launch pair per tick over all replicas)
+int vds_get_run_groups(vds_handle *h) {
+    if (!h || !h->have_static) return 1;
+    if (h->use_graph < 0) { const char *v = getenv("VDS_RUN_GRAPH"); h->use_graph = (v && *v == '0') ? 0 : 1; }
+    return run_group_count(h);
+}
+
+// Scheduling knob of vds_run in hybrid neighbour-search mode (no reference counterpart): groups <= 0 restores the default.
+int vds_set_run_groups(vds_handle *h, int32_t groups, int32_t stagger) {
+    if (!h) return VDS_EINVAL;
+    if (groups > RUN_GROUPS_MAX || stagger > 2) return fail(h, VDS_EINVAL, "vds_set_run_groups: groups <= %d, stagger 0 / 1 / 2 (or negative: default)", RUN_GROUPS_MAX);
+    drop_run_graph(h);
+    h->run_groups = groups > 0 ? groups : -1;
+    h->run_stagger = stagger >= 0 ? stagger : -1;
     return VDS_OK;
 }
 

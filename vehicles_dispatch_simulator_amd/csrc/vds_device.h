@@ -119,6 +119,8 @@ struct Static {
     int seq_pad;                     // longest visit sequence, rounded up to a multiple of 64
     const int *so_rank;              // [Oq] rank of the sorted position inside its slot, in id order (= cursor order of :912-973)
     int max_tick_orders;             // most orders processed in one tick
+    int r_lo;                        // hybrid tick launched for a GROUP of replicas (vds_run: groups on streams, the stamp-mode k_tick_rows
+                                     // of one group under the k_dfs_walk of another): first replica of the launch, a multiple of 16
     // ---- layout T ("lanes" tick, k_tick_lanes in vds_lanes.hip): lane = replica.  Per-replica tables are transposed inside
     // groups of 64 replicas so that the 64 lanes of a wavefront - the same cluster in 64 consecutive replicas - touch
     // consecutive addresses:
@@ -136,6 +138,16 @@ struct Static {
     int lane_force_slow;             // testing: every wavefront takes the table-free slow path
     int lane_ablate;                 // timing experiments only (results INVALID when non-zero): bit0 no counter atomics, bit1 no result
                                      // stores, bit2 no arrival posts, bit3 no list write-back, bit4 no header store
+};
+
+// where a host-side launcher puts its kernel: on a stream, or as a kernel node of an explicitly built hipGraph
+struct Emit {
+    hipStream_t st = nullptr;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t *deps = nullptr;
+    size_t ndeps = 0;
+    hipGraphNode_t *node = nullptr;
+    hipError_t *err = nullptr;
 };
 
 struct State {

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
     // LPT balance; the static tables are small enough to sit in every L2)
     const int4 cd = S.cdesc_ord[blockIdx.x / nchunks];
     const int c = cd.z;
-    const int chunk = blockIdx.x % nchunks;
+    const int chunk = blockIdx.x % nchunks + (ST ? (S.r_lo >> 4) : 0);           // (stamp mode may be launched per replica group)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int lane = lane_id();
     const int g = lane >> 4, l16 = lane & 15;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
         }
     } else if (DM == 1) {
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
-        const int r0 = (int)((blockIdx.x % nchunks) * ROWS_WAVES * 4);       // (a group's first slot is never padding)
+        const int r0 = (int)(chunk * ROWS_WAVES * 4);       // (a group's first slot is never padding)
         const int4 dd = S.replica_desc[S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1)];
         rowvalid = rowvalid && t < dd.z;             // (workgroup-uniform apart from r < R)
         q0 = 0; k = 0;
@@ -3206,7 +3206,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     __shared__ int s_cursor;              // rank of the dry order the walk is at: the scanning wavefronts look for work from there on
     __shared__ int s_done;                // the walk is over
     __shared__ int s_slot[WK_NS];         // pool record s: 0 free, else rank of its dry order << 2 | 1 being filled / 2 ready
-    const int r = blockIdx.x;
+    const int r = S.r_lo + (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const DayView dv = day_view(S, r);
     if (t >= dv.T) return;
@@ -4164,27 +4164,62 @@ int dfs_walk_pool(const Static &S) {
     return ns;
 }
 
-// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk
-void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
-    const int rchunks = ((S.rperm != nullptr ? S.rslots : S.R) + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+// hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk.
+// Both halves take a replica range [r_lo, r_lo + r_n) (r_lo a multiple of 16; r_n = 0: all replicas): vds_run launches the tick
+// per GROUP of replicas on separate streams, so that the stamp-mode kernel of one group (VALU-bound) runs under the walk of
+// another (a per-replica dependency chain that leaves the CUs mostly idle).  Groups need the identity row map (rperm == null).
+// (Emit: the same launch either goes to a stream or becomes a kernel node of an explicitly built hipGraph - vds_run's day graph
+// with the replica groups as parallel branches is built node by node, not captured from forked streams.)
+static void emit_rows(const Emit &e, void (*k)(Static, State, int, int), dim3 grid, dim3 block, size_t lds, Static S, State D, int t, int li) {
+    if (!e.graph) { hipLaunchKernelGGL(k, grid, block, lds, e.st, S, D, t, li); return; }
+    void *args[4] = {&S, &D, &t, &li};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void *>(k); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds; p.kernelParams = args; p.extra = nullptr;
+    *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
+}
+static void emit_walk(const Emit &e, void (*k)(Static, State, int), dim3 grid, dim3 block, size_t lds, Static S, State D, int t) {
+    if (!e.graph) { hipLaunchKernelGGL(k, grid, block, lds, e.st, S, D, t); return; }
+    void *args[3] = {&S, &D, &t};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void *>(k); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds; p.kernelParams = args; p.extra = nullptr;
+    *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
+}
+
+void emit_hybrid_rows(const Emit &e, const Static &S0, const State &D, int t, int lds_ints, int r_lo, int r_n) {
+    Static S = S0;
+    S.r_lo = r_lo;
+    const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R);
+    const int rchunks = (slots + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
     if (S.u8_ok) {
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);
-        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<true, 2, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        else hipLaunchKernelGGL((k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        if (S.seq_pad <= 64) hipLaunchKernelGGL((k_dfs_walk<true, 1>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
-        else if (S.seq_pad <= 128) hipLaunchKernelGGL((k_dfs_walk<true, 2>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
-        else hipLaunchKernelGGL((k_dfs_walk<true, 4>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        emit_rows(e, dm == 2 ? k_tick_rows<true, 2, true> : (dm == 1 ? k_tick_rows<true, 1, true> : k_tick_rows<true, 0, true>), grid, block, rows_lds_bytes(li), S, D, t, li);
     } else {
-        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<false, 2, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        else hipLaunchKernelGGL((k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        if (S.seq_pad <= 64) hipLaunchKernelGGL((k_dfs_walk<false, 1>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
-        else if (S.seq_pad <= 128) hipLaunchKernelGGL((k_dfs_walk<false, 2>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
-        else hipLaunchKernelGGL((k_dfs_walk<false, 4>), dim3(S.R), dim3(WK_THREADS), dfs_walk_lds(S), st, S, D, t);
+        emit_rows(e, dm == 2 ? k_tick_rows<false, 2, true> : (dm == 1 ? k_tick_rows<false, 1, true> : k_tick_rows<false, 0, true>), grid, block, rows_lds_bytes(lds_ints), S, D, t, lds_ints);
     }
+}
+
+void emit_hybrid_walk(const Emit &e, const Static &S0, const State &D, int t, int r_lo, int r_n) {
+    Static S = S0;
+    S.r_lo = r_lo;
+    const dim3 grid(r_n > 0 ? r_n : S.R);
+    if (S.u8_ok) emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2> : k_dfs_walk<true, 4>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
+    else emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<false, 1> : (S.seq_pad <= 128 ? k_dfs_walk<false, 2> : k_dfs_walk<false, 4>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
+}
+
+void launch_hybrid_rows(const Static &S, const State &D, int t, int lds_ints, hipStream_t st, int r_lo, int r_n) {
+    Emit e; e.st = st;
+    emit_hybrid_rows(e, S, D, t, lds_ints, r_lo, r_n);
+}
+void launch_hybrid_walk(const Static &S, const State &D, int t, hipStream_t st, int r_lo, int r_n) {
+    Emit e; e.st = st;
+    emit_hybrid_walk(e, S, D, t, r_lo, r_n);
+}
+
+void launch_tick_hybrid(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
+    launch_hybrid_rows(S, D, t, lds_ints, st, 0, 0);
+    launch_hybrid_walk(S, D, t, st, 0, 0);
 }
 
 void launch_match_dfs(const Static &S, const State &D, int t, hipStream_t st) {
