@@ -638,7 +638,9 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
 #else
     const int abl = 0;
 #endif
-    int dead[J];
+    // tag[s]: the slot's list position, IMAX once it is empty or taken - a candidate's key is (cost << 7) | tag, one
+    // v_lshl_or per candidate, and IMAX wins no minimum
+    int tag[J];
 #pragma unroll
     for (int s = 0; s < J; ++s) {
         const int pos = l16 * J + s;
@@ -647,7 +649,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             veh[s] = e.x; loc[s] = (int)e.y;
         }
         if (pos >= mnew) loc[s] = 0;
-        dead[s] = pos < mnew ? 0 : IMAX;
+        tag[s] = pos < mnew ? pos : IMAX;
     }
     int recy = 0;
     int recy4[4] = {0, 0, 0, 0};
@@ -663,28 +665,28 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     PROF_STAMP(3);
     int navail = mnew, evals = 0;
     int res[4] = {IMAX, IMAX, IMAX, IMAX};
+    const int lbase = l16 * J;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         if (jj * 16 >= kmax || (abl & 4)) break;
-        const int kk = min(16, kmax - jj * 16);
-        for (int ji = 0; ji < kk; ++ji) {
+        const int kk = __builtin_amdgcn_readfirstlane(min(16, kmax - jj * 16));      // (uniform: keep the loop counter scalar)
+        unsigned long long jmask = 0x0001000100010001ull;                            // the lanes l16 == ji of the four rows
+        for (int ji = 0; ji < kk; ++ji, jmask <<= 1) {
             const int p = (PD ? __builtin_amdgcn_ds_bpermute((rowbase + ji) << 2, recy4[jj]) : rdlane(recy, jj * 16 + ji)) & 0xFFFF;
             const bool live = !PD || jj * 16 + ji < k;          // this row still has an order at this step
             const CT *row = lds_blk + p * nc;
             int best = IMAX;
 #pragma unroll
-            for (int s = 0; s < J; ++s) {
-                const int v = (((int)row[loc[s]] << 7) | (l16 * J + s)) | dead[s];
-                best = min(best, v);
-            }
+            for (int s = 0; s < J; ++s) best = min(best, ((int)row[loc[s]] << 7) | tag[s]);
             const int rmin = live ? row_min_i32(best) : IMAX;
-            const bool hit = rmin != IMAX;
-            const int wpos = rmin & 127;
+            // the winner's slot leaves the table.  (No match: rmin & 127 = 127 can only name the last slot of the deepest table,
+            // and in a row without a match that slot is IMAX already.)
+            const int wrel = (rmin & 127) - lbase;
 #pragma unroll
-            for (int s = 0; s < J; ++s) dead[s] = (hit && wpos == l16 * J + s) ? IMAX : dead[s];
-            res[jj] = (l16 == ji) ? rmin : res[jj];
+            for (int s = 0; s < J; ++s) tag[s] = wrel == s ? IMAX : tag[s];
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(res[jj]) : "v"(res[jj]), "v"(rmin), "s"(jmask));      // res[jj] = l16 == ji ? rmin : res[jj]
             evals += live ? navail : 0;
-            navail -= hit ? 1 : 0;
+            navail -= rmin != IMAX ? 1 : 0;
         }
     }
     PROF_STAMP(4);
@@ -754,7 +756,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
     // order-preserving compaction of the survivors (:963); unchanged leading entries are not rewritten
     int alive = 0;
 #pragma unroll
-    for (int s = 0; s < J; ++s) alive += dead[s] == 0 ? 1 : 0;
+    for (int s = 0; s < J; ++s) alive += tag[s] != IMAX ? 1 : 0;
     const int incl = row_incl_scan_i32(alive);
     const int mfin = row_sum_i32(alive);
     int wp = incl - alive;
@@ -762,7 +764,7 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
 #pragma unroll
         for (int s = 0; s < J; ++s) {
             const int pos = l16 * J + s;
-            if (dead[s] == 0) {
+            if (tag[s] != IMAX) {
                 if (!(wp == pos && pos < m)) idle[wp] = make_uint2(veh[s], (unsigned)loc[s]);
                 wp++;
             }
