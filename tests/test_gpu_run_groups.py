@@ -113,6 +113,56 @@ def test_grouping_does_not_change_a_bit_and_is_the_default_from_512_replicas():
     np.testing.assert_array_equal(outs[0][0][:8], outs[0][0][504:512])           # same start nodes -> same day
 
 
+@pytest.mark.parametrize("name,groups", [("tiny_kmeans_dfs2", 3), ("tiny_kmeans", 2), ("tiny_kmeans_dfs2", 1)])
+def test_new_order_tables_on_one_handle_update_the_day_graph_in_place(name, groups):
+    """vds_load_orders between days: a day with as many slots as the last one keeps the executable graph (its kernel parameters
+    are replaced: hipGraphExecUpdate), another slot count re-builds it - every day equals the oracle either way; plain tick
+    (two groups of k_tick_rows) and hybrid tick."""
+    g = load_golden(name)
+    R = 40
+    base = synth_days(g, 2, seed=21)
+    a = base[0]
+    rng = np.random.RandomState(3)
+    perm = rng.permutation(a[1].size)
+    b = (a[0], a[1][perm].copy(), a[2][perm].copy())          # same release minutes (same slots), other trips
+    init = _init(g, R, 700)
+    env = mk_env(g, R)
+    for day in (a, b, base[1], a):
+        env.load_orders(*day)
+        env.set_run_groups(groups, 1)
+        env.reset(init)
+        env.run(env.T)
+        env.sync()
+        _check(env, g, [day], np.zeros(R, dtype=np.int32), init, replicas=[0, 7, 16, 31, 39])
+    env.close()
+
+
+def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_512_replicas():
+    g = load_golden("tiny_kmeans")
+    day = synth_days(g, 1, seed=8)
+    R = 40
+    init = _init(g, R, 300)
+    for groups, stagger in ((2, 0), (3, 2)):
+        env = mk_env(g, R)
+        env.load_orders(*day[0])
+        assert env.main_kernel() == "k_tick_rows"
+        env.set_run_groups(groups, stagger)
+        assert env.run_groups() == groups
+        env.reset(init)
+        env.run(env.T)
+        env.sync()
+        _check(env, g, day, np.zeros(R, dtype=np.int32), init)
+        env.close()
+    env = mk_env(g, 512)
+    env.load_orders(*day[0])
+    assert env.run_groups() == 2
+    env.close()
+    env = mk_env(g, 511)
+    env.load_orders(*day[0])
+    assert env.run_groups() == 1
+    env.close()
+
+
 def test_bad_arguments_are_refused():
     g = load_golden("tiny_kmeans_dfs2")
     env = mk_env(g, 4)

@@ -25,6 +25,7 @@ void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
+void emit_tick_rows(const Emit &, const Static &, const State &, int, int, int, int);
 void emit_hybrid_rows(const Emit &, const Static &, const State &, int, int, int, int);
 void emit_hybrid_walk(const Emit &, const Static &, const State &, int, int, int);
 size_t lanes_lds_bytes(const Static &, int *);
@@ -114,6 +115,7 @@ struct vds_handle {
     // depend on (tables, capacities, stream) has changed
     hipGraphExec_t run_exec = nullptr;
     int run_t0 = -1, run_n = 0, run_G = 1;
+    bool run_stale = false;                  // tables / capacities changed since the graph was built: same shape -> hipGraphExecUpdate
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
     std::vector<hipEvent_t> ev_pool;
@@ -236,7 +238,7 @@ static void drop_run_graph(vds_handle *h) {
         (void)hipGraphExecDestroy(h->run_exec);
         h->run_exec = nullptr;
     }
-    h->run_t0 = -1; h->run_n = 0; h->run_G = 1;
+    h->run_t0 = -1; h->run_n = 0; h->run_G = 1; h->run_stale = false;
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -704,7 +706,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (void *p : h->order_allocs) dev_free(p);
         h->order_allocs.clear();
-        drop_run_graph(h);
+        h->run_stale = true;
         h->have_orders = false; h->have_reset = false;
         h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
         h->err.clear();
@@ -1045,7 +1047,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     if (cap < 1) return fail(h, VDS_EINVAL, "vds_set_idle_cap: bad capacity %d", cap);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    drop_run_graph(h);
+    h->run_stale = true;
     cap = std::min(round_up(cap, 64), round_up(std::max(h->S.V, 1), 64));
     if (cap > (1 << 24)) return fail(h, VDS_EINVAL, "vds_set_idle_cap: %d > 2^24 unsupported", cap);
     if (cap == h->S.idle_cap) return VDS_OK;
@@ -1198,7 +1200,7 @@ static int run_eager(vds_handle *h, int32_t n_ticks) {
     return VDS_OK;
 }
 
-// ---- vds_run of the hybrid neighbour-search tick: replica groups as parallel branches of the day graph.
+// ---- vds_run: replica groups as parallel branches of the day graph.
 // One hybrid tick = k_tick_rows in stamp mode (VALU-bound, fills the chip) + k_dfs_walk (one workgroup per replica, a
 // dependency chain of ~50 dry orders: ~150 us whatever the replica count, the CUs mostly idle).  Replicas never interact, so
 // the replicas are split into G groups (boundaries at multiples of 16 = one k_tick_rows workgroup) and every group runs its own
@@ -1207,8 +1209,16 @@ static int run_eager(vds_handle *h, int32_t n_ticks) {
 // g after the rows of group g - 1; group 0 after the last group's rows of the previous tick); 1 (default): only the first
 // tick is staggered that way, then the groups run free; 0: free-running from the start.  (Measured: 1 = 0 >= 2.)
 // Hooked stepping (vds_step) stays one launch pair over all replicas: the hook needs every replica at the same slot.
+// The plain tick (no neighbour search: ONE k_tick_rows per tick) is grouped as well - two chains of half-size launches instead
+// of one chain: a launch of one group fills the drain / fill bubbles at the kernel boundaries of the other and the two run out of
+// phase on every SIMD (one chain: the seven workgroups of a CU start together, load together, compute together).
+static bool run_groups_hybrid(const vds_handle *h) { return h->dfs_mode && h->hybrid_ok && h->cfg.force_generic == 0; }
+static bool run_groups_plain(const vds_handle *h) {
+    // (the row-mapped kernel alone: every cost block fits LDS - no k_tick_work pass -, not the lanes layout)
+    return !h->dfs_mode && h->S.fast_ok && !h->S.layoutT && h->S.max_nc * h->S.max_nc <= h->lds_ints;
+}
 static int run_group_count(vds_handle *h) {
-    if (!(h->dfs_mode && h->hybrid_ok && h->cfg.force_generic == 0) || h->S.rperm != nullptr) return 1;
+    if (!(run_groups_hybrid(h) || run_groups_plain(h)) || h->S.rperm != nullptr) return 1;
     if (h->run_groups < 0) {
         const char *v = getenv("VDS_RUN_GROUPS");
         h->run_groups = (v && *v) ? atoi(v) : 0;
@@ -1218,8 +1228,9 @@ static int run_group_count(vds_handle *h) {
         h->run_stagger = (v && *v) ? atoi(v) : 1;
     }
     if (!h->use_graph) return 1;             // (groups only as branches of the day's graph: see vds_run)
-    // default: 3 groups from 1024 replicas on, 2 from 512 on
-    int G = h->run_groups > 0 ? h->run_groups : (h->S.R >= RUN_GROUPS_BIG_R ? 3 : (h->S.R >= RUN_GROUPS_MIN_R ? 2 : 1));
+    // default: hybrid tick 3 groups from 1024 replicas on, 2 from 512 on; plain tick 2 groups from 512 replicas on
+    const int dflt = h->S.R < RUN_GROUPS_MIN_R ? 1 : (run_groups_hybrid(h) && h->S.R >= RUN_GROUPS_BIG_R ? 3 : 2);
+    int G = h->run_groups > 0 ? h->run_groups : dflt;
     const int chunks = (h->S.R + 15) / 16;
     if (G > chunks) G = chunks;
     if (G > RUN_GROUPS_MAX) G = RUN_GROUPS_MAX;
@@ -1249,6 +1260,13 @@ static int build_group_graph(vds_handle *h, int32_t n_ticks, int G, hipGraph_t *
             hipGraphNode_t rows = nullptr, walk = nullptr;
             Emit e;
             e.graph = g; e.deps = deps; e.ndeps = nd; e.node = &rows; e.err = &err;
+            if (!h->dfs_mode) {                 // plain tick: the row-mapped kernel is the whole tick
+                emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+                if (err != hipSuccess) break;
+                prev_rows = rows;
+                last[gi] = rows;
+                continue;
+            }
             emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
             if (err != hipSuccess) break;
             prev_rows = rows;
@@ -1278,8 +1296,7 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
     if (!h->use_graph || h->profiling || n_ticks < 8 || h->last_stepped == h->t || h->t + n_ticks > h->S.T) return run_eager(h, n_ticks);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int G = run_group_count(h);
-    if (!(h->run_exec && h->run_t0 == h->t && h->run_n == n_ticks && h->run_stream == h->stream && h->run_G == G)) {
-        drop_run_graph(h);
+    if (!(h->run_exec && !h->run_stale && h->run_t0 == h->t && h->run_n == n_ticks && h->run_stream == h->stream && h->run_G == G)) {
         const int t0 = h->t, ls0 = h->last_stepped;
         hipGraph_t g = nullptr;
         int rc;
@@ -1298,10 +1315,23 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
             if (rc) return rc;
             return run_eager(h, n_ticks);
         }
-        const hipError_t ei = hipGraphInstantiate(&h->run_exec, g, nullptr, nullptr, 0);
+        // same shape as the graph at hand (new order tables, another first slot): its kernel parameters are replaced in place -
+        // no destruction (see drop_run_graph for what that costs), no instantiation
+        bool updated = false;
+        if (h->run_exec && h->run_n == n_ticks && h->run_G == G) {
+            if (h->run_stream) (void)hipStreamSynchronize(h->run_stream);
+            hipGraphNode_t bad = nullptr;
+            hipGraphExecUpdateResult res;
+            updated = hipGraphExecUpdate(h->run_exec, g, &bad, &res) == hipSuccess;
+            if (!updated) (void)hipGetLastError();
+        }
+        if (!updated) {
+            drop_run_graph(h);
+            const hipError_t ei = hipGraphInstantiate(&h->run_exec, g, nullptr, nullptr, 0);
+            if (ei != hipSuccess) { (void)hipGraphDestroy(g); h->run_exec = nullptr; (void)hipGetLastError(); return run_eager(h, n_ticks); }
+        }
         (void)hipGraphDestroy(g);
-        if (ei != hipSuccess) { h->run_exec = nullptr; (void)hipGetLastError(); return run_eager(h, n_ticks); }
-        h->run_t0 = t0; h->run_n = n_ticks; h->run_stream = h->stream; h->run_G = G;
+        h->run_t0 = t0; h->run_n = n_ticks; h->run_stream = h->stream; h->run_G = G; h->run_stale = false;
     }
     HIPCHK(h, hipGraphLaunch(h->run_exec, h->stream));
     h->t += n_ticks;
@@ -1320,7 +1350,7 @@ int vds_get_run_groups(vds_handle *h) {
 int vds_set_run_groups(vds_handle *h, int32_t groups, int32_t stagger) {
     if (!h) return VDS_EINVAL;
     if (groups > RUN_GROUPS_MAX || stagger > 2) return fail(h, VDS_EINVAL, "vds_set_run_groups: groups <= %d, stagger 0 / 1 / 2 (or negative: default)", RUN_GROUPS_MAX);
-    drop_run_graph(h);
+    h->run_stale = true;
     h->run_groups = groups > 0 ? groups : -1;
     h->run_stagger = stagger >= 0 ? stagger : -1;
     return VDS_OK;

@@ -918,7 +918,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
     // LPT balance; the static tables are small enough to sit in every L2)
     const int4 cd = S.cdesc_ord[blockIdx.x / nchunks];
     const int c = cd.z;
-    const int chunk = blockIdx.x % nchunks + (ST ? (S.r_lo >> 4) : 0);           // (stamp mode may be launched per replica group)
+    const int chunk = blockIdx.x % nchunks + (S.r_lo >> 4);                      // (vds_run launches the tick per replica group)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keep it scalar
     const int lane = lane_id();
     const int g = lane >> 4, l16 = lane & 15;
@@ -4102,24 +4102,33 @@ static int rows_lds_bytes(int lds_ints) { return 64 * 16 + ROWS_WAVES * 4 * ROW_
 
 void launch_tick_lanes(const Static &S, const State &D, int t, hipStream_t st);      // vds_lanes.hip
 
-// main kernel of a non-DFS tick (the one bench.py brackets with events)
-void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
-    if (S.layoutT) { launch_tick_lanes(S, D, t, st); return; }
-    const int chunks = (S.R + 15) / 16;
-    const int rchunks = ((S.rperm != nullptr ? S.rslots : S.R) + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
+// main kernel of a non-DFS tick (the one bench.py brackets with events); emit_rows: further down
+static void emit_rows(const Emit &e, void (*k)(Static, State, int, int), dim3 grid, dim3 block, size_t lds, Static S, State D, int t, int li);
+// the row-mapped kernel for the replicas [r_lo, r_lo + r_n) (r_lo a multiple of 16; r_n = 0: all), on a stream or as a graph node
+void emit_tick_rows(const Emit &e, const Static &S0, const State &D, int t, int lds_ints, int r_lo, int r_n) {
+    Static S = S0;
+    S.r_lo = r_lo;
+    const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R);
+    const int rchunks = (slots + ROWS_WAVES * 4 - 1) / (ROWS_WAVES * 4);
     const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 grid(S.C * rchunks), block(ROWS_WAVES * WAVE);
-    if (S.fast_ok && S.u8_ok) {
+    if (S.u8_ok) {
         const int li = min(lds_ints, (S.max_nc * S.max_nc + 15) / 16 * 4);      // byte blocks: a quarter of the LDS
-        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<true, 2>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<true, 1>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-        else hipLaunchKernelGGL((k_tick_rows<true, 0>), grid, block, rows_lds_bytes(li), st, S, D, t, li);
-    } else if (S.fast_ok) {
-        if (dm == 2) hipLaunchKernelGGL((k_tick_rows<false, 2>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        else if (dm == 1) hipLaunchKernelGGL((k_tick_rows<false, 1>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
-        else hipLaunchKernelGGL((k_tick_rows<false, 0>), grid, block, rows_lds_bytes(lds_ints), st, S, D, t, lds_ints);
+        emit_rows(e, dm == 2 ? k_tick_rows<true, 2> : (dm == 1 ? k_tick_rows<true, 1> : k_tick_rows<true, 0>), grid, block, rows_lds_bytes(li), S, D, t, li);
+    } else {
+        emit_rows(e, dm == 2 ? k_tick_rows<false, 2> : (dm == 1 ? k_tick_rows<false, 1> : k_tick_rows<false, 0>), grid, block, rows_lds_bytes(lds_ints), S, D, t, lds_ints);
     }
-    else hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * 4, st, S, D, t, lds_ints);
+}
+
+void launch_tick_main(const Static &S, const State &D, int t, int lds_ints, hipStream_t st) {
+    if (S.layoutT) { launch_tick_lanes(S, D, t, st); return; }
+    if (S.fast_ok) {
+        Emit e; e.st = st;
+        emit_tick_rows(e, S, D, t, lds_ints, 0, 0);
+        return;
+    }
+    const int chunks = (S.R + 15) / 16;
+    hipLaunchKernelGGL(k_tick<true>, dim3(S.C * chunks), dim3(256), (size_t)lds_ints * 4, st, S, D, t, lds_ints);
 }
 
 void launch_tick_work(const Static &S, const State &D, int t, hipStream_t st) {
