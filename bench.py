@@ -240,8 +240,13 @@ def main():
                         # from HBM every time): NOT a lower bound for this layout, quoted for comparability only
                         "algorithmic_bytes_per_launch": alg_bytes,
                         "algorithmic_gbs": alg_bytes / avg_s / 1e9,
+                        # avg_launch_ms: one TICK of the timed day = day_kernel_ms / launches (one HIP event pair around the day the
+                        # timed loop replays).  vds_run issues a tick as `run_groups` concurrent launches of replicas / run_groups
+                        # replicas each (parallel branches of the day graph) - bytes and time are per tick either way.
+                        # event_pair_avg_launch_ms: ONE launch over all replicas by itself (the eager, profiled pass: an event pair
+                        # per launch) - the figure rocprofv3 --stats of profiles/<tag>/kernel_stats.csv (VDS_RUN_GROUPS=1) shows
                         "avg_launch_ms": avg_s * 1e3, "launches": launches, "day_kernel_ms": day_ms,
-                        "event_pair_avg_launch_ms": float(ms.mean()),
+                        "run_groups": env.run_groups(), "event_pair_avg_launch_ms": float(ms.mean()),
                         "match_evals_per_s": work["evals"] / (day_ms * 1e-3)}
             lim = side.get("limiter")
             if lim:

@@ -8,9 +8,17 @@ O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 python -c "from vehicles_dispatch_simulator_amd import _lib; print(_lib.load().vds_build_id().decode())" > $O/build_id.txt 2>/dev/null
 B="python bench.py --no-cpu-baseline --no-neighbour-leg --distinct-days ${DISTINCT:-0} $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq -- $B --steps 1 --warmup 0 > $O/sq.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 0 > $O/sq2.log 2>&1
+# The kernel BY ITSELF: one launch per tick over all replicas (VDS_RUN_GROUPS=1) - per-launch durations and counters mean what
+# they say.  The default vds_run (replica groups as parallel branches of the day graph: overlapping half-size launches) is
+# traced once more at the end (stats_groups: profiles/run_groups_trace.py turns it into durations + overlap).
+export VDS_RUN_GROUPS=1
+RP="timeout 300 rocprofv3"
+$RP --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 2 --warmup 1 > $O/stats.log 2>&1
+$RP --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1
+$RP --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/write.log 2>&1
+$RP --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq -- $B --steps 1 --warmup 0 > $O/sq.log 2>&1
+$RP --pmc SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 0 > $O/sq2.log 2>&1
+unset VDS_RUN_GROUPS
+$RP --kernel-trace --output-format csv -d $O/stats_groups -- $B --steps 2 --warmup 1 > $O/stats_groups.log 2>&1
+python profiles/run_groups_trace.py $(find $O/stats_groups -name "*kernel_trace.csv" | head -1) > $O/groups_trace.txt 2>&1
 tail -1 $O/stats.log | cut -c1-300

@@ -1,4 +1,4 @@
-"""Summarise a rocprofv3 --kernel-trace csv of a grouped hybrid run: per kernel name the mean duration, and how much of the
+"""Summarise a rocprofv3 --kernel-trace csv of a grouped run (plain or hybrid tick): per kernel name the mean duration, and how much of the
 wall time has 0 / 1 / 2+ kernels in flight (do the groups' kernels really overlap?).
 
     python profiles/run_groups_trace.py <kernel_trace.csv>
