@@ -1,29 +1,40 @@
-"""Summarise a rocprofv3 --kernel-trace csv of a grouped run (plain or hybrid tick): per kernel name the mean duration, and how much of the
-wall time has 0 / 1 / 2+ kernels in flight (do the groups' kernels really overlap?).
+"""Summarise a rocprofv3 --kernel-trace csv of a grouped run (plain or hybrid tick): the GROUP launches of k_tick_rows /
+k_dfs_walk (grid smaller than the kernel's largest grid in the trace = a launch over replicas / groups replicas), their mean
+duration, and inside the spans they cover (a gap of more than 1 ms ends a span: days are replayed back to back) how much of the
+time has 0 / 1 / 2+ of them in flight and the time per tick.
 
-    python profiles/run_groups_trace.py <kernel_trace.csv>
+    python profiles/run_groups_trace.py <kernel_trace.csv> [ticks per day = 148]
 """
 import csv, sys, collections
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 148
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         n = r["Kernel_Name"]
         if "k_tick_rows" in n or "k_dfs_walk" in n:
-            rows.append(("rows" if "k_tick_rows" in n else "walk", int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
-rows.sort(key=lambda x: x[1])
-# keep the last day (148 ticks): the last quarter of the launches
-rows = rows[len(rows) * 3 // 4:]
-dur = collections.defaultdict(list)
-for k, s, e, q in rows: dur[k].append(e - s)
-for k, v in dur.items(): print("%s: n %d mean %.1f us  min %.1f  max %.1f" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
-print("queues:", collections.Counter(q for _, _, _, q in rows))
-ev = []
-for k, s, e, q in rows: ev.append((s, 1, k)); ev.append((e, -1, k))
-ev.sort()
-t_prev = ev[0][0]; n = {"rows": 0, "walk": 0}; hist = collections.Counter()
-for t, d, k in ev:
-    hist[(min(n["rows"], 2), min(n["walk"], 4))] += t - t_prev
-    t_prev = t; n[k] += d
-tot = sum(hist.values())
-print("wall %.2f ms over %d launches" % (tot / 1e6, len(rows)))
-for key in sorted(hist): print("rows in flight %d, walks in flight %d: %5.1f %%" % (key[0], key[1], 100.0 * hist[key] / tot))
+            rows.append(("rows" if "k_tick_rows" in n else "walk", int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))))
+gmax = collections.defaultdict(int)
+for k, s, e, g in rows: gmax[k] = max(gmax[k], g)
+full = [x for x in rows if x[3] == gmax[x[0]]]
+grp = sorted((x for x in rows if x[3] < gmax[x[0]]), key=lambda x: x[1])
+for label, sel in (("full launches (all replicas)", full), ("group launches", grp)):
+    d = collections.defaultdict(list)
+    for k, s, e, g in sel: d[k].append(e - s)
+    for k, v in d.items(): print("%s, %s: n %d mean %.1f us  min %.1f  max %.1f" % (label, k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
+if not grp:
+    print("no group launches in this trace"); sys.exit(0)
+spans, cur = [], [grp[0]]
+for x in grp[1:]:
+    if x[1] - max(y[2] for y in cur[-8:]) > 1_000_000: spans.append(cur); cur = []
+    cur.append(x)
+spans.append(cur)
+hist, wall, nl = collections.Counter(), 0, 0
+for sp in spans:
+    ev = sorted([(s, 1, k) for k, s, e, g in sp] + [(e, -1, k) for k, s, e, g in sp])
+    n = {"rows": 0, "walk": 0}; tp = ev[0][0]
+    for t, dlt, k in ev:
+        hist[(min(n["rows"], 3), min(n["walk"], 4))] += t - tp
+        tp = t; n[k] += dlt
+    wall += ev[-1][0] - ev[0][0]; nl += len(sp)
+print("%d spans, %.2f ms covered by %d group launches" % (len(spans), wall / 1e6, nl))
+for key in sorted(hist): print("k_tick_rows in flight %d, k_dfs_walk in flight %d: %5.1f %%" % (key[0], key[1], 100.0 * hist[key] / max(1, wall)))
