@@ -189,7 +189,12 @@ def days_case(seed):
     return cost, n2c, nbr, V, days, rd, valid_nodes, cfg
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "40")))))
+# 1906: one cluster, 134 vehicles, per-row days - a row without an order at a match step while its 128-slot table is full (the
+# round-3 tag-register match loop retired slot 127 of such a row)
+DAYS_SEEDS = sorted(set(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "40")))) | {1906})
+
+
+@pytest.mark.parametrize("seed", DAYS_SEEDS)
 def test_random_city_with_replica_days_matches_oracle(seed):
     cost, n2c, nbr, V, days, rd, valid_nodes, cfg = days_case(seed)
     off, idx = neighbors_to_csr(nbr)

@@ -680,8 +680,9 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             for (int s = 0; s < J; ++s) best = min(best, ((int)row[loc[s]] << 7) | tag[s]);
             const int rmin = live ? row_min_i32(best) : IMAX;
             // the winner's slot leaves the table.  (No match: rmin & 127 = 127 can only name the last slot of the deepest table,
-            // and in a row without a match that slot is IMAX already.)
-            const int wrel = (rmin & 127) - lbase;
+            // and in a row whose order found no vehicle that slot is IMAX already.  A row of a per-row day WITHOUT an order at
+            // this step - rmin forced to IMAX - may hold a vehicle there: it must name no slot.)
+            const int wrel = (PD && !live) ? -1 : (rmin & 127) - lbase;
 #pragma unroll
             for (int s = 0; s < J; ++s) tag[s] = wrel == s ? IMAX : tag[s];
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(res[jj]) : "v"(res[jj]), "v"(rmin), "s"(jmask));      // res[jj] = l16 == ji ? rmin : res[jj]
@@ -4178,7 +4179,7 @@ int dfs_walk_pool(const Static &S) {
 // hybrid neighbour-search tick: the fast kernel in stamp mode (Update + own-cluster matching, nothing committed), then the walk.
 // Both halves take a replica range [r_lo, r_lo + r_n) (r_lo a multiple of 16; r_n = 0: all replicas): vds_run launches the tick
 // per GROUP of replicas on separate streams, so that the stamp-mode kernel of one group (VALU-bound) runs under the walk of
-// another (a per-replica dependency chain that leaves the CUs mostly idle).  Groups need the identity row map (rperm == null).
+// another (a per-replica dependency chain that leaves the CUs mostly idle).  Ranges are ranges of STORED replicas (row slots).
 // (Emit: the same launch either goes to a stream or becomes a kernel node of an explicitly built hipGraph - vds_run's day graph
 // with the replica groups as parallel branches is built node by node, not captured from forked streams.)
 static void emit_rows(const Emit &e, void (*k)(Static, State, int, int), dim3 grid, dim3 block, size_t lds, Static S, State D, int t, int li) {
