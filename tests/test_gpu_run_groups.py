@@ -79,6 +79,26 @@ def test_per_replica_days_in_groups(name, layout):
         env.close()
         pytest.skip("fixture does not take the hybrid tick")
     env.set_run_groups(3, 2)
+    assert env.run_groups() == 3                     # (also with the replicas stored regrouped by day: interleaved map)
+    env.reset(init)
+    env.run(env.T)
+    env.sync()
+    _check(env, g, days, replica_day, init)
+    env.close()
+
+
+@pytest.mark.parametrize("layout", ["blocks", "interleaved"])
+def test_plain_tick_per_replica_days_in_groups(layout):
+    g = load_golden("tiny_kmeans")
+    R = 40                                           # interleaved: 14 + 13 + 13 replicas -> stored as 3 x 16 (regrouped by day)
+    days = synth_days(g, 3, seed=21)
+    replica_day = np.array([0] * 16 + [2] * 16 + [1] * 8, dtype=np.int32) if layout == "blocks" else (np.arange(R) % 3).astype(np.int32)
+    init = _init(g, R, 17)
+    env = mk_env(g, R)
+    env.load_order_days(days, replica_day)
+    assert env.main_kernel() == "k_tick_rows"
+    env.set_run_groups(3, 0)
+    assert env.run_groups() == 3
     env.reset(init)
     env.run(env.T)
     env.sync()

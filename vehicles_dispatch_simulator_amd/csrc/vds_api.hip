@@ -1218,7 +1218,9 @@ static bool run_groups_plain(const vds_handle *h) {
     return !h->dfs_mode && h->S.fast_ok && !h->S.layoutT && h->S.max_nc * h->S.max_nc <= h->lds_ints;
 }
 static int run_group_count(vds_handle *h) {
-    if (!(run_groups_hybrid(h) || run_groups_plain(h)) || h->S.rperm != nullptr) return 1;
+    // (replicas stored regrouped by day - Static.rperm - are grouped like any others: the row map is the identity on the
+    // stored replicas, a day's padding replicas replay the empty day in whichever group they fall)
+    if (!(run_groups_hybrid(h) || run_groups_plain(h))) return 1;
     if (h->run_groups < 0) {
         const char *v = getenv("VDS_RUN_GROUPS");
         h->run_groups = (v && *v) ? atoi(v) : 0;
