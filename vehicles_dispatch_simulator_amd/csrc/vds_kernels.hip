@@ -587,6 +587,11 @@ __global__ __launch_bounds__(256) void k_tick_work(Static S, State D, int t) {
 #ifndef ROWS_PF
 #define ROWS_PF 0
 #endif
+// Wavefront priority by phase (s_setprio): 1 = raised everywhere but in the match loop (the wavefronts that are about to issue
+// loads go first, the VALU-heavy match loops of the others fill the gaps), 2 = the opposite, 3 = raised until the match loop only
+#ifndef ROWS_PRIO
+#define ROWS_PRIO 0
+#endif
 #define ROWS_PF_BYTES (ROWS_WAVES * 2048)       // per workgroup: [wavefront][entries 0..31 | entries 32..63][row][256 B]
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -663,6 +668,8 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
         if (lane < k) recy = lds_rec[lane].y;
     }
     PROF_STAMP(3);
+    if (ROWS_PRIO == 1 || ROWS_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+    if (ROWS_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     int navail = mnew, evals = 0;
     int res[4] = {IMAX, IMAX, IMAX, IMAX};
     const int lbase = l16 * J;
@@ -690,6 +697,8 @@ __device__ __forceinline__ void rows_match(const Static &S, const State &D, int 
             navail -= rmin != IMAX ? 1 : 0;
         }
     }
+    if (ROWS_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+    if (ROWS_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     PROF_STAMP(4);
     if (ST) {
         const int c = (int)(b / (size_t)S.R);
@@ -904,6 +913,7 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
     constexpr bool PD = DM == 2;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     extern __shared__ int lds_dyn[];
+    if (ROWS_PRIO == 1 || ROWS_PRIO == 3) __builtin_amdgcn_s_setprio(2);
     if (DM == 0) S.n_days = 1; // the shared-day instantiation: lets the compiler fold every per-day lookup of the inlined generic paths
     // dynamic LDS: order records int4[64] | per-row scratch [16 rows][ROW_KEYS] 8 B (arrival keys, then
     // the ranked arrivals) | cost block
