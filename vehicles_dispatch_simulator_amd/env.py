@@ -198,12 +198,12 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_run(self._h, int(n_ticks)))
 
     def set_run_groups(self, groups: int = 0, stagger: int = -1):
-        """Scheduling of ``run`` in neighbour-search mode (``vds_set_run_groups``): the replicas as ``groups`` independent
-        groups on streams; results do not depend on it.  ``groups <= 0`` / ``stagger < 0``: library default."""
+        """Scheduling of ``run`` (``vds_set_run_groups``): the replicas as ``groups`` independent chains of launches (parallel
+        branches of the day graph); results do not depend on it.  ``groups <= 0`` / ``stagger < 0``: library default."""
         self._chk(self._lib.vds_set_run_groups(self._h, int(groups), int(stagger)))
 
     def run_groups(self) -> int:
-        """The group count ``run`` uses as the handle stands (1 outside the hybrid neighbour-search tick)."""
+        """The group count ``run`` uses as the handle stands (1: one launch (pair) per tick over all replicas)."""
         return int(self._lib.vds_get_run_groups(self._h))
 
     def sync(self):
