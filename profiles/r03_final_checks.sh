@@ -5,8 +5,8 @@ O=gpurun_out/r03_final_checks.txt
 python -c "from vehicles_dispatch_simulator_amd import _lib; print('build', _lib.load().vds_build_id().decode())" 2>/dev/null > $O
 echo "python -m pytest tests -m gpu -q:" >> $O
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 >> $O
-echo "VDS_FUZZ_N=6000 VDS_FUZZ_MEDIUM_N=1500 VDS_FUZZ_DAYS_N=3000 pytest tests/test_gpu_fuzz.py:" >> $O
-VDS_FUZZ_N=6000 VDS_FUZZ_MEDIUM_N=1500 VDS_FUZZ_DAYS_N=3000 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | tail -2 >> $O
+echo "VDS_FUZZ_N=6000 VDS_FUZZ_MEDIUM_N=1500 VDS_FUZZ_DAYS_N=6000 pytest tests/test_gpu_fuzz.py:" >> $O
+VDS_FUZZ_N=6000 VDS_FUZZ_MEDIUM_N=1500 VDS_FUZZ_DAYS_N=6000 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | tail -2 >> $O
 for args in "cfg2 1024" "cfg2 1024 1 interleaved 6" "cfg2 1024 16 interleaved" "cfg2 1024 16 blocked" "cfg4 1024" "cfg4 1024 8 interleaved" "cfg4 1024 8 blocked"; do
   python profiles/full_check.py $args 2>&1 | grep -v amdgpu | tail -1 >> $O
 done
