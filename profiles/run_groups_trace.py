@@ -7,12 +7,13 @@ time has 0 / 1 / 2+ of them in flight and the time per tick.
 """
 import csv, sys, collections
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 148
-rows = []
+rows, queues = [], []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         n = r["Kernel_Name"]
         if "k_tick_rows" in n or "k_dfs_walk" in n:
             rows.append(("rows" if "k_tick_rows" in n else "walk", int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))))
+            queues.append(r.get("Queue_Id", "?"))
 gmax = collections.defaultdict(int)
 for k, s, e, g in rows: gmax[k] = max(gmax[k], g)
 full = [x for x in rows if x[3] == gmax[x[0]]]
@@ -38,3 +39,15 @@ for sp in spans:
     wall += ev[-1][0] - ev[0][0]; nl += len(sp)
 print("%d spans, %.2f ms covered by %d group launches" % (len(spans), wall / 1e6, nl))
 for key in sorted(hist): print("k_tick_rows in flight %d, k_dfs_walk in flight %d: %5.1f %%" % (key[0], key[1], 100.0 * hist[key] / max(1, wall)))
+
+# gaps between consecutive group launches on the same hardware queue (a branch of the day graph runs on one queue): what a
+# dependent kernel boundary costs inside a chain
+byq = collections.defaultdict(list)
+for x, q in zip(rows, queues):
+    if x[3] < gmax[x[0]]: byq[q].append(x)
+for q, v in sorted(byq.items()):
+    v.sort(key=lambda x: x[1])
+    gaps = collections.defaultdict(list)
+    for a, b in zip(v, v[1:]):
+        if b[1] - a[2] < 1_000_000: gaps[a[0] + "->" + b[0]].append(b[1] - a[2])
+    print("queue %s: %d group launches; " % (q, len(v)) + "; ".join("%s gap mean %.1f us (n %d, max %.1f)" % (k, sum(g) / len(g) / 1e3, len(g), max(g) / 1e3) for k, g in sorted(gaps.items())))
