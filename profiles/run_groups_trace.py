@@ -50,4 +50,8 @@ for q, v in sorted(byq.items()):
     gaps = collections.defaultdict(list)
     for a, b in zip(v, v[1:]):
         if b[1] - a[2] < 1_000_000: gaps[a[0] + "->" + b[0]].append(b[1] - a[2])
-    print("queue %s: %d group launches; " % (q, len(v)) + "; ".join("%s gap mean %.1f us (n %d, max %.1f)" % (k, sum(g) / len(g) / 1e3, len(g), max(g) / 1e3) for k, g in sorted(gaps.items())))
+    busy = sum(x[2] - x[1] for x in v)
+    print("queue %s: %d group launches, %.2f ms of kernel time; " % (q, len(v), busy / 1e6) + "; ".join(
+        "%s gap median %.1f us, mean of the positive ones %.1f us, %d of %d negative (overlap on the queue), max %.1f" % (
+            k, sorted(g)[len(g) // 2] / 1e3, sum(x for x in g if x > 0) / max(1, sum(1 for x in g if x > 0)) / 1e3, sum(1 for x in g if x < 0), len(g), max(g) / 1e3)
+        for k, g in sorted(gaps.items())))
