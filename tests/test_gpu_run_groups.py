@@ -183,6 +183,33 @@ def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_512_replica
     env.close()
 
 
+@pytest.mark.parametrize("name", ["tiny_kmeans_dfs2", "tiny_kmeans"])
+def test_day_maps_reloaded_on_one_handle_in_groups(name):
+    """One handle, grouped runs: an interleaved replica -> day map (replicas stored regrouped by day, padded: more stored replicas
+    than the caller's), then a block-wise map (identity storage), then one shared day - the day graph is re-built or updated as the
+    shape changes and every replica equals its own oracle each time."""
+    g = load_golden(name)
+    R = 40
+    days = synth_days(g, 3, seed=61)
+    init = _init(g, R, 23)
+    env = mk_env(g, R)
+    maps = [(np.arange(R) % 3).astype(np.int32), np.array([0] * 16 + [2] * 16 + [1] * 8, dtype=np.int32), None, (np.arange(R) % 3).astype(np.int32)]
+    for rd in maps:
+        if rd is None:
+            env.load_orders(*days[1])
+            rd, dd = np.zeros(R, dtype=np.int32), [days[1]]
+        else:
+            env.load_order_days(days, rd)
+            dd = days
+        env.set_run_groups(3, 1)
+        assert env.run_groups() == 3
+        env.reset(init)
+        env.run(env.T)
+        env.sync()
+        _check(env, g, dd, rd, init)
+    env.close()
+
+
 def test_bad_arguments_are_refused():
     g = load_golden("tiny_kmeans_dfs2")
     env = mk_env(g, 4)
