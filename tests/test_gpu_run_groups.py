@@ -157,7 +157,7 @@ def test_new_order_tables_on_one_handle_update_the_day_graph_in_place(name, grou
     env.close()
 
 
-def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_512_replicas():
+def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_256_replicas():
     g = load_golden("tiny_kmeans")
     day = synth_days(g, 1, seed=8)
     R = 40
@@ -173,14 +173,11 @@ def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_512_replica
         env.sync()
         _check(env, g, day, np.zeros(R, dtype=np.int32), init)
         env.close()
-    env = mk_env(g, 512)
-    env.load_orders(*day[0])
-    assert env.run_groups() == 2
-    env.close()
-    env = mk_env(g, 511)
-    env.load_orders(*day[0])
-    assert env.run_groups() == 1
-    env.close()
+    for R_, G_ in ((512, 2), (256, 2), (255, 1)):       # (the plain tick: two chains from 256 replicas on)
+        env = mk_env(g, R_)
+        env.load_orders(*day[0])
+        assert env.run_groups() == G_
+        env.close()
 
 
 @pytest.mark.parametrize("name", ["tiny_kmeans_dfs2", "tiny_kmeans"])

@@ -222,6 +222,11 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
 #ifndef RUN_GROUPS_BIG_R
 #define RUN_GROUPS_BIG_R 1024
 #endif
+// the plain tick gains from two chains from 256 replicas on (one box, us per tick, one chain / two: 256 replicas 27.1 / 24.6, 384
+// 34.7 / 31.5, 512 43.6 / 38.9, 1024 83.1 / 77.3, 2048 165.0 / 157.8); the hybrid tick at 256 replicas does not (167.6 / 167.5)
+#ifndef RUN_GROUPS_PLAIN_MIN_R
+#define RUN_GROUPS_PLAIN_MIN_R 256
+#endif
 #define RUN_GROUPS_MAX 16
 
 // hipGraphExecDestroy of a graph WITH PARALLEL BRANCHES (the replica groups of vds_run) needs a quiet device and a quiet
@@ -1230,8 +1235,9 @@ static int run_group_count(vds_handle *h) {
         h->run_stagger = (v && *v) ? atoi(v) : 1;
     }
     if (!h->use_graph) return 1;             // (groups only as branches of the day's graph: see vds_run)
-    // default: hybrid tick 3 groups from 1024 replicas on, 2 from 512 on; plain tick 2 groups from 512 replicas on
-    const int dflt = h->S.R < RUN_GROUPS_MIN_R ? 1 : (run_groups_hybrid(h) && h->S.R >= RUN_GROUPS_BIG_R ? 3 : 2);
+    // default: hybrid tick 3 groups from 1024 replicas on, 2 from 512 on; plain tick 2 groups from 256 replicas on
+    const int dflt = run_groups_hybrid(h) ? (h->S.R < RUN_GROUPS_MIN_R ? 1 : (h->S.R >= RUN_GROUPS_BIG_R ? 3 : 2))
+                                          : (h->S.R < RUN_GROUPS_PLAIN_MIN_R ? 1 : 2);
     int G = h->run_groups > 0 ? h->run_groups : dflt;
     const int chunks = (h->S.R + 15) / 16;
     if (G > chunks) G = chunks;
