@@ -71,16 +71,16 @@ typedef struct vds_config {
     int32_t ring_ticks;               /* arrival-ring horizon in ticks (power of two); trips that end later go
                                          through the slower "far" tables; 0 = 32 */
     int32_t far_cap;                  /* slots per (replica, cluster) far table; 0 = auto */
-    int32_t force_generic;            /* testing: 1 = generic one-wavefront-per-bucket / serial neighbour-search kernels,
-                                         2 = first-generation neighbour-search kernel (k_tick_replica), 3 = second
-                                         generation (k_tick_replica2, lower-bound rounds: what 0 falls back to when the hybrid tick's
-                                         preconditions do not hold), 4 = third
-                                         generation (k_tick_replica3: own-cluster pass once + dry-order walk; exact,
-                                         measured slower at configs[3]); 5 = the row-mapped kernel (k_tick_rows) where 0
-                                         would pick the lanes tick; 6 = the lanes tick (k_tick_lanes: lane = replica,
-                                         transposed state tables) at any replica count - 0 picks it from 32 replicas on
-                                         when there is one shared order day, no neighbour search, costs <= 254;
-                                         0 = fastest */
+    int32_t force_generic;            /* 0 = fastest.  Without neighbour search that is k_tick_dense on the dense state
+                                         layout (4-byte idle entries, 8-byte arrival entries) when V < 2^24, every cluster has
+                                         <= 255 nodes, costs fit the packed keys (0 <= cost < 2^23, none above the pickup
+                                         window), ring_ticks <= 32, fewer than 2^25 orders per day and every aligned group of
+                                         16 replicas replays one day; otherwise k_tick_rows on the wide layout.  With
+                                         neighbour search: the hybrid tick (k_tick_rows in stamp mode + k_dfs_walk).
+                                         Testing / fallbacks: 1 = generic one-wavefront-per-bucket kernel (k_tick) / serial
+                                         neighbour search (k_match_dfs); 3 = neighbour search by lower-bound rounds
+                                         (k_tick_replica2: what 0 falls back to when the hybrid tick's preconditions do not
+                                         hold); 5 = wide layout + k_tick_rows where 0 would take the dense layout */
 } vds_config;
 
 /* Fill cfg with defaults (tick 10 min, threshold 6e11, caps auto). */
@@ -275,8 +275,8 @@ int vds_read_vehicles(vds_handle *h, int32_t replica, uint8_t *state, int32_t *n
 /* Work model of the last vds_step / vds_run call sequence since vds_reset, for roofline
  * accounting (DESIGN.md "algorithmic bytes"): int64 [8] = {ticks, orders processed, matches,
  * evaluations, arrivals, dispatches, slow-path buckets, 0} summed over replicas.  Slow-path buckets: (replica, cluster, tick)
- * buckets the fast tick kernel (k_tick_rows / k_tick_lanes) had to hand to a slower path since vds_reset - idle list beyond
- * its register / LDS tables, arrivals through the far tables, an oversize arrival slot, a cost block beyond LDS (INTEGRATION.md
+ * buckets the fast tick kernel (k_tick_dense / k_tick_rows) had to hand to a slower path since vds_reset - idle list beyond
+ * its register tables, arrivals through the far tables, an oversize arrival slot, a cost block beyond LDS (INTEGRATION.md
  * "Limits"): 0 in the generic and neighbour-search kernels, which have no such split. */
 int vds_read_work(vds_handle *h, int64_t *out);
 
@@ -313,16 +313,18 @@ int vds_cluster_cost_sums(int32_t device, const int32_t *cost, int32_t N, const 
 const char *vds_cluster_cost_sums_error(void);
 
 /* Name of the kernel that vds_step launches for the main part of a tick with the handle's current tables (the one
- * vds_profile_enable brackets with events): "k_tick_rows", "k_tick", "k_dfs_hybrid" (k_tick_rows in stamp mode + k_dfs_walk), "k_tick_replica3",
- * "k_tick_replica2", "k_tick_replica" or "k_match_dfs".  Valid after vds_load_orders; static string. */
+ * vds_profile_enable brackets with events): "k_tick_dense", "k_tick_rows", "k_tick", "k_dfs_hybrid" (k_tick_rows in stamp mode +
+ * k_dfs_walk), "k_tick_replica2" or "k_match_dfs".  Valid after vds_load_orders; static string. */
 const char *vds_main_kernel(const vds_handle *h);
 
 /* Library/ABI version: (major << 16) | minor. */
 int32_t vds_version(void);
 
-/* Which sources this binary was built from: "src:<first 12 hex digits of sha1 over the .hip sources of csrc/, vds_device.h and vds.h in
- * Makefile order>" (`make -C vehicles_dispatch_simulator_amd/csrc srchash` prints the same for a checkout), with a
- * "+prof" / "+dbg" / "+canary" suffix for the instrumented builds.  bench.py prints it and compares it with the build the
+/* Which sources this binary was built from: "src:<kernels>+<host>" - the first 12 hex digits of the sha1 over the KERNEL sources of
+ * csrc/ (the .hip kernel files, vds_kernels_common.h, vds_device.h) and the first 8 of the sha1 over the host side (vds_api.hip,
+ * vds.h); `make -C vehicles_dispatch_simulator_amd/csrc srchash` prints the same for a checkout, `make kernelhash` the kernel half
+ * (what the committed rocprofv3 figures are keyed by: they survive host-only edits).  Instrumented builds append "+prof" / "+dbg" /
+ * "+canary".  bench.py prints it and compares it with the build the
  * committed rocprofv3 figures (profiles/traffic.json, limiter.json) were measured on.  Static string. */
 const char *vds_build_id(void);
 

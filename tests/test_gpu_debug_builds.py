@@ -33,10 +33,10 @@ sys.path.insert(0, %r)
 from oracle.oracle import Oracle
 from vehicles_dispatch_simulator_amd import workloads, _lib
 assert _lib.load().vds_build_id().decode().endswith(%r), _lib.load().vds_build_id()
-for neighbor, fg, R, veh in %r:
+for neighbor, fg, R, veh, dd in %r:
     w = workloads.tiny(neighbor=neighbor, vehicles=veh, orders=4000)
     init = w.vehicle_nodes(R)
-    env = w.make_env(R, force_generic=fg)
+    env = w.make_env(R, force_generic=fg, dense_debug=dd)
     env.reset(init)
     env.run(env.T)
     got, cn = env.orders(), env.counters()
@@ -64,14 +64,15 @@ def run_worker(lib, suffix, cases):
 def test_self_checking_walk_build():
     lib = build("dbg", "libvds_dbg.so")
     # scarce vehicles: most orders run dry, redo chains and rejects; two replica counts
-    out = run_worker(lib, "+dbg", [(True, 0, 8, 40), (True, 0, 37, 25), (True, 0, 5, 90)])
+    out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)])
     assert "k_dfs_hybrid" in out
     assert "check" not in out.replace("vds_debug_check", ""), out[-3000:]
 
 
 def test_guarded_build_all_tick_paths():
     lib = build("canary", "libvds_canary.so")
-    cases = [(False, 0, 19, 150), (False, 1, 5, 150), (False, 5, 37, 150), (False, 6, 70, 150), (True, 0, 9, 40), (True, 2, 4, 40), (True, 3, 6, 40), (True, 4, 6, 40)]
+    cases = [(False, 0, 19, 150, None), (False, 0, 37, 150, (8, 0, 0, 0)), (False, 0, 37, 150, (4, 0, 0, 0)), (False, 0, 21, 150, (16, 12, 2, 0)), (False, 0, 5, 150, (16, 0, 0, 1)),
+             (False, 1, 5, 150, None), (False, 5, 37, 150, None), (True, 0, 9, 40, None), (True, 3, 6, 40, None), (True, 1, 3, 40, None)]
     out = run_worker(lib, "+canary", cases)
     assert out.count("ok ") == len(cases)
 
@@ -82,7 +83,7 @@ def test_guarded_build_replica_days_and_dispatch():
     env = dict(os.environ, VDS_LIB=lib)
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_replica_days.py"),
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
-                        "(replica and not full_size) or tiny_dispatch-fast or tiny_dispatch-generic or tiny_dispatch-lanes_l2 or tiny_dispatch_dfs2-fast or device_resident or (burst and (fast or lanes_auto))"],
+                        "(replica and not full_size) or tiny_dispatch-fast or tiny_dispatch-generic or tiny_dispatch-dense8 or tiny_dispatch-dense_tiny or tiny_dispatch_dfs2-fast or device_resident or (burst and (fast or dense4))"],
                        env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
 

@@ -1,6 +1,6 @@
 """Neighbour-search mode on shapes the golden fixtures do not reach, each replica against the CPU oracle (bit-exact),
-through all neighbour-search engines (default: hybrid tick = k_tick_rows in stamp mode + k_dfs_walk; k_tick_replica2 = force_generic 3: lower-bound rounds; k_tick_replica3 = force_generic 4:
-own-cluster pass once + dry-order walk; k_tick_replica = force_generic 2: lists edited in place):
+through all neighbour-search engines (default: hybrid tick = k_tick_rows in stamp mode + k_dfs_walk; k_tick_replica2 =
+force_generic 3: lower-bound rounds, what the hybrid tick falls back to; force_generic 1: the serial form k_match_dfs):
 visit sequences longer than 256 clusters (several batches per wavefront), idle lists far beyond the register tables,
 more than 16 arrivals of one bucket in one tick, every vehicle starting in a handful of clusters."""
 import random
@@ -22,11 +22,11 @@ def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_df
     rel = synth.release_minutes(start)
     off, idx = neighbors_to_csr(city.neighbors)
     results = {}
-    for mode in (0, 3, 4, 2):
+    for mode in (0, 3, 1):
         env = BatchedDispatchEnv(city.cost, city.node2cluster, off, idx, replicas=R, vehicles=V, depth_limit=depth,
                                  neighbor_can_server=True, force_generic=mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
         env.load_orders(rel, pick, dele)
-        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 4: "k_tick_replica3", 2: "k_tick_replica"}[mode]
+        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs"}[mode]
         env.reset(init)
         env.run(env.T)
         results[mode] = (env.orders(), env.counters(), env.obs(), [env.lists(r) for r in range(R)])

@@ -122,7 +122,7 @@ def test_api_misuse_is_reported_not_fatal():
     assert env._lib.vds_apply_dispatch_device(env._h, 65, C.c_void_p(1)) != 0          # K > 64
     assert env._lib.vds_apply_dispatch_device(env._h, 4, None) != 0                    # no tensor
     assert env._lib.vds_counters_device(env._h, None) != 0
-    assert env._lib.vds_main_kernel(env._h) == b"k_tick_rows"
+    assert env._lib.vds_main_kernel(env._h) == b"k_tick_dense"
     env.close()
 
 
@@ -244,15 +244,15 @@ def make_env(g, R, **kw):
     return env
 
 
-@pytest.mark.parametrize("fg", [0, 6])
+@pytest.mark.parametrize("fg", [0, 5])
 def test_slow_path_buckets_are_counted(fg):
     """vds_read_work[6]: buckets the fast kernel hands to a slower path.  None on an ordinary day; every tick of the crowded
-    cluster when 600 vehicles sit in one cluster (beyond the register / LDS tables of both fast kernels)."""
+    cluster when 600 vehicles sit in one cluster (beyond the register tables of both fast kernels)."""
     g = load_golden("tiny_kmeans")
     env = make_env(g, 2, force_generic=fg)
     env.reset(np.tile(g["veh_node"], (2, 1)))
     env.run(env.T)
-    assert env.work()["slow_path_buckets"] == 0 and env.main_kernel() == ("k_tick_lanes" if fg == 6 else "k_tick_rows")
+    assert env.work()["slow_path_buckets"] == 0 and env.main_kernel() == ("k_tick_rows" if fg == 5 else "k_tick_dense")
     env.close()
     g = dict(g); g["V"] = np.int64(600)
     nodes5 = np.flatnonzero(g["node2cluster"] == 5)

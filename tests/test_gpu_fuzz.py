@@ -47,7 +47,7 @@ def random_case(seed):
     dele = rng.choice(valid_nodes, size=O).astype(np.int32)
     cfg = dict(neighbor=bool(rng.random() < 0.5), depth=int(rng.integers(-1, 4)),
                threshold=int(rng.choice([600_000_000_000, 600_000_000_000, 40, 8, 0])),
-               ring_ticks=int(rng.choice([32, 32, 8, 2])), force_generic=int(rng.choice([0, 0, 0, 1, 2, 3, 4])),
+               ring_ticks=int(rng.choice([32, 32, 8, 2])), force_generic=int(rng.choice([0, 0, 0, 1, 5, 3, 0])),
                tick=int(rng.choice([10, 10, 5, 15])), R=int(rng.integers(1, 9)), dispatch=bool(rng.random() < 0.4))
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 
@@ -79,7 +79,7 @@ def medium_case(seed):
         dele[sel] = rng.choice(hot_nodes, size=int(sel.sum()))
     cfg = dict(neighbor=bool(rng.random() < 0.8), depth=int(rng.integers(0, 5)),
                threshold=int(rng.choice([600_000_000_000, 600_000_000_000, 30])),
-               ring_ticks=int(rng.choice([32, 32, 4])), force_generic=int(rng.choice([0, 0, 0, 2, 3, 4])),
+               ring_ticks=int(rng.choice([32, 32, 4])), force_generic=int(rng.choice([0, 0, 0, 5, 3, 0])),
                tick=int(rng.choice([10, 10, 5])), R=int(rng.integers(1, 4)), dispatch=bool(rng.random() < 0.3))
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 
@@ -100,14 +100,13 @@ def run_case(seed, case, idle_cap=None):
     R, N = cfg["R"], cost.shape[0]
     rng = np.random.default_rng(1000 + seed)
     init = rng.choice(valid_nodes, size=(R, V)).astype(np.int32) if V else np.zeros((R, 0), np.int32)
-    # half of the cases that would run the default kernels take the lanes tick (k_tick_lanes) instead, with random lanes per
-    # bucket / LDS table sizes / forced slow path (its own random stream: the cases above stay what they were); with neighbour
-    # search or costs beyond a byte the library falls back to its usual choice
+    # the cases that run the default kernels take the dense tick (k_tick_dense) when its preconditions hold: random lanes per
+    # replica / fast-path table sizes / forced slow path (its own random stream: the cases above stay what they were); with
+    # neighbour search or a live pickup window the library keeps the wide layout
     lr = np.random.default_rng(90_000 + seed)
     fg, kw = cfg["force_generic"], {}
-    if fg == 0 and lr.random() < 0.5:
-        fg = 6
-        kw["lanes_debug"] = (int(lr.integers(-1, 4)), int(lr.choice([0, 16, 32])), int(lr.choice([0, 8, 16])), int(lr.random() < 0.15))
+    if fg == 0:
+        kw["dense_debug"] = (int(lr.choice([16, 8, 4])), int(lr.choice([0, 0, 8, 24, 40])), int(lr.choice([0, 0, 2, 5])), int(lr.random() < 0.1))
     env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
                              tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
                              force_generic=fg, idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V), **kw)

@@ -148,33 +148,30 @@ MODES = {
     "generic": {"force_generic": True},      # one wavefront per bucket
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
-    "dfs_v1": {"force_generic": 2},          # neighbour search by the first-generation kernel (lists edited in place)
-    "dfs_v2": {"force_generic": 3},          # ... by the second-generation kernel (lower-bound rounds); default = hybrid tick
-    "dfs_v3": {"force_generic": 4},          # ... by the third-generation kernel (own-cluster pass once + dry-order walk); default = second
-    # lanes tick (k_tick_lanes, layout T: lane = replica; the default from 32 replicas on when there is no neighbour search) -
-    # one, two, four lanes per bucket; tiny per-lane LDS tables (buckets that outgrow them take the slow path); slow path only;
-    # far tables.  With neighbour search the library keeps its own choice (these fixtures then repeat the default run).
-    "lanes": {"force_generic": 6, "lanes_debug": (0, 0, 0, 0)},
-    "lanes_l2": {"force_generic": 6, "lanes_debug": (1, 0, 0, 0)},
-    "lanes_l4": {"force_generic": 6, "lanes_debug": (2, 0, 0, 0)},
-    "lanes_l8": {"force_generic": 6, "lanes_debug": (3, 0, 0, 0)},
-    "lanes_auto": {"force_generic": 6},
-    "lanes_tiny": {"force_generic": 6, "lanes_debug": (0, 8, 16, 0)},
-    "lanes_tiny_l4": {"force_generic": 6, "lanes_debug": (2, 4, 16, 0)},
-    "lanes_slow": {"force_generic": 6, "lanes_debug": (1, 0, 0, 1)},
-    "lanes_far": {"force_generic": 6, "ring_ticks": 2},
-    "rows": {"force_generic": 5},            # the row-mapped kernel where the lanes tick would be the default
+    "dfs_v2": {"force_generic": 3},          # neighbour search by lower-bound rounds (k_tick_replica2: what the hybrid tick falls back to)
+    # dense tick (k_tick_dense: the default without neighbour search) - 16 / 8 / 4 lanes per replica; tiny fast-path tables
+    # (buckets that outgrow them take dense_bucket_slow); slow path only; far tables.  With neighbour search or a live pickup
+    # window the library keeps the wide layout (these fixtures then repeat the default run).
+    "dense8": {"dense_debug": (8, 0, 0, 0)},
+    "dense4": {"dense_debug": (4, 0, 0, 0)},
+    "dense_tiny": {"dense_debug": (16, 8, 2, 0)},
+    "dense_tiny8": {"dense_debug": (8, 12, 3, 0)},
+    "dense_tiny4": {"dense_debug": (4, 20, 1, 0)},
+    "dense_slow": {"dense_debug": (16, 0, 0, 1)},
+    "dense_far": {"dense_debug": (8, 0, 0, 0), "ring_ticks": 2},
+    "rows": {"force_generic": 5},            # wide layout + the row-mapped kernel where the dense tick is the default
+    "rows_far": {"force_generic": 5, "ring_ticks": 2},
 }
-LANES = [m for m in MODES if m.startswith("lanes")]
+DENSE = [m for m in MODES if m.startswith("dense")]
 
 
 def _applies(name, mode):
-    """Mode x fixture pairs that would only repeat the default run are left out: the lanes tick (and the explicit row-mapped
-    kernel) on fixtures with neighbour search or a live pickup window (the library keeps its own choice there), the older
-    neighbour-search kernels on fixtures without neighbour search."""
+    """Mode x fixture pairs that would only repeat the default run are left out: the dense-tick variants (and the explicit
+    row-mapped kernel) on fixtures with neighbour search or a live pickup window (the library keeps its own choice there),
+    the fallback neighbour-search kernel on fixtures without neighbour search."""
     g = load_golden(name)
     searching = bool(g["neighbor_can_server"]) and int(g["depth_limit"]) > 0
-    if mode.startswith("lanes") or mode == "rows":
+    if mode.startswith("dense") or mode.startswith("rows"):
         return not searching and "window" not in name
     if mode.startswith("dfs_"):
         return searching
@@ -194,7 +191,7 @@ def test_device_resident_dispatch_tensor(name):
     run_day(g, R=5, same_init=True, device_dispatch=True)
 
 
-@pytest.mark.parametrize("name,mode", [(n, m) for n in ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid"] for m in ["fast", "generic", "rows"] + LANES if _applies(n, m)])
+@pytest.mark.parametrize("name,mode", [(n, m) for n in ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid"] for m in ["fast", "generic", "rows"] + DENSE if _applies(n, m)])
 def test_many_replicas_ragged(name, mode):
     """R not a multiple of the workgroup's replica run; every replica its own vehicle seed."""
     g = load_golden(name)
@@ -224,7 +221,7 @@ def test_tight_ring_cap_overflow_is_reported():
     env.close()
 
 
-@pytest.mark.parametrize("mode", ["fast", "generic", "far"] + LANES)
+@pytest.mark.parametrize("mode", ["fast", "generic", "far"] + DENSE)
 def test_burst_of_identical_orders(mode):
     """100 identical orders / 120 co-located vehicles: ties everywhere, 100 arrivals in one slot."""
     g, P = _burst(load_golden("tiny_kmeans"), 100)
@@ -253,7 +250,7 @@ def test_small_caps_overflow_is_reported():
     env.close()
 
 
-@pytest.mark.parametrize("mode", ["fast", "generic"] + LANES)
+@pytest.mark.parametrize("mode", ["fast", "generic"] + DENSE)
 def test_all_vehicles_in_one_cluster_oversize_bucket(mode):
     """> 256 idle vehicles in one cluster exercises the deferred 16-slot kernel."""
     g = load_golden("tiny_kmeans")

@@ -15,7 +15,7 @@ from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth, workloads
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"fast": dict(), "generic": dict(force_generic=1), "gen1": dict(force_generic=2), "gen2": dict(force_generic=3), "gen3": dict(force_generic=4)}
+MODES = {"fast": dict(), "generic": dict(force_generic=1), "rows": dict(force_generic=5), "gen2": dict(force_generic=3), "dense8": dict(dense_debug=(8, 0, 0, 0)), "dense4_tiny": dict(dense_debug=(4, 12, 2, 0))}
 
 
 def synth_days(g, n_days, seed):
@@ -48,7 +48,7 @@ def mk_oracle(g, day):
 
 
 @pytest.mark.parametrize("name,mode", [("tiny_kmeans", "fast"), ("tiny_kmeans", "generic"), ("tiny_grid", "fast"),
-                                       ("tiny_kmeans_dfs2", "fast"), ("tiny_kmeans_dfs2", "gen1"), ("tiny_kmeans_dfs2", "gen2"), ("tiny_kmeans_dfs2", "gen3"), ("tiny_kmeans_dfs2", "generic"),
+                                       ("tiny_kmeans", "rows"), ("tiny_kmeans_dfs2", "fast"), ("tiny_kmeans_dfs2", "gen2"), ("tiny_kmeans_dfs2", "generic"),
                                        ("tiny_window6", "fast"), ("tiny_empty_clusters_dfs2", "fast")])
 def test_every_replica_replays_its_own_day(name, mode):
     g = load_golden(name)
@@ -125,7 +125,7 @@ def test_strided_form_and_identical_days_equal_the_shared_day_kernel():
     day = (g["o_release_min"], g["o_pickup"], g["o_delivery"])
     O = day[0].size
     ref = mk_env(g, R); ref.load_orders(*day); ref.reset(init); ref.run(ref.T)
-    assert ref.main_kernel() == "k_tick_rows"
+    assert ref.main_kernel() == "k_tick_dense"
     exp, expc = ref.orders(), ref.counters()
     # (a) R copies of the day, stride O: every row goes through the per-row variant
     a = mk_env(g, R)

@@ -96,7 +96,7 @@ def test_plain_tick_per_replica_days_in_groups(layout):
     init = _init(g, R, 17)
     env = mk_env(g, R)
     env.load_order_days(days, replica_day)
-    assert env.main_kernel() == "k_tick_rows"
+    assert env.main_kernel() == "k_tick_dense"
     env.set_run_groups(3, 0)
     assert env.run_groups() == 3
     env.reset(init)
@@ -137,7 +137,7 @@ def test_grouping_does_not_change_a_bit_and_is_the_default_from_512_replicas():
 def test_new_order_tables_on_one_handle_update_the_day_graph_in_place(name, groups):
     """vds_load_orders between days: a day with as many slots as the last one keeps the executable graph (its kernel parameters
     are replaced: hipGraphExecUpdate), another slot count re-builds it - every day equals the oracle either way; plain tick
-    (two groups of k_tick_rows) and hybrid tick."""
+    (two groups of k_tick_dense) and hybrid tick."""
     g = load_golden(name)
     R = 40
     base = synth_days(g, 2, seed=21)
@@ -165,7 +165,7 @@ def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_256_replica
     for groups, stagger in ((2, 0), (3, 2)):
         env = mk_env(g, R)
         env.load_orders(*day[0])
-        assert env.main_kernel() == "k_tick_rows"
+        assert env.main_kernel() == "k_tick_dense"
         env.set_run_groups(groups, stagger)
         assert env.run_groups() == groups
         env.reset(init)

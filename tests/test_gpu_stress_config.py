@@ -33,7 +33,7 @@ def test_stress_config_every_replica_vs_oracle():
     init = w.vehicle_nodes(R)
     init[7] = init[2]                                # twins at different rows / wavefronts
     env = w.make_env(R)
-    assert env.main_kernel() == "k_tick_rows"
+    assert env.main_kernel() == "k_tick_dense"
     env.reset(init)
     T = env.T
     prev_matched = np.zeros(R, dtype=np.int64)

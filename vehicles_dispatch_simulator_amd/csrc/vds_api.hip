@@ -21,28 +21,26 @@ void launch_tick_main(const Static &, const State &, int, int, hipStream_t);
 void launch_tick_work(const Static &, const State &, int, hipStream_t);
 void launch_update_only(const Static &, const State &, int, hipStream_t);
 void launch_match_dfs(const Static &, const State &, int, hipStream_t);
-void launch_tick_replica(const Static &, const State &, int, hipStream_t);
 void launch_tick_replica2(const Static &, const State &, int, hipStream_t);
-void launch_tick_replica3(const Static &, const State &, int, hipStream_t);
 void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
 void emit_tick_rows(const Emit &, const Static &, const State &, int, int, int, int);
 void emit_hybrid_rows(const Emit &, const Static &, const State &, int, int, int, int);
 void emit_hybrid_walk(const Emit &, const Static &, const State &, int, int, int);
-size_t lanes_lds_bytes(const Static &, int *);
-int lanes_prepare(const Static &);
-void lanes_read_prof(unsigned long long *, hipStream_t);
 size_t dfs_walk_lds(const Static &);
 int dfs_walk_pool(const Static &);
-size_t replica3_lds(const Static &);
-int replica3_prepare();
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, const int *, const int *, hipStream_t);
 void launch_dispatch_dense(const Static &, const State &, int, int, const int *, int, hipStream_t);
 void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
 void launch_selftest_dpp(const int *, int *, int *, int *, int *, int, hipStream_t);
-void set_ablate(int, hipStream_t);
-void read_prof(unsigned long long *, hipStream_t);
+void set_ablate_tick(int, hipStream_t);
+void read_prof_tick(unsigned long long *, hipStream_t);
+void set_ablate_dfs(int, hipStream_t);
+void read_prof_dfs(unsigned long long *, hipStream_t);
+void set_ablate_dense(int, hipStream_t);
+void read_prof_dense(unsigned long long *, hipStream_t);
+void emit_tick_dense(const Emit &, const Static &, const State &, int, int, int);
 }  // namespace vds
 
 using namespace vds;
@@ -54,6 +52,8 @@ struct DayHost {
     int O = 0;                           // all orders of the day incl. never-processed ones
     int T = 0, now0 = 0, q_base = 0, Oq = 0;
     std::vector<int> so_id;              // q - q_base -> order id
+    std::vector<int> q_value;            // q - q_base -> OrderValue (:341-342)
+    std::vector<int> q_of;               // order id -> q - q_base, -1 never processed (built on first use by the dense read side)
     std::vector<int> o_tick;             // order id -> tick (or -1 never processed)
     std::vector<long long> value_upto;   // [T+1] prefix of OrderValue of processed orders by tick
     long long value_all = 0;
@@ -68,14 +68,14 @@ struct vds_handle {
     bool have_static = false, have_orders = false, have_reset = false;
     bool dfs_mode = false;
     bool dfs2_ok = false;   // k_tick_replica2 preconditions hold (see vds_kernels.hip)
-    bool dfs3_ok = false;   // k_tick_replica3 preconditions hold
     bool hybrid_ok = false; // hybrid neighbour-search tick (k_tick_rows in stamp mode + k_dfs_walk) preconditions hold
     long long blk_ints = 0; // total size of the per-cluster cost blocks
-    // lanes tick (k_tick_lanes, layout T): static preconditions, the layout the state tables were allocated for, test overrides
-    bool lanes_static_ok = false;
-    int alloc_layoutT = -1;
-    int dbg_lanes_lg = -1, dbg_lanes_loc = 0, dbg_lanes_keys = 0, dbg_lanes_slow = 0;
-    std::vector<long long> blk8s_off;        // [C] offsets of the stride-(n_c + 1) byte blocks
+    // dense layout (k_tick_dense): static preconditions, the layout the state tables were allocated for
+    bool dense_static_ok = false;
+    int alloc_dense = -1;
+    int seq_tick0 = 0;                       // dispatch_seq at the first dispatch call of the current slot (dense keys carry the sequence number inside the slot)
+    int seq_tick = -1;                       // the slot seq_tick0 belongs to
+    int dbg_dense_lpr = 0, dbg_dense_tab = 0, dbg_dense_keys = 0, dbg_dense_slow = 0;      // vds_debug_dense (0: defaults)
     int cost_min = 0, cost_max = 0;
     int max_seq = 0;        // longest visit sequence of FindServerVehicleFunction over the clusters
     std::vector<unsigned char> lbc_host;     // host copy of Static.lbc (empty: none)
@@ -206,11 +206,6 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
     }
 }
 
-// replica count from which vds_config.force_generic == 0 picks the lanes tick (k_tick_lanes) over the row-mapped kernel
-#ifndef LANES_AUTO_MIN_R
-#define LANES_AUTO_MIN_R (1 << 30)
-#endif
-
 // replica groups of vds_run in hybrid neighbour-search mode (see run_grouped)
 // defaults (measured at configs[3], one box: R = 1024 272 -> 249 us per tick with 3 groups, 2 groups 257; R = 512 197 -> 188
 // with 2 groups.  4 groups collapse to 378 us: the runtime gives every branch of the graph a stream next to the launching one,
@@ -245,6 +240,11 @@ static void drop_run_graph(vds_handle *h) {
     }
     h->run_t0 = -1; h->run_n = 0; h->run_G = 1; h->run_stale = false;
 }
+
+// lanes per replica of k_tick_dense unless VDS_DENSE_LPR / vds_debug_dense say otherwise
+#ifndef DENSE_LPR_DEFAULT
+#define DENSE_LPR_DEFAULT 16
+#endif
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -339,12 +339,9 @@ void vds_config_init(vds_config *cfg) {
 
 const char *vds_main_kernel(const vds_handle *h) {
     if (!h || !h->have_orders) return "";
-    if (!h->dfs_mode) return h->S.layoutT ? "k_tick_lanes" : (h->S.fast_ok ? "k_tick_rows" : "k_tick");
+    if (!h->dfs_mode) return h->S.dense ? "k_tick_dense" : (h->S.fast_ok ? "k_tick_rows" : "k_tick");
     if (h->hybrid_ok && h->cfg.force_generic == 0) return "k_dfs_hybrid";
-    if (h->S.C <= 3072 && h->cfg.force_generic != 1) {
-        if (h->dfs3_ok && h->cfg.force_generic == 4) return "k_tick_replica3";
-        return (h->dfs2_ok && (h->cfg.force_generic == 0 || h->cfg.force_generic == 3 || h->cfg.force_generic == 4)) ? "k_tick_replica2" : "k_tick_replica";
-    }
+    if (h->dfs2_ok && h->cfg.force_generic != 1) return "k_tick_replica2";
     return "k_match_dfs";
 }
 
@@ -570,7 +567,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         // byte copy of the whole (column-permuted) matrix for the neighbour search
         S.cost8 = nullptr;
         if (u8) {
-            std::vector<unsigned char> c8((size_t)N * N + 16, 0);       // + padding: the staged-row copy of k_tick_replica3 reads whole dwords
+            std::vector<unsigned char> c8((size_t)N * N + 16, 0);
             bool fits = true;
             for (size_t i = 0; i < (size_t)N * N && fits; ++i) { fits = costp_host[i] >= 0 && costp_host[i] <= 255; c8[i] = (unsigned char)costp_host[i]; }
             if (fits) { unsigned char *d8; if ((rc = upload(h, &d8, c8))) return rc; S.cost8 = d8; }
@@ -593,27 +590,39 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
             }
         }
         { int4 *d4o; if ((rc = upload(h, &d4o, cdo))) return rc; S.cdesc_ord = d4o; }
-        // lanes tick: byte blocks with row stride n_c + 1 whose extra column holds 0xFF - the loc byte of a taken / absent idle
-        // entry points there, so such an entry loses every comparison without a test in the match loop.  Needs costs <= 254.
-        S.blk8s = nullptr;
-        h->blk8s_off.assign(C, 0);
-        bool s_ok = S.u8_ok && max_nc <= 254;
-        for (size_t i = 0; i < blk.size() && s_ok; ++i) s_ok = blk[i] <= 254;
-        if (s_ok) {
+        // dense layout (k_tick_dense): cost blocks with row stride n_c + 1 whose extra column holds the dead cost - the loc byte of a
+        // taken / absent idle entry names that column, so such an entry loses every comparison without a test in the match loop.
+        // Bytes (column value 0xFF) when every cost is <= 254, ints (DENSE_DEAD_COST) otherwise.
+        S.blk8s = nullptr; S.blk32s = nullptr; S.cdesc_dense = nullptr;
+        bool d_ok = max_nc <= 255;
+        bool d8 = d_ok && S.u8_ok;
+        for (size_t i = 0; i < blk.size() && d8; ++i) d8 = blk[i] <= 254;
+        if (d_ok) {
+            std::vector<long long> doff(C, 0);
             long long tot = 0;
-            for (int c = 0; c < C; ++c) { const long long nc = cdesc[c].x; h->blk8s_off[c] = tot; tot += (nc * (nc + 1) + 15) / 16 * 16; }
-            s_ok = tot < (1ll << 31);
-            if (s_ok) {
-                std::vector<unsigned char> b8s((size_t)std::max<long long>(tot, 16), 0xFF);
+            const long long esz = d8 ? 1 : 4;
+            for (int c = 0; c < C; ++c) { const long long nc = cdesc[c].x; doff[c] = tot; tot += (nc * (nc + 1) * esz + 15) / 16 * 16; }      // byte offsets, 16-byte aligned
+            d_ok = tot < (1ll << 31);
+            if (d_ok) {
+                std::vector<unsigned char> bs((size_t)std::max<long long>(tot, 16), 0);
                 for (int c = 0; c < C; ++c) {
                     const long long nc = cdesc[c].x;
-                    for (long long pp = 0; pp < nc; ++pp)
-                        for (long long l = 0; l < nc; ++l) b8s[(size_t)(h->blk8s_off[c] + pp * (nc + 1) + l)] = (unsigned char)blk[(size_t)cdesc[c].y + pp * nc + l];
+                    for (long long pp = 0; pp < nc; ++pp) {
+                        for (long long l = 0; l <= nc; ++l) {
+                            const int v = l < nc ? blk[(size_t)cdesc[c].y + pp * nc + l] : (d8 ? 0xFF : DENSE_DEAD_COST);
+                            if (d8) bs[(size_t)(doff[c] + pp * (nc + 1) + l)] = (unsigned char)v;
+                            else memcpy(bs.data() + (size_t)(doff[c] + (pp * (nc + 1) + l) * 4), &v, 4);
+                        }
+                    }
                 }
-                unsigned char *d8; if ((rc = upload(h, &d8, b8s))) return rc; S.blk8s = d8;
+                unsigned char *db; if ((rc = upload(h, &db, bs))) return rc;
+                if (d8) S.blk8s = db; else S.blk32s = reinterpret_cast<const int *>(db);
+                std::vector<int4> cdd(C);
+                for (int i = 0; i < C; ++i) cdd[i] = make_int4(cdesc[corder[i]].x, (int)doff[corder[i]], corder[i], 0);
+                int4 *d4d; if ((rc = upload(h, &d4d, cdd))) return rc; S.cdesc_dense = d4d;
             }
         }
-        h->lanes_static_ok = s_ok;
+        h->dense_static_ok = d_ok;
     }
     h->max_seq = 0;
     for (int c = 0; c < C; ++c) h->max_seq = std::max(h->max_seq, dfs_off[c + 1] - dfs_off[c]);
@@ -633,7 +642,11 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     // LDS budget for the cluster cost block
     const int lds_budget_ints = (64 * 1024) / 4;
     h->lds_ints = std::min((max_nc * max_nc + 3) / 4 * 4, lds_budget_ints);
-    h->lanes_static_ok = h->lanes_static_ok && !h->dfs_mode && S.fast_ok && S.V < (1 << 24);
+    {   // dense layout: no neighbour search, packed keys, 24-bit vehicle ids, the largest block (stride n_c + 1) within the LDS budget
+        const long long esz = S.blk8s ? 1 : 4;
+        h->dense_static_ok = h->dense_static_ok && !h->dfs_mode && S.fast_ok && S.V < (1 << 24) &&
+                             (long long)max_nc * (max_nc + 1) * esz <= 64 * 1024 && h->cfg.force_generic == 0;
+    }
     h->have_static = true;
     return VDS_OK;
 }
@@ -656,17 +669,14 @@ static int alloc_state(vds_handle *h, int O) {
     ring_cap = round_up(ring_cap, 16);
     if (ring_cap > 65520) return fail(h, VDS_EINVAL, "ring_cap=%d > 65520 unsupported", ring_cap);
     int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
-    S.G = (R + 63) / 64;
-    if (S.layoutT && (std::max(idle_cap, S.idle_cap) > 65532 || H > 32)) S.layoutT = 0;      // list positions travel in 16 bits, insert ticks in 5
-    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_layoutT >= S.layoutT && h->alloc_R == R)
+    if (S.dense && H > 32) S.dense = 0;                  // dense keys carry the insert tick modulo 64: a slot's entries must be younger than 32 ticks
+    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_dense == S.dense && h->alloc_R == R)
         return VDS_OK;                                   // another day on the same handle: the state tables still fit
     for (void *p : h->state_allocs) dev_free(p);
     h->state_allocs.clear();
     S.idle_cap = idle_cap; S.fl_cap = far_cap; S.in_cap = far_cap; S.H = H; S.ring_cap = ring_cap;
     const size_t B = (size_t)C * R;
-    // layout T pads the replica dimension of idle / ring to whole groups of 64 (vds_device.h); its tables also hold layout 0
-    const size_t BT = S.layoutT ? (size_t)C * S.G * 64 : B;
-    h->alloc_layoutT = S.layoutT;
+    h->alloc_dense = S.dense;
     h->alloc_R = R;
     int rc;
     struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
@@ -678,11 +688,14 @@ static int alloc_state(vds_handle *h, int O) {
         h->alloc_sink = &h->idle_allocs;
         for (void *p : h->idle_allocs) dev_free(p);
         h->idle_allocs.clear();
-        rc = dev_alloc(h, &D.idle, std::max(B * idle_cap, BT * idle_cap / 2));      // (layout T: 4-byte entries)
+        rc = dev_alloc(h, &D.idle, S.dense ? (B * idle_cap + 1) / 2 : B * idle_cap);      // (dense layout: 4-byte entries)
         h->alloc_sink = keep;
         if (rc) return rc;
     }
-    if ((rc = dev_alloc(h, &D.ring, (size_t)H * BT * ring_cap))) return rc;
+    if ((rc = dev_alloc(h, &D.ring, S.dense ? ((size_t)H * B * ring_cap + 1) / 2 : (size_t)H * B * ring_cap))) return rc;      // (dense: 8-byte entries)
+    D.ring_min = nullptr;
+    if (S.dense && (rc = dev_alloc(h, &D.ring_min, (size_t)H * B * ring_cap))) return rc;
+    S.ring_min_on = D.ring_min != nullptr;
     if ((rc = dev_alloc(h, &D.ring_cnt, (size_t)H * B))) return rc;
     if ((rc = dev_alloc(h, &D.fl, B * far_cap))) return rc;
     if ((rc = dev_alloc(h, &D.inbox, 2 * B * far_cap))) return rc;
@@ -713,7 +726,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->order_allocs.clear();
         h->run_stale = true;
         h->have_orders = false; h->have_reset = false;
-        h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
+        h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
         h->err.clear();
     }
     Static &S = h->S;
@@ -775,6 +788,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
         H.Oq = n_proc;
         H.so_id.assign(n_proc, 0);
+        H.q_value.assign(n_proc, 0);
         H.value_upto.assign(T + 1, 0);
         std::vector<int> toff(T + 1, 0);
         const size_t rec0 = so_rec.size(), oq0 = ord_q.size();
@@ -791,6 +805,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                 int q = fill[(size_t)ti * C + pc]++;
                 so_rec[rec0 + q] = make_int4(i, h->node_local[pk[i]] | (h->node_local[dl[i]] << 16), dc | (pc << 16), value[i]);
                 H.so_id[q] = i;
+                H.q_value[q] = value[i];
                 so_pnode[rec0 + q] = pk[i];
                 ord_q[oq0 + k++] = (int)rec0 + q;                       // absolute positions
                 toff[ti + 1]++;
@@ -912,56 +927,22 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[day_of_internal[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
         int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
     }
-    // ---- lanes tick (k_tick_lanes, layout T: lane = replica): one shared order day, byte costs <= 254, no neighbour search.
-    //      force_generic 0: from 32 replicas on; 6: at any replica count; 5 (and everything else): the row-mapped kernel.
+    // ---- dense layout (k_tick_dense: 4-byte idle entries, 8-byte arrival entries): the plain tick with one order day per workgroup
+    //      chunk (day modes 0 / 1), ids that fit the packed keys.  vds_config.force_generic 5 keeps the wide layout and k_tick_rows.
+    S.dense = (h->dense_static_ok && (n_days == 1 || S.chunk_days) && Omax < (1 << DENSE_ID_BITS)) ? 1 : 0;
     {
-        S.G = (S.R + 63) / 64;
-        // per-lane LDS tables: idle entries (4 B each) and arrival slots (8 B each); tuning knobs VDS_LANES_LOC / VDS_LANES_KEYS /
-        // VDS_LANES_LG (environment, read here) or vds_debug_lanes
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
-        S.lane_loc_slots = round_up(std::max(16, h->dbg_lanes_loc > 0 ? h->dbg_lanes_loc : env_int("VDS_LANES_LOC", 32)), 16);
-        S.lane_key_slots = std::max(8, h->dbg_lanes_keys > 0 ? h->dbg_lanes_keys : env_int("VDS_LANES_KEYS", 16));
-        S.lane_force_slow = h->dbg_lanes_slow;
-        S.lane_ablate = env_int("VDS_LANES_ABLATE", 0);
-        const int force_lg = h->dbg_lanes_lg >= 0 ? h->dbg_lanes_lg : env_int("VDS_LANES_LG", -1);
-        const bool can = h->lanes_static_ok && n_days == 1 && Omax <= (1 << 26) && lanes_prepare(S) == 0;
-        const int auto_min_r = env_int("VDS_LANES_AUTO_MIN_R", LANES_AUTO_MIN_R);
-        S.layoutT = (can && ((h->cfg.force_generic == 0 && S.R >= auto_min_r) || h->cfg.force_generic == 6)) ? 1 : 0;
-        S.cdesc_lanes = nullptr; S.lane_blocks = nullptr; S.lane_nblocks = 0;
-        if (S.layoutT) {
-            // lanes per bucket (1, 2, 4, 8) by the cluster's share of the day: the per-lane LDS tables hold lane_loc_slots idle
-            // entries and lane_key_slots arrivals, a bucket gets L times that; buckets that outgrow them take the slow path
-            std::vector<long long> deliv(C, 0), pick(C, 0);
-            for (const int4 &rr : so_rec) { deliv[rr.z & 0xFFFF]++; pick[(unsigned)rr.z >> 16]++; }
-            const double nproc = std::max<double>(1.0, (double)so_rec.size());
-            std::vector<int> lg(C, 0);
-            std::vector<double> wgt(C, 0.0);
-            for (int c = 0; c < C; ++c) {
-                const double share = deliv[c] / nproc;
-                const double a_peak = share * mto, m_exp = share * S.V;
-                const double need = std::max((a_peak * 1.6 + 6.0) / S.lane_key_slots, (m_exp * 1.3 + a_peak + 8.0) / S.lane_loc_slots);
-                lg[c] = force_lg >= 0 ? std::min(force_lg, 3) : (need <= 1.0 ? 0 : need <= 2.0 ? 1 : need <= 4.0 ? 2 : 3);
-                wgt[c] = ((double)pick[c] / nproc) * (m_exp + a_peak + 1.0) / (1 << lg[c]) + 1e-9 * (h->cl_off[c + 1] - h->cl_off[c]);
-            }
-            std::vector<int> ord(C);
-            for (int c = 0; c < C; ++c) ord[c] = c;
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wgt[a] > wgt[b]; });
-            std::vector<int4> cdl(C);
-            std::vector<int2> blocks;
-            for (int i = 0; i < C; ++i) {
-                const int c = ord[i], nc = h->cl_off[c + 1] - h->cl_off[c];
-                cdl[i] = make_int4(nc | (lg[c] << 16), (int)h->blk8s_off[c], c, nc + 1);
-                for (int wi = 0; wi < (S.G << lg[c]); ++wi) blocks.push_back(make_int2(i, wi));
-            }
-            int4 *dcl; if ((rc = upload(h, &dcl, cdl))) return rc; S.cdesc_lanes = dcl;
-            int2 *dbl; if ((rc = upload(h, &dbl, blocks))) return rc; S.lane_blocks = dbl;
-            S.lane_nblocks = (int)blocks.size();
-        }
+        if (env_int("VDS_DENSE", 1) == 0) S.dense = 0;
+        const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", DENSE_LPR_DEFAULT);
+        S.dense_lpr = (lpr == 4 || lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
+        S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, 128) : 128;
+        S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
+        S.dense_force_slow = h->dbg_dense_slow;
     }
     h->alloc_sink = nullptr;
     if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;
-    h->alloc_sink = &h->order_allocs;            // results: [R][Oq], or - layout T - [Oq][64 G]
-    rc = dev_alloc(h, &h->D.out, (size_t)(h->alloc_layoutT > 0 ? S.G * 64 : S.R) * std::max(Oqmax, 1));
+    h->alloc_sink = &h->order_allocs;            // results: [R][Oq]
+    rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1));
     h->alloc_sink = nullptr;
     if (rc) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
@@ -971,8 +952,6 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->dfs2_ok = h->dfs_mode && Omax <= (1 << 20) && Z.max_nc <= 2047 && h->cost_min >= 0 && h->cost_max < (1 << 15) &&
                      Z.V <= 20480 && Z.N <= 65534 && Z.C <= 3072 && h->blk_ints < (1ll << 29) && Z.idle_cap <= 32767 && Z.max_tick_orders < 32768 &&
                      lds2 <= 64 * 1024;
-        // k_tick_replica3: the same packing limits, 16-bit ranks inside a slot, and its (bigger) LDS footprint; byte costs
-        // need the byte copy of the matrix for the staged row
         // hybrid tick: the fast kernel's preconditions (packed keys, no live pickup window, every cost block in LDS), one
         // order day per workgroup, 16-bit ranks / positions / columns, the walk's LDS footprint
         h->S.walk_pool = 0; h->S.walk_pool = dfs_walk_pool(h->S);
@@ -987,8 +966,6 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
             h->alloc_sink = nullptr;
             if (rc) return rc;
         }
-        h->dfs3_ok = h->cfg.force_generic == 4 && h->dfs2_ok && Z.max_tick_orders < 65535 && (!Z.u8_ok || Z.cost8 != nullptr) &&
-                     replica3_lds(Z) + 4096 <= 160 * 1024 && replica3_prepare() == 0;
     }
     h->have_orders = true;
     return VDS_OK;
@@ -1040,7 +1017,7 @@ static int reset_device(vds_handle *h) {
     // vds_read_orders may look at it (it only reads orders whose tick has been stepped)
     launch_reset(S, h->D, h->d_veh_node, h->stream);
     HIPCHK(h, hipGetLastError());
-    h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0;
+    h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
     h->have_reset = true;
     return VDS_OK;
 }
@@ -1059,15 +1036,14 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     for (void *p : h->idle_allocs) dev_free(p);
     h->idle_allocs.clear();
     h->alloc_sink = &h->idle_allocs;
-    const size_t B0 = (size_t)h->S.C * h->S.R, BT0 = h->alloc_layoutT > 0 ? (size_t)h->S.C * h->S.G * 64 : B0;
-    const int rc = dev_alloc(h, &h->D.idle, std::max(B0 * cap, BT0 * cap / 2));
+    const size_t B0 = (size_t)h->S.C * h->S.R;
+    const int rc = dev_alloc(h, &h->D.idle, h->S.dense ? (B0 * cap + 1) / 2 : B0 * cap);
     h->alloc_sink = nullptr;
     if (rc) return rc;
     h->S.idle_cap = cap;
-    if (cap > 65532) h->S.layoutT = 0;       // k_tick_lanes carries list positions in 16 bits: the row-mapped kernel takes over
     h->idle_cap_grown = cap;
     // k_tick_replica2 addresses list positions with 15 bits
-    if (cap > 32767) { h->dfs2_ok = false; h->dfs3_ok = false; }
+    if (cap > 32767) h->dfs2_ok = false;
     if (cap > 16384) h->hybrid_ok = false;
     return VDS_OK;
 }
@@ -1150,10 +1126,11 @@ static int step_impl(vds_handle *h) {
             if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
             HIPCHK(h, hipEventRecord(a, h->stream));
         }
-        launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
+        if (h->S.dense) { Emit e; e.st = h->stream; emit_tick_dense(e, h->S, h->D, h->t, 0, 0); }
+        else launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
-        // the fast kernel only defers buckets whose cluster cost block does not fit LDS
-        if (!h->S.fast_ok || h->S.max_nc * h->S.max_nc > h->lds_ints) launch_tick_work(h->S, h->D, h->t, h->stream);
+        // the fast kernel only defers buckets whose cluster cost block does not fit LDS (wide layout)
+        if (!h->S.dense && (!h->S.fast_ok || h->S.max_nc * h->S.max_nc > h->lds_ints)) launch_tick_work(h->S, h->D, h->t, h->stream);
     } else if (h->hybrid_ok && h->cfg.force_generic == 0) {
         // neighbour search, hybrid: Update + own-cluster matching cluster-major (k_tick_rows, stamp mode), then one
         // workgroup per replica walks the dry orders and commits the slot (k_dfs_walk)
@@ -1165,19 +1142,15 @@ static int step_impl(vds_handle *h) {
         }
         launch_tick_hybrid(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
-    } else if (h->S.C <= 3072 && h->cfg.force_generic != 1) {   // 11 ints of LDS per cluster
+    } else if (h->dfs2_ok && h->cfg.force_generic != 1) {
         hipEvent_t a = nullptr, b = nullptr;
         if (h->profiling) {
             a = next_event(h); b = next_event(h);
             if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
             HIPCHK(h, hipEventRecord(a, h->stream));
         }
-        // neighbour search: lower-bound rounds, one workgroup per replica
-        // k_tick_replica3 (own-cluster pass once + dry-order walk) is exact but measured SLOWER than the lower-bound rounds of
-        // k_tick_replica2 at configs[3]: opt-in only
-        if (h->dfs3_ok && h->cfg.force_generic == 4) launch_tick_replica3(h->S, h->D, h->t, h->stream);
-        else if (h->dfs2_ok && (h->cfg.force_generic == 0 || h->cfg.force_generic == 3 || h->cfg.force_generic == 4)) launch_tick_replica2(h->S, h->D, h->t, h->stream);
-        else launch_tick_replica(h->S, h->D, h->t, h->stream);
+        // neighbour search: lower-bound rounds, one workgroup per replica (what the hybrid tick falls back to)
+        launch_tick_replica2(h->S, h->D, h->t, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
     } else {
         launch_update_only(h->S, h->D, h->t, h->stream);       // serial reference form
@@ -1219,8 +1192,8 @@ static int run_eager(vds_handle *h, int32_t n_ticks) {
 // phase on every SIMD (one chain: the seven workgroups of a CU start together, load together, compute together).
 static bool run_groups_hybrid(const vds_handle *h) { return h->dfs_mode && h->hybrid_ok && h->cfg.force_generic == 0; }
 static bool run_groups_plain(const vds_handle *h) {
-    // (the row-mapped kernel alone: every cost block fits LDS - no k_tick_work pass -, not the lanes layout)
-    return !h->dfs_mode && h->S.fast_ok && !h->S.layoutT && h->S.max_nc * h->S.max_nc <= h->lds_ints;
+    // (the fast kernel alone: every cost block fits LDS - no k_tick_work pass)
+    return !h->dfs_mode && h->S.fast_ok && (h->S.dense || h->S.max_nc * h->S.max_nc <= h->lds_ints);
 }
 static int run_group_count(vds_handle *h) {
     // (replicas stored regrouped by day - Static.rperm - are grouped like any others: the row map is the identity on the
@@ -1269,7 +1242,8 @@ static int build_group_graph(vds_handle *h, int32_t n_ticks, int G, hipGraph_t *
             Emit e;
             e.graph = g; e.deps = deps; e.ndeps = nd; e.node = &rows; e.err = &err;
             if (!h->dfs_mode) {                 // plain tick: the row-mapped kernel is the whole tick
-                emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+                if (h->S.dense) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
+                else emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
                 if (err != hipSuccess) break;
                 prev_rows = rows;
                 last[gi] = rows;
@@ -1401,8 +1375,9 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
     if (n < 0 || !replica || !from_cluster || !idle_pos || !target_node) return fail(h, VDS_EINVAL, "vds_apply_dispatch: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const Static &S = h->S;
-    if (S.layoutT && (long long)h->dispatch_seq + n >= (1 << 26))
-        return fail(h, VDS_ECAPACITY, "vds_apply_dispatch: more than 2^26 dispatch actions in one episode (the lanes tick orders arrivals by 26-bit ids); vds_config.force_generic = 5 selects the row-mapped kernel");
+    if (h->seq_tick != h->t) { h->seq_tick = h->t; h->seq_tick0 = h->dispatch_seq; }
+    if (S.dense && (long long)(h->dispatch_seq - h->seq_tick0) + n >= (1 << DENSE_ID_BITS))
+        return fail(h, VDS_ECAPACITY, "vds_apply_dispatch: more than 2^%d dispatch actions in one slot (the dense arrival keys carry a %d-bit sequence number); vds_config.force_generic = 5 selects the wide layout", DENSE_ID_BITS, DENSE_ID_BITS);
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) {
         order[i] = i;
@@ -1433,7 +1408,7 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
         int i = order[k];
         if (k == 0 || replica[i] != replica[order[k - 1]] || from_cluster[i] != from_cluster[order[k - 1]]) grp_off.push_back(k);
         pack[k] = h->ext2int.empty() ? replica[i] : h->ext2int[replica[i]]; pack[(size_t)n + k] = from_cluster[i]; pack[(size_t)2 * n + k] = idle_pos[i];
-        pack[(size_t)3 * n + k] = target_node[i]; pack[(size_t)4 * n + k] = h->dispatch_seq + i;   // dict insertion order = action order
+        pack[(size_t)3 * n + k] = target_node[i]; pack[(size_t)4 * n + k] = h->dispatch_seq - h->seq_tick0 + i;   // dict insertion order = action order (sequence number inside the slot)
         pack[(size_t)5 * n + k] = arrive_min ? arrive_min[i] : 0; pack[(size_t)6 * n + k] = counted ? counted[i] : 1;
     }
     const int ngroups = (int)grp_off.size();
@@ -1579,13 +1554,7 @@ static int read_orders_impl(vds_handle *h, int32_t r0, int32_t nr, uint8_t *stat
     if (rc) return rc;
     const int Oq = S.Oq, O = h->O;     // row strides: the longest day's (a shorter day leaves the tail of its row at 0 / -1)
     std::vector<int2> res((size_t)nr * std::max(Oq, 1));
-    if (Oq > 0 && nr > 0 && S.layoutT) {
-        // [Oq][64 G]: columns r0 .. r0 + nr of every order's row, transposed on the host
-        std::vector<int2> cols((size_t)Oq * nr);
-        HIPCHK(h, hipMemcpy2D(cols.data(), (size_t)nr * sizeof(int2), h->D.out + r0, (size_t)S.G * 64 * sizeof(int2), (size_t)nr * sizeof(int2), Oq, hipMemcpyDeviceToHost));
-        for (int q = 0; q < Oq; ++q)
-            for (int r = 0; r < nr; ++r) res[(size_t)r * Oq + q] = cols[(size_t)q * nr + r];
-    } else if (Oq > 0 && nr > 0 && !h->ext2int.empty()) {
+    if (Oq > 0 && nr > 0 && !h->ext2int.empty()) {
         for (int r = 0; r < nr; ++r)       // regrouped storage: the caller's replica r0 + r lives in row ext2int[r0 + r]
             HIPCHK(h, hipMemcpy(res.data() + (size_t)r * Oq, h->D.out + (size_t)h->ext2int[r0 + r] * Oq, (size_t)Oq * sizeof(int2), hipMemcpyDeviceToHost));
     } else if (Oq > 0 && nr > 0)
@@ -1630,16 +1599,10 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
     const bool want_arr = arr_off && arr_veh;
     if (want_idle) {
         std::vector<uint2> idle((size_t)C * S.idle_cap);
-        if (S.layoutT) {
-            // quads of four packed entries {veh << 8 | loc}: [C][G][idle_cap / 4][64][4]; this replica's column of every quad row
-            // one strided copy of the replica's column over every (cluster, group, quad) row, then its group's rows are picked
-            const size_t rows_per_c = (size_t)(S.idle_cap >> 2), pitch = 64 * 4 * sizeof(unsigned), rows = (size_t)C * S.G * rows_per_c;
-            std::vector<unsigned> col(rows * 4);
-            HIPCHK(h, hipMemcpy2D(col.data(), 4 * sizeof(unsigned), reinterpret_cast<const unsigned *>(h->D.idle) + (size_t)(replica & 63) * 4, pitch, 4 * sizeof(unsigned), rows, hipMemcpyDeviceToHost));
-            for (int c = 0; c < C; ++c) {
-                const unsigned *src = col.data() + ((size_t)c * S.G + (size_t)(replica >> 6)) * rows_per_c * 4;
-                for (int e = 0; e < S.idle_cap; ++e) idle[(size_t)c * S.idle_cap + e] = make_uint2(src[e] >> 8, src[e] & 0xFFu);
-            }
+        if (S.dense) {      // packed entries {veh << 8 | loc}
+            std::vector<unsigned> pk((size_t)C * S.idle_cap);
+            HIPCHK(h, hipMemcpy2D(pk.data(), S.idle_cap * sizeof(unsigned), reinterpret_cast<const unsigned *>(h->D.idle) + (size_t)replica * S.idle_cap, (size_t)R * S.idle_cap * sizeof(unsigned), S.idle_cap * sizeof(unsigned), C, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < pk.size(); ++i) idle[i] = make_uint2(pk[i] >> 8, pk[i] & 0xFFu);
         } else
         HIPCHK(h, hipMemcpy2D(idle.data(), S.idle_cap * sizeof(uint2), h->D.idle + (size_t)replica * S.idle_cap, (size_t)R * S.idle_cap * sizeof(uint2), S.idle_cap * sizeof(uint2), C, hipMemcpyDeviceToHost));
         int n = 0;
@@ -1664,15 +1627,37 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
         std::vector<int> rcnt((size_t)H * C);
         HIPCHK(h, hipMemcpy2D(fl.data(), S.fl_cap * sizeof(int4), h->D.fl + (size_t)replica * S.fl_cap, (size_t)R * S.fl_cap * sizeof(int4), S.fl_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy2D(inb.data(), S.in_cap * sizeof(int4), h->D.inbox + ((size_t)np * C * R + replica) * S.in_cap, (size_t)R * S.in_cap * sizeof(int4), S.in_cap * sizeof(int4), C, hipMemcpyDeviceToHost));
-        if (S.layoutT) {    // [H][C][G][ring_cap][64]: one strided copy of the replica's column over every row, its group's rows picked
-            const size_t rows = (size_t)H * C * S.G * S.ring_cap;
-            std::vector<int4> col(rows);
-            HIPCHK(h, hipMemcpy2D(col.data(), sizeof(int4), h->D.ring + (replica & 63), 64 * sizeof(int4), sizeof(int4), rows, hipMemcpyDeviceToHost));
-            for (int sc = 0; sc < H * C; ++sc)
-                memcpy(ring.data() + (size_t)sc * S.ring_cap, col.data() + ((size_t)sc * S.G + (size_t)(replica >> 6)) * S.ring_cap, (size_t)S.ring_cap * sizeof(int4));
+        HIPCHK(h, hipMemcpy2D(rcnt.data(), sizeof(int), h->D.ring_cnt + replica, (size_t)R * sizeof(int), sizeof(int), (size_t)H * C, hipMemcpyDeviceToHost));
+        if (S.dense) {
+            // dense entries {veh << 8 | dest_local, key}: widened here.  The arrival minute of an order-carrying entry follows from
+            // the order's result (RealExpTime of the slot it was matched in + PickupWaitTime + OrderValue, :954-960); a
+            // dispatched vehicle's comes from ring_min
+            std::vector<uint2> r2((size_t)H * C * S.ring_cap);
+            std::vector<int> rmin((size_t)H * C * S.ring_cap);
+            HIPCHK(h, hipMemcpy2D(r2.data(), S.ring_cap * sizeof(uint2), reinterpret_cast<const uint2 *>(h->D.ring) + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(uint2), S.ring_cap * sizeof(uint2), (size_t)H * C, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy2D(rmin.data(), S.ring_cap * sizeof(int), h->D.ring_min + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(int), S.ring_cap * sizeof(int), (size_t)H * C, hipMemcpyDeviceToHost));
+            DayHost &DH = h->days[h->replica_day[replica_ext]];
+            std::vector<int2> res((size_t)std::max(DH.Oq, 1));
+            if (DH.Oq > 0) HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)replica * S.Oq, (size_t)DH.Oq * sizeof(int2), hipMemcpyDeviceToHost));
+            if (DH.q_of.empty()) { DH.q_of.assign(std::max(DH.O, 1), -1); for (int q = 0; q < DH.Oq; ++q) DH.q_of[DH.so_id[q]] = q; }
+            for (int sl = 0; sl < H; ++sl)
+                for (int c = 0; c < C; ++c) {
+                    const int k = std::min(rcnt[(size_t)sl * C + c] & 0xFFFF, S.ring_cap);
+                    for (int j = 0; j < k; ++j) {
+                        const size_t i = ((size_t)sl * C + c) * S.ring_cap + j;
+                        const uint2 e = r2[i];
+                        const int disp = dense_key_is_dispatch(e.y), id = dense_key_id(e.y), ins = dense_key_tick(e.y, std::max(last, 0));
+                        int arrive = rmin[i];
+                        if (!disp) {
+                            const int q = (id >= 0 && id < DH.O) ? DH.q_of[id] : -1;
+                            if (q < 0) return fail(h, VDS_ESTATE, "vds_read_lists: corrupt arrival entry (order %d)", id);
+                            arrive = DH.now0 + ins * S.tick_minutes + res[q].y + DH.q_value[q];
+                        }
+                        ring[i] = make_int4((int)(e.x >> 8), id, arrive, meta_pack(ins, disp, (int)(e.x & 0xFFu)));
+                    }
+                }
         } else
         HIPCHK(h, hipMemcpy2D(ring.data(), S.ring_cap * sizeof(int4), h->D.ring + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(int4), S.ring_cap * sizeof(int4), (size_t)H * C, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy2D(rcnt.data(), sizeof(int), h->D.ring_cnt + replica, (size_t)R * sizeof(int), sizeof(int), (size_t)H * C, hipMemcpyDeviceToHost));
         int n = 0;
         arr_off[0] = 0;
         std::vector<int4> ent;
@@ -1707,32 +1692,18 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
 int vds_debug_ablate(vds_handle *h, int32_t flags) {
     if (!h) return VDS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    set_ablate(flags, h->stream);
+    set_ablate_tick(flags, h->stream);
+    set_ablate_dfs(flags, h->stream);
+    set_ablate_dense(flags, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return VDS_OK;
 }
 
-// Test hook (not part of the drop-in surface): overrides for the lanes tick, effective from the next vds_load_orders on -
-// lanes per bucket (log2: 0, 1, 2; -1 = by demand share), per-lane LDS capacities (0 = defaults), force the slow path.
-int vds_debug_lanes(vds_handle *h, int32_t log2_lanes, int32_t loc_slots, int32_t key_slots, int32_t force_slow) {
+// Test hook (not part of the drop-in surface): overrides for the dense tick, effective from the next vds_load_orders on - lanes
+// per replica (16 / 8 / 4; 0 = default), idle entries / arrivals per bucket its fast path takes (0 = 128 / 64), force the slow path.
+int vds_debug_dense(vds_handle *h, int32_t lpr, int32_t tab, int32_t keys, int32_t force_slow) {
     if (!h) return VDS_EINVAL;
-    h->dbg_lanes_lg = log2_lanes; h->dbg_lanes_loc = loc_slots; h->dbg_lanes_keys = key_slots; h->dbg_lanes_slow = force_slow;
-    return VDS_OK;
-}
-
-// Timing experiments (results INVALID while non-zero): Static.lane_ablate of k_tick_lanes, effective from the next launch.
-int vds_debug_lanes_ablate(vds_handle *h, int32_t flags) {
-    if (!h) return VDS_EINVAL;
-    drop_run_graph(h);
-    h->S.lane_ablate = flags;
-    return VDS_OK;
-}
-
-// instrumented build (make prof): [4][16] cycle sums per section of k_tick_lanes' fast path by lanes-per-bucket class
-int vds_debug_lanes_prof(vds_handle *h, uint64_t *out64) {
-    if (!h || !out64) return VDS_EINVAL;
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    lanes_read_prof((unsigned long long *)out64, h->stream);
+    h->dbg_dense_lpr = lpr; h->dbg_dense_tab = tab; h->dbg_dense_keys = keys; h->dbg_dense_slow = force_slow;
     return VDS_OK;
 }
 
@@ -1770,7 +1741,10 @@ int vds_debug_poke_guard(vds_handle *h) {
 int vds_debug_read_prof(vds_handle *h, uint64_t *out32) {
     if (!h || !out32) return VDS_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    read_prof((unsigned long long *)out32, h->stream);
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    read_prof_tick((unsigned long long *)out32, h->stream);
+    read_prof_dfs((unsigned long long *)out32, h->stream);
+    read_prof_dense((unsigned long long *)out32, h->stream);
     return VDS_OK;
 }
 
@@ -1840,9 +1814,10 @@ static int apply_dispatch_device_impl(vds_handle *h, int32_t K, const void *dev_
     if (K == 0) return VDS_OK;
     if (K < 0 || K > 64 || !dev_actions) return fail(h, VDS_EINVAL, "vds_apply_dispatch_device: K must be in [0, 64] and the action tensor non-null");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (h->S.layoutT && (long long)h->dispatch_seq + K >= (1 << 26))
-        return fail(h, VDS_ECAPACITY, "vds_apply_dispatch_device: more than 2^26 dispatch actions in one episode (the lanes tick orders arrivals by 26-bit ids); vds_config.force_generic = 5 selects the row-mapped kernel");
-    launch_dispatch_dense(h->S, h->D, h->t, K, (const int *)dev_actions, h->dispatch_seq, h->stream);
+    if (h->seq_tick != h->t) { h->seq_tick = h->t; h->seq_tick0 = h->dispatch_seq; }
+    if (h->S.dense && (long long)(h->dispatch_seq - h->seq_tick0) + K >= (1 << DENSE_ID_BITS))
+        return fail(h, VDS_ECAPACITY, "vds_apply_dispatch_device: more than 2^%d dispatch actions in one slot (the dense arrival keys carry a %d-bit sequence number); vds_config.force_generic = 5 selects the wide layout", DENSE_ID_BITS, DENSE_ID_BITS);
+    launch_dispatch_dense(h->S, h->D, h->t, K, (const int *)dev_actions, h->dispatch_seq - h->seq_tick0, h->stream);
     HIPCHK(h, hipGetLastError());
     h->dispatch_seq += K;
     return VDS_OK;

@@ -16,6 +16,7 @@
 //   fl/inbox                     "far" entries whose arrival lies >= H ticks ahead (rare): owner-private
 //                                list + double-buffered inbox, migrated into the ring when they get near
 //   out      [R][Oq] {veh, wait} per-order result, indexed by bucket-sorted order position q
+// The plain tick (no neighbour search) runs on the DENSE variant of idle / ring (4-byte / 8-byte entries): see "Dense layout".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -121,23 +122,16 @@ struct Static {
     int max_tick_orders;             // most orders processed in one tick
     int r_lo;                        // hybrid tick launched for a GROUP of replicas (vds_run: groups on streams, the stamp-mode k_tick_rows
                                      // of one group under the k_dfs_walk of another): first replica of the launch, a multiple of 16
-    // ---- layout T ("lanes" tick, k_tick_lanes in vds_lanes.hip): lane = replica.  Per-replica tables are transposed inside
-    // groups of 64 replicas so that the 64 lanes of a wavefront - the same cluster in 64 consecutive replicas - touch
-    // consecutive addresses:
-    //   idle  u32 {veh << 8 | loc_local}   [C][G][idle_cap / 4][64][4]   (entry e of replica r: quad e / 4, column r % 64, element e % 4)
-    //   ring  int4 (unchanged entry)       [H][C][G][ring_cap][64]
-    //   out   int2 {veh, wait}             [Oq][64 G]
-    // hdr / cnt / ring_cnt / fl / inbox keep their [C][R] layouts.
-    int layoutT;                     // 1: the tables above are in layout T
-    int G;                           // groups of 64 replicas = ceil(R / 64)
-    const int4 *cdesc_lanes;         // [C] {n_c | log2(lanes per bucket) << 16, offset into blk8s, cluster, row stride n_c + 1}, heaviest first
-    const int2 *lane_blocks;         // [lane_nblocks] {index into cdesc_lanes, wavefront index inside the cluster}
-    int lane_nblocks;
-    const unsigned char *blk8s;      // per-cluster byte cost blocks with row stride n_c + 1; column n_c holds 0xFF (the cost of a taken / absent entry)
-    int lane_loc_slots, lane_key_slots;   // per-lane LDS capacities: idle entries / arrivals per lane (x lanes per bucket)
-    int lane_force_slow;             // testing: every wavefront takes the table-free slow path
-    int lane_ablate;                 // timing experiments only (results INVALID when non-zero): bit0 no counter atomics, bit1 no result
-                                     // stores, bit2 no arrival posts, bit3 no list write-back, bit4 no header store
+    // ---- dense layout (the plain tick k_tick_dense, vds_tick_dense.hip; see "Dense layout" below)
+    int dense;                       // 1: idle / ring hold packed entries
+    int dense_lpr;                   // lanes per replica of k_tick_dense: 16 / 8 / 4 (4 / 8 / 16 replicas per wavefront)
+    int dense_tab, dense_keys;       // idle entries / arrivals per bucket its fast path takes (<= 128 / 64; smaller: tests)
+    int dense_force_slow;            // testing: every bucket takes dense_bucket_slow
+    int ring_min_on;                 // (dense) State.ring_min exists: arrival minutes of dispatched vehicles, for the container views
+    const int *blk32s;               // (dense, costs beyond a byte) per-cluster int cost blocks with row stride n_c + 1, column n_c = DENSE_DEAD_COST
+    const unsigned char *blk8s;      // (dense, byte costs <= 254) the same as bytes, column n_c = 0xFF: the loc byte of a taken / absent
+                                     // entry names that column, so the entry loses every comparison without a test in the match loop
+    const int4 *cdesc_dense;         // [C] {n_c, offset into blk8s / blk32s, cluster, 0}, heaviest cluster first
 };
 
 // where a host-side launcher puts its kernel: on a stream, or as a kernel node of an explicitly built hipGraph
@@ -154,7 +148,7 @@ struct State {
     int *hdr;
     long long *cnt;
     uint2 *idle;
-    int4 *ring;
+    int4 *ring;          // wide layout: int4 entries; dense layout: uint2 {veh << 8 | dest_local, key} (ring2())
     int *ring_cnt;
     int4 *fl;
     int4 *inbox;
@@ -162,40 +156,54 @@ struct State {
     int2 *out;
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
+    int *ring_min;       // dense layout: [H][C][R][ring_cap] arrival minute of a DISPATCHED vehicle's entry (order-carrying entries: recomputed
+                         // from the order's result on the read side); written by the dispatch kernels only, never read by a tick
 };
 
-// ---- layout T addressing (host and device)
-// idle entry e of (c, r): ((unsigned *)D.idle)[idleT_base + (e >> 2) * 256 + (e & 3)]
-__host__ __device__ inline size_t idleT_base(const Static &S, int c, int r) {
-    return ((((size_t)c * S.G + (size_t)(r >> 6)) * (size_t)(S.idle_cap >> 2)) * 64 + (size_t)(r & 63)) * 4;
+// ---- Dense layout (Static.dense): what the plain tick (no neighbour search) runs on when V < 2^24, every cluster has at most
+// 255 nodes, H <= 32 and order ids / dispatch sequence numbers of one slot stay below 2^25 - otherwise the wide layout above.
+//   idle   u32  [C][R][idle_cap]      {veh << 8 | loc_local}
+//   ring   uint2 [H][C][R][ring_cap]  {veh << 8 | dest_local, key}, key = (insert_tick & 63) << 26 | is_dispatch << 25 | id
+//          (id: Order.ID, or the dispatch's sequence number inside its slot).  Dict insertion order = ascending
+//          (insert_tick, is_dispatch, id); the entries of one arrival slot were inserted during the last H <= 32 ticks, so
+//          key - ((t - 32) << 26) (mod 2^32) orders them (dense_key_rel).
+//   ring_min int [H][C][R][ring_cap]  arrival minute, DISPATCH entries only
+// hdr / cnt / ring_cnt / fl / inbox / out keep their layouts (far entries stay int4 {veh, id, arrive, meta}).
+#define DENSE_DEAD_COST 0x00FFFFFF      // cost of the dead column of an int block: (cost << 7 | pos) stays a positive int
+#define DENSE_ID_BITS 25
+__host__ __device__ inline unsigned dense_pack(unsigned veh, unsigned loc) { return (veh << 8) | (loc & 0xFFu); }
+__host__ __device__ inline unsigned dense_key(int tick, int is_dispatch, int id) {
+    return ((unsigned)(tick & 63) << 26) | ((unsigned)(is_dispatch & 1) << 25) | ((unsigned)id & ((1u << DENSE_ID_BITS) - 1));
 }
-__host__ __device__ inline size_t idleT_elem(int e) { return (size_t)(e >> 2) * 256 + (size_t)(e & 3); }
-// ring entry i of (slot, c, r): D.ring[ringT_base + i * 64]
-__host__ __device__ inline size_t ringT_base(const Static &S, int slot, int c, int r) {
-    return ((((size_t)slot * S.C + c) * S.G + (size_t)(r >> 6)) * (size_t)S.ring_cap) * 64 + (size_t)(r & 63);
-}
-__host__ __device__ inline unsigned idleT_pack(unsigned veh, unsigned loc) { return (veh << 8) | (loc & 0xFFu); }
+// comparable form of a key read at tick t (insert ticks in (t - 32, t])
+__host__ __device__ inline unsigned dense_key_rel(unsigned key, int t) { return key - ((unsigned)((t - 32) & 63) << 26); }
+__host__ __device__ inline int dense_key_is_dispatch(unsigned key) { return (int)((key >> 25) & 1u); }
+__host__ __device__ inline int dense_key_id(unsigned key) { return (int)(key & ((1u << DENSE_ID_BITS) - 1)); }
+// insert tick of an entry seen at tick t_now (the slot it sits in is due after t_now, it was inserted at most H - 1 ticks ago)
+__host__ __device__ inline int dense_key_tick(unsigned key, int t_now) { return t_now - (int)(((unsigned)t_now - (key >> 26)) & 63u); }
 
 // One (cluster, replica) idle list in either layout: what the kernels shared by both layouts (reset, dispatch) go through.
 struct IdleRef {
-    uint2 *p;        // layout 0: {veh, loc_local} entries, contiguous
-    unsigned *q;     // layout T (non-null): packed entries, see Static
+    uint2 *p;        // wide layout: {veh, loc_local} entries
+    unsigned *q;     // dense layout (non-null): packed entries
     __device__ __forceinline__ uint2 get(int e) const {
         if (!q) return p[e];
-        const unsigned v = q[idleT_elem(e)];
+        const unsigned v = q[e];
         return make_uint2(v >> 8, v & 0xFFu);
     }
     __device__ __forceinline__ void set(int e, uint2 v) const {
         if (!q) p[e] = v;
-        else q[idleT_elem(e)] = idleT_pack(v.x, v.y);
+        else q[e] = dense_pack(v.x, v.y);
     }
 };
 __device__ __forceinline__ IdleRef idle_ref(const Static &S, const State &D, int c, int r) {
     IdleRef f;
-    if (S.layoutT) { f.p = nullptr; f.q = reinterpret_cast<unsigned *>(D.idle) + idleT_base(S, c, r); }
-    else { f.p = D.idle + ((size_t)c * S.R + r) * S.idle_cap; f.q = nullptr; }
+    const size_t off = ((size_t)c * S.R + r) * S.idle_cap;
+    if (S.dense) { f.p = nullptr; f.q = reinterpret_cast<unsigned *>(D.idle) + off; }
+    else { f.p = D.idle + off; f.q = nullptr; }
     return f;
 }
+__device__ __forceinline__ uint2 *ring2(const State &D) { return reinterpret_cast<uint2 *>(D.ring); }
 
 __device__ __forceinline__ DayView day_view(const Static &S, int r) {
     if (S.n_days <= 1) return DayView{S.bkt_off, S.tick_off, S.now0, S.T, 0};

@@ -41,7 +41,7 @@ class BatchedDispatchEnv:
                  depth_limit: int = 0, neighbor_can_server: bool = False, tick_minutes: int = 10,
                  reject_threshold: int = PICKUP_REJECT_THRESHOLD, device: int = 0,
                  idle_cap: int = 0, ring_cap: int = 0, ring_ticks: int = 0, far_cap: int = 0,
-                 force_generic: bool = False, stream: Optional[int] = None, lanes_debug=None):
+                 force_generic: bool = False, stream: Optional[int] = None, dense_debug=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.VdsConfig()
@@ -50,8 +50,8 @@ class BatchedDispatchEnv:
         cfg.tick_minutes, cfg.neighbor_can_server = int(tick_minutes), int(bool(neighbor_can_server))
         cfg.pickup_reject_threshold = int(reject_threshold)
         cfg.idle_cap, cfg.ring_cap, cfg.ring_ticks, cfg.far_cap = int(idle_cap), int(ring_cap), int(ring_ticks), int(far_cap)
-        # 0 fastest kernels, 1 generic / serial forms, 2-4 older neighbour-search kernels, 5 row-mapped kernel instead of
-        # the lanes tick, 6 lanes tick at any replica count (include/vds.h)
+        # 0 fastest kernels, 1 generic / serial forms, 3 lower-bound-round neighbour search, 5 wide state layout + row-mapped
+        # kernel where 0 takes the dense layout (include/vds.h)
         cfg.force_generic = int(force_generic)
         rc = self._lib.vds_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -67,8 +67,8 @@ class BatchedDispatchEnv:
         self.node2cluster = node2cluster
         if stream is not None:
             self._chk(self._lib.vds_set_stream(self._h, C.c_void_p(stream)))
-        if lanes_debug is not None:       # test hook: (log2 lanes per bucket, loc slots, key slots, force slow path)
-            self._chk(self._lib.vds_debug_lanes(self._h, *[int(x) for x in lanes_debug]))
+        if dense_debug is not None:       # test hook: (lanes per replica, idle entries / arrivals the fast path takes, force slow path)
+            self._chk(self._lib.vds_debug_dense(self._h, *[int(x) for x in dense_debug]))
         self._chk(self._lib.vds_load_static(self._h, _p(cost), self.N, _p(node2cluster), self.C, _p(nbr_off), _p(nbr_idx), int(depth_limit)))
         self.O = 0
         self.T = 0
