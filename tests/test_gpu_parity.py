@@ -159,6 +159,12 @@ MODES = {
     "dense_tiny4": {"dense_debug": (4, 20, 1, 0)},
     "dense_slow": {"dense_debug": (16, 0, 0, 1)},
     "dense_far": {"dense_debug": (8, 0, 0, 0), "ring_ticks": 2},
+    # the same with the arrival ring instead of static arrival slots (what the dense tick does when arrivals can lie more than
+    # DENSE_PULL_WMAX slots behind their earliest slot): force_slow bit 1
+    "dense_ring": {"dense_debug": (16, 0, 0, 2)},
+    "dense_ring8_tiny": {"dense_debug": (8, 12, 3, 2)},
+    "dense_ring_slow": {"dense_debug": (16, 0, 0, 3)},
+    "dense_ring_far": {"dense_debug": (4, 0, 0, 2), "ring_ticks": 2},
     "rows": {"force_generic": 5},            # wide layout + the row-mapped kernel where the dense tick is the default
     "rows_far": {"force_generic": 5, "ring_ticks": 2},
 }
@@ -211,9 +217,12 @@ def _burst(g, n_orders):
     return g, P
 
 
-def test_tight_ring_cap_overflow_is_reported():
+@pytest.mark.parametrize("mode", ["dense_ring", "rows"])
+def test_tight_ring_cap_overflow_is_reported(mode):
+    """(With static arrival slots - the dense tick's default - order-carrying arrivals never touch the ring: nothing can overflow,
+    the same day simply runs, see test_burst_of_identical_orders.)"""
     g, P = _burst(load_golden("tiny_kmeans"), 100)
-    env = make_env(g, 2, ring_cap=16, idle_cap=128)
+    env = make_env(g, 2, ring_cap=16, idle_cap=128, **MODES[mode])
     env.reset(np.full((2, 120), P, dtype=np.int32))
     with pytest.raises(Exception, match="arrival ring overflow"):
         env.run(env.T)

@@ -15,7 +15,7 @@ from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth, workloads
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"fast": dict(), "generic": dict(force_generic=1), "rows": dict(force_generic=5), "gen2": dict(force_generic=3), "dense8": dict(dense_debug=(8, 0, 0, 0)), "dense4_tiny": dict(dense_debug=(4, 12, 2, 0))}
+MODES = {"fast": dict(), "generic": dict(force_generic=1), "rows": dict(force_generic=5), "gen2": dict(force_generic=3), "dense8": dict(dense_debug=(8, 0, 0, 0)), "dense4_tiny": dict(dense_debug=(4, 12, 2, 0)), "dense_ring": dict(dense_debug=(16, 0, 0, 2))}
 
 
 def synth_days(g, n_days, seed):

@@ -31,7 +31,7 @@ int dfs_walk_pool(const Static &);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, const int *, const int *, hipStream_t);
 void launch_dispatch_dense(const Static &, const State &, int, int, const int *, int, hipStream_t);
-void launch_pack_obs(const Static &, const State &, int, int *, hipStream_t);
+void launch_pack_obs(const Static &, const State &, int, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
 void launch_selftest_dpp(const int *, int *, int *, int *, int *, int, hipStream_t);
 void set_ablate_tick(int, hipStream_t);
@@ -75,6 +75,17 @@ struct vds_handle {
     int alloc_dense = -1;
     int seq_tick0 = 0;                       // dispatch_seq at the first dispatch call of the current slot (dense keys carry the sequence number inside the slot)
     int seq_tick = -1;                       // the slot seq_tick0 belongs to
+    // device-resident copies of S / D for the slow path of k_tick_dense (Static.self_dev / state_dev), and what they hold
+    Static *d_S = nullptr;
+    State *d_D = nullptr;
+    Static S_up{};
+    State D_up{};
+    bool have_up = false;
+    std::vector<int2> pull_drec;             // host copy of Static.d_rec
+    std::vector<int> pull_slot_q;            // slot (absolute d_rec position) -> q - q_base of its order
+    std::vector<int4> pull_desc;             // per day {d_first base, d_rec base, TA, 0} (static arrival slots of the dense tick)
+    int pull_Od_max = 0;
+    std::vector<int> cl_cmax;                // [C] largest cost inside the cluster's block
     int dbg_dense_lpr = 0, dbg_dense_tab = 0, dbg_dense_keys = 0, dbg_dense_slow = 0;      // vds_debug_dense (0: defaults)
     int cost_min = 0, cost_max = 0;
     int max_seq = 0;        // longest visit sequence of FindServerVehicleFunction over the clusters
@@ -246,6 +257,27 @@ static void drop_run_graph(vds_handle *h) {
 #define DENSE_LPR_DEFAULT 16
 #endif
 
+// Brings the device-resident copies of h->S / h->D up to date (on the handle's stream, ordered before the launches that follow).
+// Called before every launch / graph launch of the dense tick; a no-op while nothing has changed.
+static int dev_copy_sync(vds_handle *h) {
+    if (!h->S.dense) return VDS_OK;
+    if (!h->d_S) {
+        HIPCHK(h, hipMalloc((void **)&h->d_S, sizeof(Static)));
+        HIPCHK(h, hipMalloc((void **)&h->d_D, sizeof(State)));
+    }
+    h->S.self_dev = h->d_S; h->S.state_dev = h->d_D;
+    Static want = h->S;
+    want.r_lo = 0;
+    if (h->have_up && memcmp(&want, &h->S_up, sizeof(Static)) == 0 && memcmp(&h->D, &h->D_up, sizeof(State)) == 0) return VDS_OK;
+    // (pageable host memory: the runtime stages the bytes before the call returns)
+    HIPCHK(h, hipMemcpyAsync(h->d_S, &want, sizeof(Static), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_D, &h->D, sizeof(State), hipMemcpyHostToDevice, h->stream));
+    memcpy(&h->S_up, &want, sizeof(Static));
+    memcpy(&h->D_up, &h->D, sizeof(State));
+    h->have_up = true;
+    return VDS_OK;
+}
+
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" {
@@ -376,6 +408,8 @@ int vds_destroy(vds_handle *h) {
     for (void *p : h->idle_allocs) dev_free(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     drop_run_graph(h);
+    if (h->d_S) (void)hipFree(h->d_S);
+    if (h->d_D) (void)hipFree(h->d_D);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return VDS_OK;
@@ -623,6 +657,14 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
             }
         }
         h->dense_static_ok = d_ok;
+        // largest RoadCost inside each cluster = the longest PickupWaitTime an order of that cluster can get (:929-933)
+        h->cl_cmax.assign(C, 0);
+        for (int c = 0; c < C; ++c) {
+            const long long nc = cdesc[c].x;
+            int mx = 0;
+            for (long long e = 0; e < nc * nc; ++e) mx = std::max(mx, blk[(size_t)cdesc[c].y + e]);
+            h->cl_cmax[c] = mx;
+        }
     }
     h->max_seq = 0;
     for (int c = 0; c < C; ++c) h->max_seq = std::max(h->max_seq, dfs_off[c + 1] - dfs_off[c]);
@@ -937,12 +979,95 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         S.dense_lpr = (lpr == 4 || lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
         S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, 128) : 128;
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
-        S.dense_force_slow = h->dbg_dense_slow;
+        S.dense_force_slow = h->dbg_dense_slow & 1;
+        S.pull = (S.dense && !(h->dbg_dense_slow & 2) && env_int("VDS_DENSE_PULL", 1) != 0) ? 1 : 0;
     }
+    // ---- static arrival slots of the dense tick ("pull", vds_device.h): every processed order owns one u32 slot per replica in
+    //      D.arr, in the order (destination cluster, earliest arrival slot a0, id); the destination bucket reads the slots of the
+    //      orders that can arrive now instead of receiving atomically appended ring entries.
+    S.so_dq = nullptr; S.d_rec = nullptr; S.d_first = nullptr; S.replica_desc2 = nullptr; S.pull_W = 0; S.pull_hmax = 0;
+    int Od_max = 0;
+    if (S.pull) {
+        const int Hc = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
+        const int tk = S.tick_minutes;
+        auto slots_of = [&](long long rel) -> int { return rel <= 0 ? 1 : (int)((rel + tk - 1) / tk); };      // post_arrival's d
+        std::vector<int2> so_dq(so_rec.size(), make_int2(-1, 0));
+        std::vector<int2> d_rec;
+        std::vector<int> d_first;
+        std::vector<int4> ddesc2(ddesc.size(), make_int4(0, 0, 0, 0));
+        int W = 0, hmax = 0;
+        bool ok = true;
+        for (int dd = 0; dd < n_days && ok; ++dd) {
+            const DayDesc &de = ddesc[dd];
+            const int TA = de.T + Hc;                        // a0 < T + H for every pull order
+            if (TA >= 65535) { ok = false; break; }
+            struct PO { int dc, a0, id, q, dmin, tins; };
+            std::vector<PO> po;
+            po.reserve(de.Oq);
+            for (int t = 0; t < de.T; ++t)
+                for (int c = 0; c < C; ++c)
+                    for (int q = bkt_off[de.bkt_base + (size_t)t * C + c]; q < bkt_off[de.bkt_base + (size_t)t * C + c + 1]; ++q) {
+                        const int4 &rr = so_rec[q];
+                        const int dmin = slots_of(rr.w), dmax = slots_of((long long)rr.w + h->cl_cmax[c]);
+                        if (dmax >= Hc) continue;            // may outlive the ring horizon: stays on the ring / far path
+                        W = std::max(W, dmax - dmin);
+                        hmax = std::max(hmax, dmin);
+                        po.push_back(PO{rr.z & 0xFFFF, t + dmin, rr.x, q, dmin, t});
+                    }
+            std::sort(po.begin(), po.end(), [](const PO &a, const PO &b) { return a.dc != b.dc ? a.dc < b.dc : (a.a0 != b.a0 ? a.a0 < b.a0 : a.id < b.id); });
+            const int base = (int)d_rec.size();
+            ddesc2[dd] = make_int4((int)d_first.size(), base, TA, (int)po.size());
+            // d_first[a][c]: first position (absolute) of the day's orders to cluster c with a0 >= a, a = 0 .. TA
+            std::vector<int> first((size_t)(TA + 1) * C, 0);
+            {
+                size_t i = 0;
+                for (int c = 0; c < C; ++c) {
+                    for (int a = 0; a <= TA; ++a) {
+                        while (i < po.size() && po[i].dc == c && po[i].a0 < a) ++i;
+                        first[(size_t)a * C + c] = base + (int)i;
+                    }
+                    while (i < po.size() && po[i].dc == c) ++i;
+                }
+            }
+            for (size_t i = 0; i < po.size(); ++i) {
+                const PO &o = po[i];
+                const int4 &rr = so_rec[o.q];
+                d_rec.push_back(make_int2((int)dense_key(o.tins, 0, o.id), o.a0 | ((int)((unsigned)rr.y >> 16) << 16) | (o.dmin << 24)));
+                so_dq[o.q] = make_int2((int)i, o.dmin);
+            }
+            d_first.insert(d_first.end(), first.begin(), first.end());
+            Od_max = std::max(Od_max, (int)po.size());
+        }
+        if ((long long)d_first.size() >= (1ll << 31) || W > DENSE_PULL_WMAX) ok = false;
+        if (!ok) S.pull = 0;
+        else {
+            struct Sink2 { vds_handle *h; ~Sink2() { h->alloc_sink = nullptr; } } sink2{h};
+            h->alloc_sink = &h->order_allocs;
+            S.pull_W = W; S.pull_hmax = hmax;
+            int2 *d2; if ((rc = upload(h, &d2, so_dq))) return rc; S.so_dq = d2;
+            if ((rc = upload(h, &d2, d_rec))) return rc; S.d_rec = d2;
+            if ((rc = upload(h, &d, d_first))) return rc; S.d_first = d;
+            std::vector<int4> rd2(S.R);
+            for (int r = 0; r < S.R; ++r) rd2[r] = day_of_internal[r] < n_days ? ddesc2[day_of_internal[r]] : make_int4(0, 0, 0, 0);
+            int4 *d4r; if ((rc = upload(h, &d4r, rd2))) return rc; S.replica_desc2 = d4r;
+            h->pull_desc = ddesc2;
+            h->pull_drec = d_rec;
+            h->pull_slot_q.assign(d_rec.size(), 0);
+            for (size_t q = 0; q < so_dq.size(); ++q) {
+                if (so_dq[q].x < 0) continue;
+                // which day? q -> day by q_base ranges
+                int dd = (int)(std::upper_bound(ddesc.begin(), ddesc.begin() + n_days, (int)q, [](int v, const DayDesc &e) { return v < e.q_base; }) - ddesc.begin()) - 1;
+                h->pull_slot_q[(size_t)ddesc2[dd].y + so_dq[q].x] = (int)q - ddesc[dd].q_base;
+            }
+        }
+    }
+    h->pull_Od_max = Od_max;
     h->alloc_sink = nullptr;
     if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;
     h->alloc_sink = &h->order_allocs;            // results: [R][Oq]
     rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1));
+    h->D.arr = nullptr;
+    if (!rc && S.pull) rc = dev_alloc(h, &h->D.arr, (size_t)S.R * std::max(h->pull_Od_max, 1));       // [Od][R]
     h->alloc_sink = nullptr;
     if (rc) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
@@ -1126,7 +1251,11 @@ static int step_impl(vds_handle *h) {
             if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
             HIPCHK(h, hipEventRecord(a, h->stream));
         }
-        if (h->S.dense) { Emit e; e.st = h->stream; emit_tick_dense(e, h->S, h->D, h->t, 0, 0); }
+        if (h->S.dense) {
+            const int rcs = dev_copy_sync(h);
+            if (rcs) return rcs;
+            Emit e; e.st = h->stream; emit_tick_dense(e, h->S, h->D, h->t, 0, 0);
+        }
         else launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
         // the fast kernel only defers buckets whose cluster cost block does not fit LDS (wide layout)
@@ -1277,6 +1406,7 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
     if (h->use_graph < 0) { const char *v = getenv("VDS_RUN_GRAPH"); h->use_graph = (v && *v == '0') ? 0 : 1; }
     if (!h->use_graph || h->profiling || n_ticks < 8 || h->last_stepped == h->t || h->t + n_ticks > h->S.T) return run_eager(h, n_ticks);
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    { const int rcs = dev_copy_sync(h); if (rcs) return rcs; }
     const int G = run_group_count(h);
     if (!(h->run_exec && !h->run_stale && h->run_t0 == h->t && h->run_n == n_ticks && h->run_stream == h->stream && h->run_G == G)) {
         const int t0 = h->t, ls0 = h->last_stepped;
@@ -1434,7 +1564,7 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
 int vds_obs_device(vds_handle *h, void **dev_ptr) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_obs_device: call vds_reset first");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    launch_pack_obs(h->S, h->D, h->last_stepped < 0 ? 0 : h->last_stepped, h->d_obs, h->stream);
+    launch_pack_obs(h->S, h->D, h->last_stepped < 0 ? 0 : h->last_stepped, h->last_stepped >= 0 ? 1 : 0, h->d_obs, h->stream);
     HIPCHK(h, hipGetLastError());
     if (dev_ptr) *dev_ptr = h->d_obs;
     return VDS_OK;
@@ -1658,11 +1788,43 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
                 }
         } else
         HIPCHK(h, hipMemcpy2D(ring.data(), S.ring_cap * sizeof(int4), h->D.ring + (size_t)replica * S.ring_cap, (size_t)R * S.ring_cap * sizeof(int4), S.ring_cap * sizeof(int4), (size_t)H * C, hipMemcpyDeviceToHost));
+        // static arrival slots (dense tick, S.pull): the order-carrying vehicles on their way sit in D.arr[slot][R]
+        std::vector<std::vector<int4>> pulled(S.pull ? C : 0);
+        if (S.pull && last >= 0) {
+            const int dday = h->replica_day[replica_ext];
+            DayHost &DH = h->days[dday];
+            const int4 d2 = h->pull_desc[dday];
+            const size_t nslot = (size_t)d2.w;
+            std::vector<unsigned> col(std::max<size_t>(nslot, 1));
+            if (nslot) HIPCHK(h, hipMemcpy2D(col.data(), sizeof(unsigned), h->D.arr + replica, (size_t)R * sizeof(unsigned), sizeof(unsigned), nslot, hipMemcpyDeviceToHost));
+            std::vector<int2> res((size_t)std::max(DH.Oq, 1));
+            if (DH.Oq > 0) HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)replica * S.Oq, (size_t)DH.Oq * sizeof(int2), hipMemcpyDeviceToHost));
+            // destination cluster of a slot: the slots are sorted by it; walk d_first of slot row 0
+            std::vector<int> dfirst0((size_t)C + 1);
+            {
+                std::vector<int> row0((size_t)C);
+                HIPCHK(h, hipMemcpy(row0.data(), S.d_first + d2.x, (size_t)C * sizeof(int), hipMemcpyDeviceToHost));
+                for (int c = 0; c < C; ++c) dfirst0[c] = row0[c] - d2.y;
+                dfirst0[C] = (int)nslot;
+            }
+            for (int c = 0; c < C; ++c)
+                for (int i = dfirst0[c]; i < dfirst0[c + 1]; ++i) {
+                    const int2 rec = h->pull_drec[(size_t)d2.y + i];
+                    const int a0 = rec.y & 0xFFFF, dmin = (int)((unsigned)rec.y >> 24), tins = a0 - dmin;
+                    if (tins > last) continue;                       // not processed yet
+                    const unsigned e = col[i];
+                    if (e == 0xFFFFFFFFu || a0 + (int)(e & 0xFFu) <= last) continue;      // rejected / arrived
+                    const int q = h->pull_slot_q[(size_t)d2.y + i];
+                    const int arrive = DH.now0 + tins * S.tick_minutes + res[q].y + DH.q_value[q];      // :954-960
+                    pulled[c].push_back(make_int4((int)(e >> 8), dense_key_id((unsigned)rec.x), arrive, meta_pack(tins, 0, (rec.y >> 16) & 0xFF)));
+                }
+        }
         int n = 0;
         arr_off[0] = 0;
         std::vector<int4> ent;
         for (int c = 0; c < C; ++c) {
             ent.clear();
+            if (S.pull) ent.insert(ent.end(), pulled[c].begin(), pulled[c].end());
             const int f = hdr[(size_t)c * HDR_WORDS + HDR_FL];
             const int q = last < 0 ? 0 : hdr[(size_t)c * HDR_WORDS + HDR_INBOX0 + np];
             for (int j = 0; j < f; ++j) ent.push_back(fl[(size_t)c * S.fl_cap + j]);

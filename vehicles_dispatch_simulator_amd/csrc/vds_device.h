@@ -70,6 +70,7 @@ struct DayDesc {
 };
 struct DayView { const int *bkt_off; const int *tick_off; int now0, T, q_base; };
 
+struct State;
 struct Static {
     int N, C, V, R, Oq, T;           // R: replicas the tables hold; Oq: result slots per replica (max over days); T: longest day
     int R_ext;                       // replicas the caller sees (vds_config.replicas); R >= R_ext when the replicas are stored regrouped
@@ -127,6 +128,14 @@ struct Static {
     int dense_lpr;                   // lanes per replica of k_tick_dense: 16 / 8 / 4 (4 / 8 / 16 replicas per wavefront)
     int dense_tab, dense_keys;       // idle entries / arrivals per bucket its fast path takes (<= 128 / 64; smaller: tests)
     int dense_force_slow;            // testing: every bucket takes dense_bucket_slow
+    const Static *self_dev;          // device-resident copy of this struct and of the State next to it (vds_api.hip keeps them current):
+    const struct State *state_dev;   // what the rarely taken slow path of k_tick_dense reads instead of by-value kernel arguments
+    // static arrival slots ("pull", see below): 1 = order-carrying arrivals go through D.arr instead of the ring
+    int pull, pull_W, pull_hmax;     // W: most slots an arrival can lie behind its earliest slot a0; hmax: longest trip in slots (dmin)
+    const int2 *so_dq;               // [Oq] per sorted order {slot index in its day's D.arr rows (-1: ring / far path), dmin}
+    const int2 *d_rec;               // per slot, sorted by (destination cluster, a0, id): {dense_key(insert tick, 0, id), a0 | dest_local << 16 | dmin << 24}
+    const int *d_first;              // per day [(TA + 1) x C]: first slot (absolute d_rec position) of cluster c with a0 >= a
+    const int4 *replica_desc2;       // [R] {d_first base, d_rec base, TA, slots} of the replica's day
     int ring_min_on;                 // (dense) State.ring_min exists: arrival minutes of dispatched vehicles, for the container views
     const int *blk32s;               // (dense, costs beyond a byte) per-cluster int cost blocks with row stride n_c + 1, column n_c = DENSE_DEAD_COST
     const unsigned char *blk8s;      // (dense, byte costs <= 254) the same as bytes, column n_c = 0xFF: the loc byte of a taken / absent
@@ -156,6 +165,7 @@ struct State {
     int2 *out;
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
+    unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] {veh << 8 | arrival slot - a0}, 0xFFFFFFFF rejected
     int *ring_min;       // dense layout: [H][C][R][ring_cap] arrival minute of a DISPATCHED vehicle's entry (order-carrying entries: recomputed
                          // from the order's result on the read side); written by the dispatch kernels only, never read by a tick
 };
@@ -169,6 +179,15 @@ struct State {
 //          key - ((t - 32) << 26) (mod 2^32) orders them (dense_key_rel).
 //   ring_min int [H][C][R][ring_cap]  arrival minute, DISPATCH entries only
 // hdr / cnt / ring_cnt / fl / inbox / out keep their layouts (far entries stay int4 {veh, id, arrive, meta}).
+// Static arrival slots ("pull").  An order's arrival slot is its (static) processing slot + d, d = ceil((PickupWaitTime + OrderValue) /
+// slot length) (:954-960): only the wait - at most the largest cost inside the pickup cluster - is dynamic, so the arrival lies in
+// [a0, a0 + W] with a0 = processing slot + d(wait 0) static.  Every processed order owns ONE u32 per replica in D.arr[slot][R],
+// slots sorted by (destination cluster, a0, id): the matching bucket stores {veh << 8 | arrival slot - a0} (0xFFFFFFFF: rejected)
+// with a plain store - no atomic, no position to wait for, 16 consecutive replicas = one 64-byte line - and the destination
+// bucket of slot t reads the entries of its orders with a0 in [t - W, t] (a contiguous range, known from static tables) and
+// takes those whose arrival slot is t.  Dict insertion order = the orders' (insert tick, id) keys (static, d_rec).  Dispatched
+// vehicles (hooks) and orders whose trip may outlive the ring horizon keep the ring / far path.  Used when W <= DENSE_PULL_WMAX.
+#define DENSE_PULL_WMAX 3
 #define DENSE_DEAD_COST 0x00FFFFFF      // cost of the dead column of an int block: (cost << 7 | pos) stays a positive int
 #define DENSE_ID_BITS 25
 __host__ __device__ inline unsigned dense_pack(unsigned veh, unsigned loc) { return (veh << 8) | (loc & 0xFFu); }

@@ -1001,7 +1001,8 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
 // ---------------------------------------------------------------------------------------
 // Read-side helpers.
 // obs [5][R][C]: idle_pre, idle_now, supply, cl_orders, inflight.  `t` = tick last stepped.
-__global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int *obs) {
+// stepped: a slot has been stepped since the reset (t = the last one); otherwise t = 0 and nothing has been processed yet
+__global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int stepped, int *obs) {
     // state is cluster-major ([C][R]), the observation block replica-major ([5][R][C]): 16 x 16 tiles through LDS so
     // that both the reads (16 consecutive replicas) and the writes (16 consecutive clusters) are 64-byte runs
     __shared__ int tile[5][16][17];
@@ -1017,10 +1018,29 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
             const int tr = S.n_days <= 1 ? t : min(t, day_view(S, r).T - 1);      // a replica whose day is over stopped at its own last tick
             int infl = h[HDR_FL] + h[HDR_INBOX0 + ((tr + 1) & 1)];
             for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
+            // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
+            int supply = (int)((unsigned)D.ring_cnt[(size_t)((tr + 1) & (S.H - 1)) * RC + b] >> 16);
+            if (S.pull && stepped) {
+                // static arrival slots (vds_device.h): the orders to this cluster that are on their way sit in D.arr, not in the ring -
+                // processed (insert tick <= tr), matched, arrival slot a0 + delta behind tr; due by the next slot: a0 + delta == tr + 1
+                const int4 d2 = S.n_days <= 1 ? make_int4(0, 0, 0x7FFFFFFF, 0) : S.replica_desc2[r];
+                const int *df = S.d_first + d2.x;
+                const int TA = S.n_days <= 1 ? S.T + S.H : d2.z;
+                const int lo = df[(size_t)max(tr - S.pull_W + 1, 0) * S.C + c], hi = df[(size_t)min(tr + S.pull_hmax + 1, TA) * S.C + c];
+                for (int i = lo; i < hi; ++i) {
+                    const int2 rec = S.d_rec[i];
+                    const int a0 = rec.y & 0xFFFF, tins = a0 - (int)((unsigned)rec.y >> 24);
+                    if (tins > tr) continue;                     // not processed yet: the entry is not of this episode
+                    const unsigned e = D.arr[(size_t)(i - d2.y) * S.R + r];
+                    if (e == 0xFFFFFFFFu) continue;              // rejected
+                    const int at = a0 + (int)(e & 0xFFu);
+                    infl += at > tr ? 1 : 0;
+                    supply += at == tr + 1 ? 1 : 0;
+                }
+            }
             tile[0][ty][tx] = h[HDR_IDLE_PRE];
             tile[1][ty][tx] = h[HDR_IDLE];
-            // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
-            tile[2][ty][tx] = (int)((unsigned)D.ring_cnt[(size_t)((tr + 1) & (S.H - 1)) * RC + b] >> 16);
+            tile[2][ty][tx] = supply;
             tile[3][ty][tx] = h[HDR_ORDERS];
             tile[4][ty][tx] = infl;
         }
@@ -1268,8 +1288,8 @@ void launch_dispatch_dense(const Static &S, const State &D, int t, int K, const 
     hipLaunchKernelGGL(k_dispatch_dense, dim3(S.R), dim3(64), 0, st, S, D, t, K, actions, seq_base);
 }
 
-void launch_pack_obs(const Static &S, const State &D, int t, int *obs, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_obs, dim3((S.R + 15) / 16, (S.C + 15) / 16), dim3(256), 0, st, S, D, t, obs);
+void launch_pack_obs(const Static &S, const State &D, int t, int stepped, int *obs, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_obs, dim3((S.R + 15) / 16, (S.C + 15) / 16), dim3(256), 0, st, S, D, t, stepped, obs);
 }
 
 void launch_reduce_counters(const Static &S, const State &D, long long *per, long long *tot, hipStream_t st) {

@@ -33,6 +33,29 @@ VDS_PROF_ACCESSORS(dense)
 #define DN_KEYS 64           // arrivals per bucket per tick the fast path ranks
 #define DN_ORDERS 64         // orders per (cluster, tick) bucket the fast path matches
 
+// Kernel arguments of the fast path: only what it reads (the whole Static / State pair as by-value arguments costs ~100 SGPR
+// spills, each reload a VALU instruction).  The slow path - rare - reads the device-resident copies behind Sdev / Ddev.
+struct DenseArgs {
+    // state tables
+    int *hdr; long long *cnt; unsigned *idle; uint2 *ring; int *ring_cnt; int4 *inbox; int2 *out; int *err;
+    // static / per-day tables
+    const int4 *cdesc_dense; const char *blk; const int4 *so_rec; const int *bkt_off; const int4 *replica_desc; const int *rperm;
+    int R, C, H, idle_cap, ring_cap, in_cap, Oq;
+    int tick_minutes, now0, tick_div_limit; unsigned tick_magic;
+    int r_lo, dense_tab, dense_keys, dense_force_slow;
+    int *ring_min;                   // (instrumented build: shadow target of the doubled posts)
+    // static arrival slots ("pull", vds_device.h)
+    unsigned *arr; const int2 *so_dq; const int2 *d_rec; const int *d_first; const int4 *replica_desc2; int pull_W;
+    const Static *Sdev; const State *Ddev;
+};
+__device__ __forceinline__ uint2 *ring2(const DenseArgs &D) { return D.ring; }
+// ceil(rel / tick_minutes) for 0 < rel < 2^25 (the fast path: costs < 2^23)
+__device__ __forceinline__ int ticks_until_fast(const DenseArgs &S, int rel) {
+    const int n = rel + S.tick_minutes - 1;
+    if (S.tick_div_limit > (1 << 26)) return (int)__umulhi((unsigned)n, S.tick_magic);
+    return n / S.tick_minutes;
+}
+
 // ---- reductions over aligned groups of LPR lanes (every lane of a group receives the result)
 template <int LPR>
 __device__ __forceinline__ int grp_min(int v) {
@@ -117,42 +140,63 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
     if (A > S.ring_cap) A = S.ring_cap;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
     const int P = f + qin;
-    // ---- arrivals of this slot: ring entries + due far entries, ranked by the full key
+    // static arrival slots (S.pull): the bucket's candidates = d_rec[clo .. clo + n), their entries D.arr[clo - qdb + i][r]
+    int clo = 0, n = 0, qdb = 0;
+    if (S.pull) {
+        const int4 d2 = S.n_days <= 1 ? make_int4(0, 0, 0, 0) : S.replica_desc2[r];
+        const int *df = S.d_first + d2.x;
+        clo = df[(size_t)max(t - S.pull_W, 0) * S.C + c];
+        n = df[(size_t)(t + 1) * S.C + c] - clo;
+        qdb = d2.y;
+    }
+    // ---- arrivals of this slot: candidates that say "slot t" + ring entries + due far entries, ranked by the full key
     // key of arrival x: ((insert_tick << 1 | is_dispatch) << 32) | id
-    int ndue = 0;
+    int ndue = 0, ncarr = 0;
     {
-        const int nring = (A + WAVE - 1) / WAVE, nfar = (P + WAVE - 1) / WAVE;
-        for (int I = 0; I < nring + nfar; ++I) {
-            // this chunk's candidates
-            unsigned long long key = ~0ull;
-            unsigned ent = 0;
-            bool valid = false;
-            if (I < nring) {
-                const int idx = I * WAVE + lane;
-                if (idx < A) {
-                    const uint2 e = ring[idx];
-                    key = ((unsigned long long)(((unsigned)dense_key_tick(e.y, t) << 1) | (unsigned)dense_key_is_dispatch(e.y)) << 32) | (unsigned)dense_key_id(e.y);
-                    ent = e.x; valid = true;
-                }
-            } else {
-                const int idx = (I - nring) * WAVE + lane;
-                if (idx < P) {
-                    const int4 e = pending_load(fl, inb, f, P, idx);
-                    if (e.z <= now) { key = entry_key(e.y, e.w); ent = dense_pack((unsigned)e.x, (unsigned)meta_dest(e.w)); valid = true; }
-                }
+        const int ncand = (n + WAVE - 1) / WAVE, nring = (A + WAVE - 1) / WAVE, nfar = (P + WAVE - 1) / WAVE;
+        auto fetch = [&](int I, unsigned long long &key, unsigned &ent) -> bool {
+            key = ~0ull; ent = 0u;
+            const int lane_ = lane_id();
+            if (I < ncand) {
+                const int idx = I * WAVE + lane_;
+                if (idx >= n) return false;
+                const unsigned raw = D.arr[(size_t)(clo - qdb + idx) * S.R + r];
+                const int2 rec = S.d_rec[clo + idx];
+                const int a0 = rec.y & 0xFFFF;
+                if ((int)(raw & 0xFFu) != t - a0) return false;
+                const unsigned tins = (unsigned)(a0 - (int)((unsigned)rec.y >> 24));
+                key = ((unsigned long long)(tins << 1) << 32) | (unsigned)dense_key_id((unsigned)rec.x);
+                ent = (raw & 0xFFFFFF00u) | (((unsigned)rec.y >> 16) & 0xFFu);
+                return true;
             }
-            // rank against every arrival
+            I -= ncand;
+            if (I < nring) {
+                const int idx = I * WAVE + lane_;
+                if (idx >= A) return false;
+                const uint2 e = ring[idx];
+                key = ((unsigned long long)(((unsigned)dense_key_tick(e.y, t) << 1) | (unsigned)dense_key_is_dispatch(e.y)) << 32) | (unsigned)dense_key_id(e.y);
+                ent = e.x;
+                return true;
+            }
+            I -= nring;
+            const int idx = I * WAVE + lane_;
+            if (idx >= P) return false;
+            const int4 e = pending_load(fl, inb, f, P, idx);
+            if (e.z > now) return false;
+            key = entry_key(e.y, e.w);
+            ent = dense_pack((unsigned)e.x, (unsigned)meta_dest(e.w));
+            return true;
+        };
+        const int nall = ncand + nring + nfar;
+        for (int I = 0; I < nall; ++I) {
+            unsigned long long key;
+            unsigned ent;
+            const bool valid = fetch(I, key, ent);
             int rank = 0;
-            for (int Jc = 0; Jc < nring + nfar; ++Jc) {
-                unsigned long long kj = ~0ull;
-                if (Jc == I) kj = key;
-                else if (Jc < nring) {
-                    const int jdx = Jc * WAVE + lane;
-                    if (jdx < A) { const uint2 e = ring[jdx]; kj = ((unsigned long long)(((unsigned)dense_key_tick(e.y, t) << 1) | (unsigned)dense_key_is_dispatch(e.y)) << 32) | (unsigned)dense_key_id(e.y); }
-                } else {
-                    const int jdx = (Jc - nring) * WAVE + lane;
-                    if (jdx < P) { const int4 e = pending_load(fl, inb, f, P, jdx); if (e.z <= now) kj = entry_key(e.y, e.w); }
-                }
+            for (int Jc = 0; Jc < nall; ++Jc) {
+                unsigned long long kj = key;
+                unsigned ej;
+                if (Jc != I) (void)fetch(Jc, kj, ej);
                 const int khi = (int)(kj >> 32), klo = (int)(kj & 0xFFFFFFFFull);
                 for (int j = 0; j < WAVE; ++j) {
                     const unsigned long long kk = ((unsigned long long)(unsigned)rdlane(khi, j) << 32) | (unsigned)rdlane(klo, j);
@@ -163,7 +207,9 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
                 const int pos = m + rank;
                 if (pos < S.idle_cap) idle[pos] = ent;
             }
-            if (I >= nring) ndue += popc64(ballot(valid));
+            const int nv = popc64(ballot(valid));
+            if (I < ncand) ncarr += nv;
+            else if (I >= ncand + nring) ndue += nv;
         }
     }
     wave_fence();
@@ -194,7 +240,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
         }
     }
     if (lane == 0 && rc0 != 0) D.ring_cnt[si] = 0;
-    int Atot = A + ndue;
+    int Atot = A + ndue + ncarr;
     if (m + Atot > S.idle_cap) {
         if (lane == 0) atomicOr(&D.err[0], ERR_IDLE_CAP);
         Atot = S.idle_cap - m;
@@ -239,7 +285,12 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
         }
         if (lane == 0) {
             out_r[q0 + j] = make_int2(res_veh, res_wait);
-            if (res_veh >= 0) post_arrival<false, true>(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
+            const int2 dq = S.pull ? S.so_dq[q0 + j] : make_int2(-1, 0);
+            if (dq.x >= 0) {            // static arrival slot: {veh << 8 | arrival slot - a0}, all ones when rejected
+                const int rel = res_wait + rec.w;
+                const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
+                D.arr[(size_t)dq.x * S.R + r] = res_veh >= 0 ? (((unsigned)res_veh << 8) | (unsigned)(d - dq.y)) : 0xFFFFFFFFu;
+            } else if (res_veh >= 0) post_arrival<false, true>(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
     }
     wave_fence();
@@ -333,6 +384,65 @@ __device__ __forceinline__ void merge_arrivals_any(const uint2 *ring, unsigned *
     else merge_arrivals<LPR, DN_KEYS / LPR, J>(ring, tab, lg, m, A, Amax, tbase, e);
 }
 
+// The same with static arrival slots (PULL): arrival slot a of a lane is candidate idx = a * LPR + lg of the bucket's n candidates
+// (raw D.arr entries parked in tab[0 .. n) by the prologue, their static records in lds_drec) or, behind them, entry idx - n of
+// the ring slot (dispatched vehicles).  A candidate arrives when its entry's low byte equals t - a0.
+template <int LPR, int NA, int J>
+__device__ __forceinline__ void merge_pull(const uint2 *ring, unsigned *tab, const int2 *lds_drec, int lg, int m, int n, int Aring, int Ntot, int t,
+                                           unsigned tbase, const unsigned *e) {
+    unsigned ent[NA], key[NA];
+    int rank[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int idx = a * LPR + lg;
+        ent[a] = 0u; key[a] = 0xFFFFFFFFu; rank[a] = 0;
+        if (idx < n) {
+            const unsigned raw = tab[idx];
+            const int2 rec = lds_drec[idx];
+            if ((int)(raw & 0xFFu) == t - (rec.y & 0xFFFF)) { key[a] = (unsigned)rec.x - tbase; ent[a] = (raw & 0xFFFFFF00u) | ((unsigned)(rec.y >> 16) & 0xFFu); }
+        } else if (idx - n < Aring) {
+            const uint2 r8 = ring[idx - n];
+            key[a] = r8.y - tbase; ent[a] = r8.x;
+        }
+    }
+    wave_order();          // every raw entry has been read: the table takes the keys
+#pragma unroll
+    for (int a = 0; a < NA; ++a) tab[a * LPR + lg] = key[a];
+    wave_order();
+    for (int i = 0; i < Ntot; ++i) {
+        const unsigned kk = tab[i];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) rank[a] += kk < key[a] ? 1 : 0;
+    }
+    wave_order();          // every key has been read: the table now takes the list
+    if (J > 0) {
+        const int lbase = lg * J;
+        if (lbase < m) {
+            if (J >= 4) {
+#pragma unroll
+                for (int s = 0; s < J; s += 4) *reinterpret_cast<uint4 *>(tab + lbase + s) = make_uint4(e[s], e[s + 1], e[s + 2], e[s + 3]);
+            } else {
+                *reinterpret_cast<uint2 *>(tab + lbase) = make_uint2(e[0], e[1]);
+            }
+        }
+        wave_order();
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+        if (key[a] != 0xFFFFFFFFu) tab[m + rank[a]] = ent[a];
+    wave_order();
+}
+template <int LPR, int J>
+__device__ __forceinline__ void merge_pull_any(const uint2 *ring, unsigned *tab, const int2 *lds_drec, int lg, int m, int n, int Aring, int Ntot, int t,
+                                               unsigned tbase, const unsigned *e) {
+    if (Ntot <= LPR) merge_pull<LPR, 1, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+    else if (Ntot <= 2 * LPR) merge_pull<LPR, 2, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+    else if (Ntot <= 4 * LPR) merge_pull<LPR, 4, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+    else if (Ntot <= 8 * LPR || LPR == 16) merge_pull<LPR, 8, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+    else if (Ntot <= 16 * LPR || LPR == 8) merge_pull<LPR, (LPR <= 8 ? 16 : 8), J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+    else merge_pull<LPR, (LPR == 4 ? 32 : 8), J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+}
+
 // counters of one bucket: lanes 0..7 of a 16- / 8-lane group hold the preloaded words (cntv), 4-lane groups add in place
 template <int LPR>
 __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long cntv, int k, int rej, int wsum, int vsum, int evals, int A) {
@@ -353,10 +463,22 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 
 // Fast path body, specialised on the group width LPR and the table size TS (J = TS / LPR slots per lane).
 //   tab     the row's LDS table (DN_TAB u32): arrival keys during the ranking, then the merged list, then the packed survivors
-template <int LPR, int TS, typename CT, int DM>
-__device__ __forceinline__ void dense_body(const Static &S, const State &D, int t, int now, int q0, int k, int qb, const CT *lds_blk, int nc,
+// Timing-only ablation switches of the instrumented build (make prof; vds_debug_ablate - results INVALID when non-zero):
+//   1 no arrival posts, 2 no idle write-back, 4 no match loop, 8 no result stores, 16 no header / counter stores, 32 posts: atomic
+//   only, 64 posts: entry store only, 256 nothing after the header loads, 512 empty kernel, 1024 no cost-block staging,
+//   2048 no list / arrival loads and no merge; state-preserving: 4096 every post twice (second into a shadow table), 8192 the
+//   atomic twice, 16384 the entry store twice, 32768 no counter stores
+#ifdef VDS_PROF
+#define DN_ABL (g_ablate)
+#else
+#define DN_ABL 0
+#endif
+
+// PULL: m / A as everywhere (A = all arrivals of the slot), Aring = those that sit in the ring slot, n = the bucket's candidates
+template <int LPR, int TS, typename CT, int DM, bool PULL>
+__device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &D, int t, int now, int q0, int k, int qb, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, unsigned *tab, int r, bool rowvalid, size_t b, size_t si,
-                                           int m, int A, long long cntv) {
+                                           int m, int A, long long cntv, int n, int Aring, const int2 *lds_drec, const int2 *lds_dq) {
     constexpr int J = TS / LPR;                 // slots per lane
     constexpr int NL = (J + 3) / 4;             // packed loc registers
     constexpr int NG = DN_ORDERS / LPR;         // result registers (orders jj * LPR + lg)
@@ -366,12 +488,13 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
     const int gbase = lane & ~(LPR - 1);
     const int lbase = lg * J;
     const int mnew = m + A;
-    unsigned *idle = reinterpret_cast<unsigned *>(D.idle) + b * S.idle_cap;
+    const int abl = DN_ABL;
+    unsigned *idle = D.idle + b * S.idle_cap;
     // 3. the idle list (one chunk of J entries per lane) and this slot's arrivals: all loads in flight together
     unsigned e[J];
 #pragma unroll
     for (int s = 0; s < J; ++s) e[s] = 0u;
-    if (k > 0 && lbase < m) {
+    if (k > 0 && lbase < m && !(abl & 2048)) {
         if (J >= 4) {
 #pragma unroll
             for (int s = 0; s < J; s += 4) {
@@ -383,16 +506,18 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
             e[0] = v.x; e[1] = v.y;
         }
     }
-    const int Amax = wave_max_of_groups<LPR>(A);
+    const int Amax = (abl & 2048) ? 0 : wave_max_of_groups<LPR>(PULL ? Aring : A);       // (ring entries)
+    const int Ntot = PULL ? n + Amax : Amax;                                          // arrival slots to rank (wave-uniform)
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
     if (k == 0) {
         // no order in this (tick, cluster) bucket: the list is not read - the ranked arrivals are appended behind it in HBM
-        if (Amax > 0) {
-            merge_arrivals_any<LPR, 0>(ring, tab, lg, 0, A, Amax, tbase, nullptr);
+        if (Ntot > 0) {
+            if (PULL) merge_pull_any<LPR, 0>(ring, tab, lds_drec, lg, 0, n, Aring, Ntot, t, tbase, nullptr);
+            else merge_arrivals_any<LPR, 0>(ring, tab, lg, 0, A, Amax, tbase, nullptr);
             if (rowvalid) {
                 for (int idx = lg; idx < A; idx += LPR) idle[m + idx] = tab[idx];
-                if (lg == 0 && A > 0) D.ring_cnt[si] = 0;
+                if (lg == 0 && (PULL ? Aring : A) > 0) D.ring_cnt[si] = 0;
             }
         }
         if (rowvalid) {
@@ -402,9 +527,10 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
         return;
     }
     // 4. arrivals ranked by dict insertion key; list + arrivals merged in the row's table, merged chunks read back
-    if (Amax > 0) {
-        merge_arrivals_any<LPR, J>(ring, tab, lg, m, A, Amax, tbase, e);
-        if (rowvalid && lg == 0 && A > 0) D.ring_cnt[si] = 0;
+    if (Ntot > 0) {
+        if (PULL) merge_pull_any<LPR, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+        else merge_arrivals_any<LPR, J>(ring, tab, lg, m, A, Amax, tbase, e);
+        if (rowvalid && lg == 0 && (PULL ? Aring : A) > 0) D.ring_cnt[si] = 0;
         if (J >= 4) {
 #pragma unroll
             for (int s = 0; s < J; s += 4) {
@@ -438,7 +564,7 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
     for (int jj = 0; jj < NG; ++jj) res[jj] = IMAX;
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
-        if (jj * LPR >= k) break;
+        if (jj * LPR >= k || (abl & 4)) break;
         const int kk = __builtin_amdgcn_readfirstlane(min(LPR, k - jj * LPR));
         // lanes lg == ji of every group
         unsigned long long jmask = LPR == 16 ? 0x0001000100010001ull : (LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull);
@@ -463,60 +589,7 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
             navail -= hit ? 1 : 0;
         }
     }
-    // 6. results (:947-965): vehicle ids through the LDS crossbar, arrival posts (ring-slot atomics issued here, their dependent
-    //    entry stores after the compaction traffic below)
-    int wsum = 0, vsum = 0, rej = 0;
-    int2 *out_r = D.out + (size_t)r * S.Oq + (q0 - qb);
-    int ppos[NG], pslot[NG];
-    unsigned pent[NG];
-#pragma unroll
-    for (int jj = 0; jj < NG; ++jj) {
-        ppos[jj] = -1;
-        if (jj * LPR >= k) continue;
-        const int j = jj * LPR + lg;
-        const bool has = rowvalid && j < k;
-        const int4 rr = lds_rec[j < k ? j : 0];
-        const int rv = res[jj];
-        const bool matched = has && (rv >> 7) != DEAD;
-        const int wait = rv >> 7;
-        const int wpos = rv & 127;
-        const int src = (gbase + (wpos / J)) << 2;       // winner's entry: e[wpos % J] of group lane wpos / J
-        unsigned went = 0;
-#pragma unroll
-        for (int s = 0; s < J; ++s) {
-            const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)e[s]);
-            went = (wpos % J) == s ? got : went;
-        }
-        const int vid = matched ? (int)(went >> 8) : -1;
-        if (has) out_r[j] = make_int2(vid, matched ? wait : -1);
-        if (matched) {
-            // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery), entered into the destination's arrival table
-            const int rel = wait + rr.w;
-            const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
-            const int dc = rr.z & 0xFFFF;
-            const unsigned ent = dense_pack((unsigned)vid, (unsigned)rr.y >> 16);
-            if (d < S.H) {
-                pslot[jj] = ((t + d) & (S.H - 1)) * S.C + dc;
-                const int old = atomicAdd(&D.ring_cnt[(size_t)pslot[jj] * S.R + r], 0x10001);          // high half: carries an order (:889)
-                ppos[jj] = old & 0xFFFF;
-                pent[jj] = ent;
-            } else {
-                // trip beyond the ring horizon: the destination's far inbox (full entry)
-                const size_t db = (size_t)dc * S.R + r;
-                const int np = (t + 1) & 1;
-                const int slot = atomicAdd(&D.hdr[db * HDR_WORDS + HDR_INBOX0 + np], 1);
-                if (slot < S.in_cap) D.inbox[((size_t)np * S.C * S.R + db) * S.in_cap + slot] = make_int4(vid, rr.x, now + rel, meta_pack(t, 0, (int)((unsigned)rr.y >> 16)));
-                else atomicOr(&D.err[0], ERR_INBOX_CAP);
-            }
-        }
-        wsum += matched ? wait : 0;
-        vsum += matched ? rr.w : 0;
-        rej += (has && !matched) ? 1 : 0;
-    }
-    wsum = grp_sum<LPR>(wsum);
-    vsum = grp_sum<LPR>(vsum);
-    rej = grp_sum<LPR>(rej);
-    // 7. order-preserving compaction of the survivors (:963) through the row's table, written back with whole-chunk stores from
+    // 6. order-preserving compaction of the survivors (:963) through the row's table, written back with whole-chunk stores from
     //    the first changed position on
     int alive = 0, firstdead = IMAX;
 #pragma unroll
@@ -538,7 +611,7 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
         }
     }
     wave_order();
-    if (rowvalid && lbase < mfin && lbase + J > fc) {
+    if (rowvalid && lbase < mfin && lbase + J > fc && !(abl & 2)) {
         if (J >= 4) {
 #pragma unroll
             for (int s = 0; s < J; s += 4) {
@@ -548,17 +621,75 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
             *reinterpret_cast<uint2 *>(idle + lbase) = *reinterpret_cast<const uint2 *>(tab + lbase);
         }
     }
-    // 8. header, counters
-    if (rowvalid) {
-        if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_IDLE ? mfin : (lg == HDR_IDLE_PRE ? mnew : k);
-        store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, k, rej, wsum, vsum, evals, A);
-    }
-    // 9. the arrival entries (their ring positions have come back by now)
+    // 7. results (:947-965): vehicle ids through the LDS crossbar, the arrival posts (ring-slot atomic, then the entry)
+    int wsum = 0, vsum = 0, rej = 0;
+    int2 *out_r = D.out + (size_t)r * S.Oq + (q0 - qb);
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
-        if (ppos[jj] < 0) continue;
-        if (ppos[jj] >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
-        else ring2(D)[((size_t)pslot[jj] * S.R + r) * S.ring_cap + ppos[jj]] = make_uint2(pent[jj], dense_key(t, 0, lds_rec[jj * LPR + lg].x));
+        if (jj * LPR >= k) break;
+        const int j = jj * LPR + lg;
+        const bool has = rowvalid && j < k;
+        const int4 rr = lds_rec[j < k ? j : 0];
+        const int rv = res[jj];
+        const bool matched = has && (rv >> 7) != DEAD;
+        const int wait = rv >> 7;
+        const int wpos = rv & 127;
+        const int src = (gbase + (wpos / J)) << 2;       // winner's entry: e[wpos % J] of group lane wpos / J
+        unsigned went = 0;
+#pragma unroll
+        for (int s = 0; s < J; ++s) {
+            const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)e[s]);
+            went = (wpos % J) == s ? got : went;
+        }
+        const int vid = matched ? (int)(went >> 8) : -1;
+        if (has && !(abl & 8)) out_r[j] = make_int2(vid, matched ? wait : -1);
+        int2 dq = make_int2(-1, 0);
+        if (PULL) dq = lds_dq[j < k ? j : 0];
+        if (PULL && dq.x >= 0) {
+            // :954-960 with a static arrival slot: a plain store of {veh << 8 | arrival slot - a0} (rejected: all ones) - every
+            // processed order writes its slot, so what a destination bucket reads is always of this episode
+            const int rel = wait + rr.w;
+            const int d = rel <= 0 ? 1 : ticks_until_fast(S, rel);
+            if (has && !(abl & 1)) D.arr[(size_t)dq.x * S.R + r] = matched ? (((unsigned)vid << 8) | (unsigned)(d - dq.y)) : 0xFFFFFFFFu;
+        } else if (matched && !(abl & 1)) {
+            // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery), entered into the destination's arrival table
+            const int rel = wait + rr.w;
+            const int d = rel <= 0 ? 1 : ticks_until_fast(S, rel);
+            const int dc = rr.z & 0xFFFF;
+            if (d < S.H) {
+                const size_t i = ((size_t)(((t + d) & (S.H - 1)) * S.C + dc)) * S.R + r;
+                int pos = (rr.x & 7);
+                if (!(abl & 64)) pos = atomicAdd(&D.ring_cnt[i], (abl & 32) ? 0 : 0x10001) & 0xFFFF;          // high half: carries an order (:889)
+                if (pos >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
+                else if (!(abl & 32)) ring2(D)[i * S.ring_cap + pos] = make_uint2(dense_pack((unsigned)vid, (unsigned)rr.y >> 16), dense_key(t, 0, rr.x));
+#ifdef VDS_PROF
+                if (abl & (4096 | 8192 | 16384)) {      // the same post once more into a shadow table (state untouched): what a post COSTS
+                    int *sh = D.ring_min + i * S.ring_cap;
+                    int p2 = pos & 3;
+                    if (abl & (4096 | 8192)) p2 = atomicAdd(&sh[0], 0x10001) & 3;
+                    if (abl & (4096 | 16384)) *reinterpret_cast<uint2 *>(sh + 2 + 2 * p2) = make_uint2((unsigned)vid, (unsigned)rr.x);
+                }
+#endif
+            } else {
+                // trip beyond the ring horizon: the destination's far inbox (full entry)
+                const size_t db = (size_t)dc * S.R + r;
+                const int np = (t + 1) & 1;
+                const int slot = atomicAdd(&D.hdr[db * HDR_WORDS + HDR_INBOX0 + np], 1);
+                if (slot < S.in_cap) D.inbox[((size_t)np * S.C * S.R + db) * S.in_cap + slot] = make_int4(vid, rr.x, now + rel, meta_pack(t, 0, (int)((unsigned)rr.y >> 16)));
+                else atomicOr(&D.err[0], ERR_INBOX_CAP);
+            }
+        }
+        wsum += matched ? wait : 0;
+        vsum += matched ? rr.w : 0;
+        rej += (has && !matched) ? 1 : 0;
+    }
+    wsum = grp_sum<LPR>(wsum);
+    vsum = grp_sum<LPR>(vsum);
+    rej = grp_sum<LPR>(rej);
+    // 8. header, counters
+    if (rowvalid && !(abl & 16)) {
+        if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_IDLE ? mfin : (lg == HDR_IDLE_PRE ? mnew : k);
+        if (!(abl & 32768)) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, k, rej, wsum, vsum, evals, A);
     }
 }
 
@@ -574,15 +705,22 @@ __device__ __forceinline__ void dense_body(const Static &S, const State &D, int 
 #define DN_MIN_WAVES4 4
 #endif
 
-template <bool U8, int DM, int LPR>
-__global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4)) void k_tick_dense(Static S, State D, int t, int blk_bytes) {
+#define DN_CAND 128          // static arrival slots (candidates) per bucket per tick the fast path takes (= DN_TAB: they are parked in the row's table)
+
+template <bool U8, int DM, int LPR, bool PULL>
+__global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4)) void k_tick_dense(DenseArgs P, int t) {
+    const DenseArgs &S = P, &D = P;
+    if (DN_ABL & 512) return;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     constexpr int RPW = WAVE / LPR;             // rows per wavefront
+    constexpr int NTHR = DN_ROWS * LPR;
     extern __shared__ int lds_dyn[];
-    if (DM == 0) S.n_days = 1;                  // the shared-day instantiation: folds the per-day lookups of the inlined slow path
-    // dynamic LDS: order records int4[64] | per-row tables [16][DN_TAB] u32 | cost block (row stride n_c + 1)
+    // dynamic LDS: order records int4[64] | their arrival-slot records int2[64] | candidate records int2[DN_CAND] (both PULL only)
+    //              | per-row tables [16][DN_TAB] u32 | cost block (row stride n_c + 1)
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
-    unsigned *tab_all = reinterpret_cast<unsigned *>(lds_rec + DN_ORDERS);
+    int2 *lds_dq = reinterpret_cast<int2 *>(lds_rec + DN_ORDERS);
+    int2 *lds_drec = lds_dq + (PULL ? DN_ORDERS : 0);
+    unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
     CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * DN_TAB);
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
@@ -597,15 +735,24 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     const int r = (DM == 1 && S.rperm != nullptr) ? S.rperm[rslot] : rslot;
     bool rowvalid = r >= 0 && r < S.R;
     int q0, k, now, qb = 0;
+    int clo = 0, n = 0, qdb = 0;                // PULL: the bucket's candidates = d_rec[clo .. clo + n), D.arr rows clo - qdb ...
     if (DM == 1) {
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
         const int r0 = chunk * DN_ROWS;         // (a group's first slot is never padding)
-        const int4 dd = S.replica_desc[S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1)];
+        const int rd = S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1);
+        const int4 dd = S.replica_desc[rd];
         rowvalid = rowvalid && t < dd.z;
         q0 = 0; k = 0;
         if (t < dd.z) {                          // (past the day's last slot its bucket table must not be read)
             const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
             q0 = bo[0]; k = bo[1] - q0;
+            if (PULL) {
+                const int4 d2 = S.replica_desc2[rd];        // {d_first base, d_rec base, TA, 0}
+                const int *df = S.d_first + d2.x;
+                clo = df[(size_t)max(t - S.pull_W, 0) * S.C + c];
+                n = df[(size_t)(t + 1) * S.C + c] - clo;
+                qdb = d2.y;
+            }
         }
         now = dd.y + t * S.tick_minutes;
         qb = dd.w;
@@ -613,10 +760,16 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
         q0 = S.bkt_off[(size_t)t * S.C + c];
         k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
         now = S.now0 + t * S.tick_minutes;
+        if (PULL) {
+            clo = S.d_first[(size_t)max(t - S.pull_W, 0) * S.C + c];
+            n = S.d_first[(size_t)(t + 1) * S.C + c] - clo;
+        }
     }
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
-    // 1. bucket header words
+    const bool wg_ok = k <= DN_ORDERS && n <= DN_CAND;
+    unsigned *tab = tab_all + (wave * RPW + g) * DN_TAB;
+    // 1. bucket header words; PULL: the raw entries of the bucket's candidates, parked in the row's table
     int m = 0, far = 0, A = 0;
     long long cntv = 0;
     if (rowvalid) {
@@ -627,36 +780,66 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
         A = D.ring_cnt[si] & 0xFFFF;
         if (LPR >= CNT_WORDS && lg < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + lg];
     }
-    const bool wg_ok = k <= DN_ORDERS;
-    const int mnew0 = m + A;
-    const bool bad = rowvalid && (!wg_ok || far != 0 || A > S.dense_keys || A > S.ring_cap || mnew0 > S.dense_tab || mnew0 > S.idle_cap || S.dense_force_slow);
-    const unsigned long long badrows = ballot(bad && lg == 0);
-    if (badrows != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(badrows));      // buckets that leave the fast path: vds_read_work
-    if (bad) { rowvalid = false; m = 0; A = 0; }
-    const bool any = ballot(rowvalid) != 0;
-    const int mmax = wave_max_of_groups<LPR>(m + A);
-    // 2. stage the cluster's cost block and the bucket's order records in LDS
-    const char *blk_g = reinterpret_cast<const char *>(U8 ? (const void *)S.blk8s : (const void *)S.blk32s) + cd.y;
+    if (PULL && wg_ok) {
+        const unsigned *ar = D.arr + (size_t)(clo - qdb) * S.R + (rowvalid ? r : 0);
+        for (int i0 = 0; i0 < n; i0 += 4 * LPR) {          // four loads in flight per lane
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * LPR + lg;
+                v[u] = 0xFFFFFFFFu;
+                if (idx < n && rowvalid) v[u] = ar[(size_t)idx * S.R];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * LPR + lg;
+                if (idx < n) tab[idx] = v[u];
+            }
+        }
+    }
+    if (DN_ABL & 256) { if (m + far + A + (int)cntv == 0x7FFFFFF1) D.err[1] = 1; return; }
+    // 2. stage the cluster's cost block, the bucket's order records and - PULL - the candidates' static records in LDS
+    const char *blk_g = S.blk + cd.y;
     if (k > 0) {
         const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
         const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
         int4 rec = make_int4(0, 0, 0, 0);
-        if ((int)threadIdx.x < min(k, DN_ORDERS)) rec = S.so_rec[q0 + threadIdx.x];
-        for (int i = threadIdx.x; i < n4; i += DN_ROWS * LPR) lds4[i] = blk4[i];
-        if ((int)threadIdx.x < min(k, DN_ORDERS)) lds_rec[threadIdx.x] = rec;
+        int2 dq = make_int2(-1, 0);
+        const bool mine = (int)threadIdx.x < min(k, DN_ORDERS);
+        if (mine) { rec = S.so_rec[q0 + threadIdx.x]; if (PULL) dq = S.so_dq[q0 + threadIdx.x]; }
+        if (!(DN_ABL & 1024)) for (int i = threadIdx.x; i < n4; i += NTHR) lds4[i] = blk4[i];
+        if (mine) { lds_rec[threadIdx.x] = rec; if (PULL) lds_dq[threadIdx.x] = dq; }
     }
+    if (PULL && wg_ok)
+        for (int i = threadIdx.x; i < n; i += NTHR) lds_drec[i] = S.d_rec[clo + i];
     __syncthreads();
+    // arrivals of the slot: PULL: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
+    int Aring = A;
+    if (PULL) {
+        int ap = 0;
+        if (wg_ok)
+            for (int idx = lg; idx < n; idx += LPR) ap += (int)(tab[idx] & 0xFFu) == t - (lds_drec[idx].y & 0xFFFF) ? 1 : 0;
+        A = Aring + grp_sum<LPR>(ap);
+    }
+    const int mnew0 = m + A;
+    const bool bad = rowvalid && (!wg_ok || far != 0 || Aring > S.dense_keys || Aring > S.ring_cap || A > DN_TAB || mnew0 > S.dense_tab || mnew0 > S.idle_cap || S.dense_force_slow ||
+                                  (PULL && (A - Aring > S.dense_keys * 2 || n + Aring > DN_TAB)));
+    const unsigned long long badrows = ballot(bad && lg == 0);
+    if (badrows != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(badrows));      // buckets that leave the fast path: vds_read_work
+    if (bad) { rowvalid = false; m = 0; A = 0; Aring = 0; }
+    const bool any = ballot(rowvalid) != 0;
+    const int mmax = wave_max_of_groups<LPR>(m + A);
     if (any) {
-        unsigned *tab = tab_all + (wave * RPW + g) * DN_TAB;
-        if (mmax <= 32) dense_body<LPR, 32, CT, DM>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv);
-        else if (mmax <= 64) dense_body<LPR, 64, CT, DM>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv);
-        else dense_body<LPR, 128, CT, DM>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv);
+        const int nn = wg_ok ? n : 0;
+        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_dq);
+        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_dq);
+        else dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_dq);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int l0 = __ffsll((long long)rest) - 1;
-        dense_bucket_slow<CT>(S, D, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc);
+        dense_bucket_slow<CT>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc);
     }
 }
 
@@ -664,33 +847,48 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
 // launcher: the dense tick for the replicas [r_lo, r_lo + r_n) (r_lo a multiple of 16; r_n = 0: all), on a stream or as a kernel
 // node of an explicitly built hipGraph (vds_run's day graph)
 
-static void emit_dense(const Emit &e, void (*k)(Static, State, int, int), dim3 grid, dim3 block, size_t lds, Static S, State D, int t, int bb) {
-    if (!e.graph) { hipLaunchKernelGGL(k, grid, block, lds, e.st, S, D, t, bb); return; }
-    void *args[4] = {&S, &D, &t, &bb};
+static void emit_dense(const Emit &e, void (*k)(DenseArgs, int), dim3 grid, dim3 block, size_t lds, DenseArgs P, int t) {
+    if (!e.graph) { hipLaunchKernelGGL(k, grid, block, lds, e.st, P, t); return; }
+    void *args[2] = {&P, &t};
     hipKernelNodeParams p{};
     p.func = reinterpret_cast<void *>(k); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds; p.kernelParams = args; p.extra = nullptr;
     *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
 }
 
-template <int LPR>
-static void emit_dense_lpr(const Emit &e, const Static &S, const State &D, int t, dim3 grid, size_t lds, int bb) {
+template <int LPR, bool PULL>
+static void emit_dense_lpr(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
     const int dm = S.n_days <= 1 ? 0 : 1;
     const dim3 block(DN_ROWS * LPR);
-    if (S.blk8s) emit_dense(e, dm ? k_tick_dense<true, 1, LPR> : k_tick_dense<true, 0, LPR>, grid, block, lds, S, D, t, bb);
-    else emit_dense(e, dm ? k_tick_dense<false, 1, LPR> : k_tick_dense<false, 0, LPR>, grid, block, lds, S, D, t, bb);
+    if (S.blk8s) emit_dense(e, dm ? k_tick_dense<true, 1, LPR, PULL> : k_tick_dense<true, 0, LPR, PULL>, grid, block, lds, P, t);
+    else emit_dense(e, dm ? k_tick_dense<false, 1, LPR, PULL> : k_tick_dense<false, 0, LPR, PULL>, grid, block, lds, P, t);
 }
 
-void emit_tick_dense(const Emit &e, const Static &S0, const State &D, int t, int r_lo, int r_n) {
-    Static S = S0;
-    S.r_lo = r_lo;
+// S.self_dev / S.state_dev: device-resident copies of S and D (kept current by vds_api.hip: dev_copy_sync) for the slow path
+void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int r_lo, int r_n) {
+    DenseArgs P;
+    P.hdr = D.hdr; P.cnt = D.cnt; P.idle = reinterpret_cast<unsigned *>(D.idle); P.ring = reinterpret_cast<uint2 *>(D.ring);
+    P.ring_cnt = D.ring_cnt; P.inbox = D.inbox; P.out = D.out; P.err = D.err;
+    P.cdesc_dense = S.cdesc_dense; P.blk = S.blk8s ? reinterpret_cast<const char *>(S.blk8s) : reinterpret_cast<const char *>(S.blk32s);
+    P.so_rec = S.so_rec; P.bkt_off = S.bkt_off; P.replica_desc = S.replica_desc; P.rperm = S.rperm;
+    P.R = S.R; P.C = S.C; P.H = S.H; P.idle_cap = S.idle_cap; P.ring_cap = S.ring_cap; P.in_cap = S.in_cap; P.Oq = S.Oq;
+    P.tick_minutes = S.tick_minutes; P.now0 = S.now0; P.tick_div_limit = S.tick_div_limit; P.tick_magic = S.tick_magic;
+    P.r_lo = r_lo; P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
+    P.Sdev = S.self_dev; P.Ddev = S.state_dev; P.ring_min = D.ring_min;
+    P.arr = D.arr; P.so_dq = S.so_dq; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
     const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R);
     const int rchunks = (slots + DN_ROWS - 1) / DN_ROWS;
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
-    const size_t lds = DN_ORDERS * 16 + DN_ROWS * DN_TAB * 4 + bb;
-    if (S.dense_lpr == 8) emit_dense_lpr<8>(e, S, D, t, grid, lds, bb);
-    else if (S.dense_lpr == 4) emit_dense_lpr<4>(e, S, D, t, grid, lds, bb);
-    else emit_dense_lpr<16>(e, S, D, t, grid, lds, bb);
+    const size_t lds = DN_ORDERS * 16 + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * DN_TAB * 4 + bb;
+    if (S.pull) {
+        if (S.dense_lpr == 8) emit_dense_lpr<8, true>(e, S, P, t, grid, lds);
+        else if (S.dense_lpr == 4) emit_dense_lpr<4, true>(e, S, P, t, grid, lds);
+        else emit_dense_lpr<16, true>(e, S, P, t, grid, lds);
+    } else {
+        if (S.dense_lpr == 8) emit_dense_lpr<8, false>(e, S, P, t, grid, lds);
+        else if (S.dense_lpr == 4) emit_dense_lpr<4, false>(e, S, P, t, grid, lds);
+        else emit_dense_lpr<16, false>(e, S, P, t, grid, lds);
+    }
 }
 
 }  // namespace vds
