@@ -972,6 +972,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     // ---- dense layout (k_tick_dense: 4-byte idle entries, 8-byte arrival entries): the plain tick with one order day per workgroup
     //      chunk (day modes 0 / 1), ids that fit the packed keys.  vds_config.force_generic 5 keeps the wide layout and k_tick_rows.
     S.dense = (h->dense_static_ok && (n_days == 1 || S.chunk_days) && Omax < (1 << DENSE_ID_BITS)) ? 1 : 0;
+    // (static arrival slots: the all-ones vehicle field marks a rejected order)
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
         if (env_int("VDS_DENSE", 1) == 0) S.dense = 0;
@@ -980,18 +981,18 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, 128) : 128;
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
         S.dense_force_slow = h->dbg_dense_slow & 1;
-        S.pull = (S.dense && !(h->dbg_dense_slow & 2) && env_int("VDS_DENSE_PULL", 1) != 0) ? 1 : 0;
+        S.pull = (S.dense && S.V < (1 << 24) - 1 && !(h->dbg_dense_slow & 2) && env_int("VDS_DENSE_PULL", 1) != 0) ? 1 : 0;
     }
     // ---- static arrival slots of the dense tick ("pull", vds_device.h): every processed order owns one u32 slot per replica in
     //      D.arr, in the order (destination cluster, earliest arrival slot a0, id); the destination bucket reads the slots of the
     //      orders that can arrive now instead of receiving atomically appended ring entries.
-    S.so_dq = nullptr; S.d_rec = nullptr; S.d_first = nullptr; S.replica_desc2 = nullptr; S.pull_W = 0; S.pull_hmax = 0;
+    S.so_slot = nullptr; S.d_rec = nullptr; S.d_first = nullptr; S.replica_desc2 = nullptr; S.pull_W = 0; S.pull_hmax = 0;
     int Od_max = 0;
     if (S.pull) {
         const int Hc = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
         const int tk = S.tick_minutes;
         auto slots_of = [&](long long rel) -> int { return rel <= 0 ? 1 : (int)((rel + tk - 1) / tk); };      // post_arrival's d
-        std::vector<int2> so_dq(so_rec.size(), make_int2(-1, 0));
+        std::vector<int> so_slot(so_rec.size(), -1);
         std::vector<int2> d_rec;
         std::vector<int> d_first;
         std::vector<int4> ddesc2(ddesc.size(), make_int4(0, 0, 0, 0));
@@ -1033,7 +1034,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                 const PO &o = po[i];
                 const int4 &rr = so_rec[o.q];
                 d_rec.push_back(make_int2((int)dense_key(o.tins, 0, o.id), o.a0 | ((int)((unsigned)rr.y >> 16) << 16) | (o.dmin << 24)));
-                so_dq[o.q] = make_int2((int)i, o.dmin);
+                so_slot[o.q] = (int)i;
             }
             d_first.insert(d_first.end(), first.begin(), first.end());
             Od_max = std::max(Od_max, (int)po.size());
@@ -1044,8 +1045,8 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
             struct Sink2 { vds_handle *h; ~Sink2() { h->alloc_sink = nullptr; } } sink2{h};
             h->alloc_sink = &h->order_allocs;
             S.pull_W = W; S.pull_hmax = hmax;
-            int2 *d2; if ((rc = upload(h, &d2, so_dq))) return rc; S.so_dq = d2;
-            if ((rc = upload(h, &d2, d_rec))) return rc; S.d_rec = d2;
+            if ((rc = upload(h, &d, so_slot))) return rc; S.so_slot = d;
+            int2 *d2; if ((rc = upload(h, &d2, d_rec))) return rc; S.d_rec = d2;
             if ((rc = upload(h, &d, d_first))) return rc; S.d_first = d;
             std::vector<int4> rd2(S.R);
             for (int r = 0; r < S.R; ++r) rd2[r] = day_of_internal[r] < n_days ? ddesc2[day_of_internal[r]] : make_int4(0, 0, 0, 0);
@@ -1053,11 +1054,11 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
             h->pull_desc = ddesc2;
             h->pull_drec = d_rec;
             h->pull_slot_q.assign(d_rec.size(), 0);
-            for (size_t q = 0; q < so_dq.size(); ++q) {
-                if (so_dq[q].x < 0) continue;
+            for (size_t q = 0; q < so_slot.size(); ++q) {
+                if (so_slot[q] < 0) continue;
                 // which day? q -> day by q_base ranges
                 int dd = (int)(std::upper_bound(ddesc.begin(), ddesc.begin() + n_days, (int)q, [](int v, const DayDesc &e) { return v < e.q_base; }) - ddesc.begin()) - 1;
-                h->pull_slot_q[(size_t)ddesc2[dd].y + so_dq[q].x] = (int)q - ddesc[dd].q_base;
+                h->pull_slot_q[(size_t)ddesc2[dd].y + so_slot[q]] = (int)q - ddesc[dd].q_base;
             }
         }
     }
@@ -1811,9 +1812,9 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
                 for (int i = dfirst0[c]; i < dfirst0[c + 1]; ++i) {
                     const int2 rec = h->pull_drec[(size_t)d2.y + i];
                     const int a0 = rec.y & 0xFFFF, dmin = (int)((unsigned)rec.y >> 24), tins = a0 - dmin;
-                    if (tins > last) continue;                       // not processed yet
+                    if (tins > last || a0 + S.pull_W <= last) continue;      // not processed yet / arrived for sure (the entry's slot byte is only meaningful within 127 slots)
                     const unsigned e = col[i];
-                    if (e == 0xFFFFFFFFu || a0 + (int)(e & 0xFFu) <= last) continue;      // rejected / arrived
+                    if (pull_is_reject(e) || pull_slots_ahead(e, last) <= 0) continue;      // rejected / arrived
                     const int q = h->pull_slot_q[(size_t)d2.y + i];
                     const int arrive = DH.now0 + tins * S.tick_minutes + res[q].y + DH.q_value[q];      // :954-960
                     pulled[c].push_back(make_int4((int)(e >> 8), dense_key_id((unsigned)rec.x), arrive, meta_pack(tins, 0, (rec.y >> 16) & 0xFF)));

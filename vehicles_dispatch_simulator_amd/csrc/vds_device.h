@@ -132,7 +132,7 @@ struct Static {
     const struct State *state_dev;   // what the rarely taken slow path of k_tick_dense reads instead of by-value kernel arguments
     // static arrival slots ("pull", see below): 1 = order-carrying arrivals go through D.arr instead of the ring
     int pull, pull_W, pull_hmax;     // W: most slots an arrival can lie behind its earliest slot a0; hmax: longest trip in slots (dmin)
-    const int2 *so_dq;               // [Oq] per sorted order {slot index in its day's D.arr rows (-1: ring / far path), dmin}
+    const int *so_slot;              // [Oq] per sorted order: slot index in its day's D.arr rows (-1: ring / far path)
     const int2 *d_rec;               // per slot, sorted by (destination cluster, a0, id): {dense_key(insert tick, 0, id), a0 | dest_local << 16 | dmin << 24}
     const int *d_first;              // per day [(TA + 1) x C]: first slot (absolute d_rec position) of cluster c with a0 >= a
     const int4 *replica_desc2;       // [R] {d_first base, d_rec base, TA, slots} of the replica's day
@@ -165,7 +165,7 @@ struct State {
     int2 *out;
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
-    unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] {veh << 8 | arrival slot - a0}, 0xFFFFFFFF rejected
+    unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] pull_entry / pull_reject
     int *ring_min;       // dense layout: [H][C][R][ring_cap] arrival minute of a DISPATCHED vehicle's entry (order-carrying entries: recomputed
                          // from the order's result on the read side); written by the dispatch kernels only, never read by a tick
 };
@@ -182,12 +182,18 @@ struct State {
 // Static arrival slots ("pull").  An order's arrival slot is its (static) processing slot + d, d = ceil((PickupWaitTime + OrderValue) /
 // slot length) (:954-960): only the wait - at most the largest cost inside the pickup cluster - is dynamic, so the arrival lies in
 // [a0, a0 + W] with a0 = processing slot + d(wait 0) static.  Every processed order owns ONE u32 per replica in D.arr[slot][R],
-// slots sorted by (destination cluster, a0, id): the matching bucket stores {veh << 8 | arrival slot - a0} (0xFFFFFFFF: rejected)
-// with a plain store - no atomic, no position to wait for, 16 consecutive replicas = one 64-byte line - and the destination
-// bucket of slot t reads the entries of its orders with a0 in [t - W, t] (a contiguous range, known from static tables) and
-// takes those whose arrival slot is t.  Dict insertion order = the orders' (insert tick, id) keys (static, d_rec).  Dispatched
+// slots sorted by (destination cluster, a0, id): the matching bucket stores pull_entry(veh, arrival slot) (pull_reject: no
+// vehicle) with a plain store - no atomic, no position to wait for, 16 consecutive replicas = one 64-byte line - and the
+// destination bucket of slot t reads the entries of its orders with a0 in [t - W, t] (a contiguous range, known from static
+// tables) and takes those whose arrival-slot byte is t's (every candidate was processed less than 128 slots ago).  Dict insertion order = the orders' (insert tick, id) keys (static, d_rec).  Dispatched
 // vehicles (hooks) and orders whose trip may outlive the ring horizon keep the ring / far path.  Used when W <= DENSE_PULL_WMAX.
 #define DENSE_PULL_WMAX 3
+__host__ __device__ inline unsigned pull_entry(int veh, int arrival_slot) { return ((unsigned)veh << 8) | ((unsigned)arrival_slot & 0xFFu); }
+// rejected at slot t: a byte no slot in (t, t + 128) has
+__host__ __device__ inline unsigned pull_reject(int t) { return 0xFFFFFF00u | ((unsigned)(t + 128) & 0xFFu); }
+__host__ __device__ inline bool pull_is_reject(unsigned e) { return (e >> 8) == 0xFFFFFFu; }
+// slots between `now_slot` and the entry's arrival (<= 0: arrived), for entries processed at most 127 slots before now_slot
+__host__ __device__ inline int pull_slots_ahead(unsigned e, int now_slot) { return (int)(signed char)((e & 0xFFu) - ((unsigned)now_slot & 0xFFu)); }
 #define DENSE_DEAD_COST 0x00FFFFFF      // cost of the dead column of an int block: (cost << 7 | pos) stays a positive int
 #define DENSE_ID_BITS 25
 __host__ __device__ inline unsigned dense_pack(unsigned veh, unsigned loc) { return (veh << 8) | (loc & 0xFFu); }

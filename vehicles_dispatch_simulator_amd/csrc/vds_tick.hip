@@ -1029,13 +1029,13 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                 const int lo = df[(size_t)max(tr - S.pull_W + 1, 0) * S.C + c], hi = df[(size_t)min(tr + S.pull_hmax + 1, TA) * S.C + c];
                 for (int i = lo; i < hi; ++i) {
                     const int2 rec = S.d_rec[i];
-                    const int a0 = rec.y & 0xFFFF, tins = a0 - (int)((unsigned)rec.y >> 24);
+                    const int tins = (rec.y & 0xFFFF) - (int)((unsigned)rec.y >> 24);
                     if (tins > tr) continue;                     // not processed yet: the entry is not of this episode
                     const unsigned e = D.arr[(size_t)(i - d2.y) * S.R + r];
-                    if (e == 0xFFFFFFFFu) continue;              // rejected
-                    const int at = a0 + (int)(e & 0xFFu);
-                    infl += at > tr ? 1 : 0;
-                    supply += at == tr + 1 ? 1 : 0;
+                    if (pull_is_reject(e)) continue;
+                    const int ahead = pull_slots_ahead(e, tr);
+                    infl += ahead > 0 ? 1 : 0;
+                    supply += ahead == 1 ? 1 : 0;
                 }
             }
             tile[0][ty][tx] = h[HDR_IDLE_PRE];

@@ -45,7 +45,7 @@ struct DenseArgs {
     int r_lo, dense_tab, dense_keys, dense_force_slow;
     int *ring_min;                   // (instrumented build: shadow target of the doubled posts)
     // static arrival slots ("pull", vds_device.h)
-    unsigned *arr; const int2 *so_dq; const int2 *d_rec; const int *d_first; const int4 *replica_desc2; int pull_W;
+    unsigned *arr; const int *so_slot; const int2 *d_rec; const int *d_first; const int4 *replica_desc2; int pull_W;
     const Static *Sdev; const State *Ddev;
 };
 __device__ __forceinline__ uint2 *ring2(const DenseArgs &D) { return D.ring; }
@@ -110,14 +110,124 @@ __device__ __forceinline__ unsigned loc_bytes4(unsigned e0, unsigned e1, unsigne
 __device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) { return (mask & a) | (~mask & b); }      // v_bfi_b32
 __device__ __forceinline__ unsigned byte_of(unsigned v, int i) { return (v >> (8 * i)) & 0xFFu; }
 
+// inclusive scan over the 64 lanes (row scan + row_bcast:15 / :31)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v = row_incl_scan_i32(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// Match + results + compaction of ONE bucket by the whole wavefront with the list in registers (slow path of k_tick_dense for
+// lists of up to 64 * J entries: beyond the 128-entry tables of the row groups).  Byte costs, cost block in LDS.  Lane l holds
+// positions l*J .. l*J+J-1; candidate key (cost << 10 | position), wave-wide DPP minimum.  Returns the new list length.
+template <int J>
+__device__ int dense_match_wave(const Static &S, const State &D, int r, int t, int now, int m, int q0, int k, const unsigned char *lds_blk, int nc,
+                                unsigned *idle, int &wait_sum, int &value_sum, long long &evals, int &rejects) {
+    constexpr int NL = J / 4;
+    const int lane = lane_id();
+    const int lbase = lane * J;
+    unsigned e[J];
+#pragma unroll
+    for (int s = 0; s < J; ++s) e[s] = 0u;
+    if (lbase < m) {
+#pragma unroll
+        for (int s = 0; s < J; s += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(idle + lbase + s);
+            e[s] = v.x; e[s + 1] = v.y; e[s + 2] = v.z; e[s + 3] = v.w;
+        }
+    }
+    const unsigned ncrep = (unsigned)nc * 0x01010101u;
+    unsigned L[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const unsigned v = loc_bytes4(e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]);
+        const int nv = min(max(m - lbase - 4 * i, 0), 4);
+        L[i] = bfi((unsigned)(0xFFFFFFFFull << (8 * nv)), ncrep, v);
+    }
+    int navail = m;
+    int2 *out_r = out_row(S, D, r);
+    for (int base = 0; base < k; base += WAVE) {
+        const int kk = min(WAVE, k - base);
+        int4 rec = make_int4(0, 0, 0, 0);
+        int slot = -1;
+        if (lane < kk) { rec = S.so_rec[q0 + base + lane]; if (S.pull) slot = S.so_slot[q0 + base + lane]; }
+        int res = IMAX;
+        for (int j = 0; j < kk; ++j) {
+            const int p = rdlane(rec.y, j) & 0xFFFF;
+            const unsigned char *row = lds_blk + p * (nc + 1);
+            int best = IMAX;
+#pragma unroll
+            for (int s = 0; s < J; ++s) best = min(best, (int)(((unsigned)row[byte_of(L[s >> 2], s & 3)] << 10) | (unsigned)s));
+            best += lbase;
+            const int rmin = wave_min_i32(best);
+            const int wrel = (rmin & 1023) - lbase;
+            const unsigned bm = 0xFFu << ((wrel & 3) << 3);
+            const int hi = wrel >> 2;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) L[i] = bfi(hi == i ? bm : 0u, ncrep, L[i]);
+            res = lane == j ? rmin : res;
+            evals += navail;
+            navail -= (rmin >> 10) != 0xFF ? 1 : 0;
+        }
+        // results of this batch: lane j holds order base + j
+        const bool has = lane < kk;
+        const bool matched = has && (res >> 10) != 0xFF;
+        const int wait = res >> 10, wpos = res & 1023;
+        unsigned went = 0;
+#pragma unroll
+        for (int s = 0; s < J; ++s) {
+            const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute((wpos / J) << 2, (int)e[s]);
+            went = (wpos % J) == s ? got : went;
+        }
+        const int vid = matched ? (int)(went >> 8) : -1;
+        if (has) {
+            out_r[q0 + base + lane] = make_int2(vid, matched ? wait : -1);
+            if (slot >= 0) {            // static arrival slot
+                const int rel = wait + rec.w;
+                const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
+                D.arr[(size_t)slot * S.R + r] = matched ? pull_entry(vid, t + d) : pull_reject(t);
+            } else if (matched) post_arrival<true, true>(S, D, rec.z & 0xFFFF, r, t, now, vid, rec.x, now + wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
+        }
+        wait_sum += wave_sum_i32(matched ? wait : 0);
+        value_sum += wave_sum_i32(matched ? rec.w : 0);
+        rejects += wave_sum_i32((has && !matched) ? 1 : 0);
+    }
+    // order-preserving compaction (:963): survivors from the first taken position on
+    int alive = 0, firstdead = IMAX;
+#pragma unroll
+    for (int s = J - 1; s >= 0; --s) {
+        const bool dead = byte_of(L[s >> 2], s & 3) == (unsigned)nc;
+        alive += dead ? 0 : 1;
+        firstdead = dead ? lbase + s : firstdead;
+    }
+    const int incl = wave_incl_scan_i32(alive);
+    const int mfin = rdlane(incl, WAVE - 1);
+    const int fc = wave_min_i32(firstdead);
+    int wp = incl - alive;
+#pragma unroll
+    for (int s = 0; s < J; ++s) {
+        if (byte_of(L[s >> 2], s & 3) != (unsigned)nc) {
+            if (wp >= fc) idle[wp] = e[s];
+            wp++;
+        }
+    }
+    return mfin;
+}
+
 // ---------------------------------------------------------------------------------------
 // Slow path: the whole tick of ONE bucket by one wavefront, any list length / arrival count / order count, straight from
 // HBM (dense layout).  Far entries (arrival >= H ticks after the insertion) stay in the bucket's far list `fl` - full int4
 // entries - until they are due; they are then ranked together with the slot's ring entries by the full dict-insertion key
 // (insert_tick, is_dispatch, id).  An order-carrying far entry due at the NEXT slot is announced in that slot's counter (high
 // half of ring_cnt = SupplyExpect, :880-891).
+// lds_blk: the cluster's cost block in LDS (null: not staged - a bucket without orders)
 template <typename CT>
-__device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r, int t, const CT *blk_g, int nc) {
+__device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r, int t, const CT *blk_g, int nc, const CT *lds_blk) {
     const int lane = lane_id();
     const int p = t & 1;
     const DayView dv = day_view(S, r);
@@ -163,7 +273,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
                 const unsigned raw = D.arr[(size_t)(clo - qdb + idx) * S.R + r];
                 const int2 rec = S.d_rec[clo + idx];
                 const int a0 = rec.y & 0xFFFF;
-                if ((int)(raw & 0xFFu) != t - a0) return false;
+                if ((raw & 0xFFu) != ((unsigned)t & 0xFFu)) return false;
                 const unsigned tins = (unsigned)(a0 - (int)((unsigned)rec.y >> 24));
                 key = ((unsigned long long)(tins << 1) << 32) | (unsigned)dense_key_id((unsigned)rec.x);
                 ent = (raw & 0xFFFFFF00u) | (((unsigned)rec.y >> 16) & 0xFFu);
@@ -248,11 +358,22 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
     m += Atot;
     const int m_pre = m;
     wave_fence();
-    // ---- match (:912-973): every order scans the list in place; a taken entry is marked 0xFFFFFFFF and skipped from then on
     long long wait_sum = 0, value_sum = 0, evals = 0;
     int rejects = 0, navail = m;
+    // ---- match (:912-973).  Byte costs and at most 1024 entries: the list in registers, cost block in LDS
+    bool done = false;
+    if (sizeof(CT) == 1 && lds_blk != nullptr && k > 0 && m <= 16 * WAVE) {
+        int ws = 0, vs = 0;
+        const unsigned char *lb = reinterpret_cast<const unsigned char *>(lds_blk);
+        if (m <= 4 * WAVE) m = dense_match_wave<4>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
+        else if (m <= 8 * WAVE) m = dense_match_wave<8>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
+        else m = dense_match_wave<16>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
+        wait_sum = ws; value_sum = vs; navail = m;
+        done = true;
+    }
+    // ... otherwise every order scans the list in place; a taken entry is marked 0xFFFFFFFF and skipped from then on
     int2 *out_r = out_row(S, D, r);
-    for (int j = 0; j < k; ++j) {
+    for (int j = 0; j < (done ? 0 : k); ++j) {
         const int4 rec = S.so_rec[q0 + j];
         evals += navail;
         int res_veh = -1, res_wait = -1;
@@ -285,17 +406,17 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
         }
         if (lane == 0) {
             out_r[q0 + j] = make_int2(res_veh, res_wait);
-            const int2 dq = S.pull ? S.so_dq[q0 + j] : make_int2(-1, 0);
-            if (dq.x >= 0) {            // static arrival slot: {veh << 8 | arrival slot - a0}, all ones when rejected
+            const int slot = S.pull ? S.so_slot[q0 + j] : -1;
+            if (slot >= 0) {            // static arrival slot
                 const int rel = res_wait + rec.w;
                 const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
-                D.arr[(size_t)dq.x * S.R + r] = res_veh >= 0 ? (((unsigned)res_veh << 8) | (unsigned)(d - dq.y)) : 0xFFFFFFFFu;
+                D.arr[(size_t)slot * S.R + r] = res_veh >= 0 ? pull_entry(res_veh, t + d) : pull_reject(t);
             } else if (res_veh >= 0) post_arrival<false, true>(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
     }
     wave_fence();
     // ---- order-preserving compaction (:963)
-    if (navail != m) {
+    if (!done && navail != m) {
         int newm = 0;
         for (int base = 0; base < m; base += WAVE) {
             const int i = base + lane;
@@ -386,7 +507,7 @@ __device__ __forceinline__ void merge_arrivals_any(const uint2 *ring, unsigned *
 
 // The same with static arrival slots (PULL): arrival slot a of a lane is candidate idx = a * LPR + lg of the bucket's n candidates
 // (raw D.arr entries parked in tab[0 .. n) by the prologue, their static records in lds_drec) or, behind them, entry idx - n of
-// the ring slot (dispatched vehicles).  A candidate arrives when its entry's low byte equals t - a0.
+// the ring slot (dispatched vehicles).  A candidate arrives when its entry's low byte is slot t's.
 template <int LPR, int NA, int J>
 __device__ __forceinline__ void merge_pull(const uint2 *ring, unsigned *tab, const int2 *lds_drec, int lg, int m, int n, int Aring, int Ntot, int t,
                                            unsigned tbase, const unsigned *e) {
@@ -398,8 +519,10 @@ __device__ __forceinline__ void merge_pull(const uint2 *ring, unsigned *tab, con
         ent[a] = 0u; key[a] = 0xFFFFFFFFu; rank[a] = 0;
         if (idx < n) {
             const unsigned raw = tab[idx];
-            const int2 rec = lds_drec[idx];
-            if ((int)(raw & 0xFFu) == t - (rec.y & 0xFFFF)) { key[a] = (unsigned)rec.x - tbase; ent[a] = (raw & 0xFFFFFF00u) | ((unsigned)(rec.y >> 16) & 0xFFu); }
+            if ((raw & 0xFFu) == ((unsigned)t & 0xFFu)) {
+                const int2 rec = lds_drec[idx];
+                key[a] = (unsigned)rec.x - tbase; ent[a] = (raw & 0xFFFFFF00u) | ((unsigned)(rec.y >> 16) & 0xFFu);
+            }
         } else if (idx - n < Aring) {
             const uint2 r8 = ring[idx - n];
             key[a] = r8.y - tbase; ent[a] = r8.x;
@@ -467,7 +590,8 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 //   1 no arrival posts, 2 no idle write-back, 4 no match loop, 8 no result stores, 16 no header / counter stores, 32 posts: atomic
 //   only, 64 posts: entry store only, 256 nothing after the header loads, 512 empty kernel, 1024 no cost-block staging,
 //   2048 no list / arrival loads and no merge; state-preserving: 4096 every post twice (second into a shadow table), 8192 the
-//   atomic twice, 16384 the entry store twice, 32768 no counter stores
+//   atomic twice, 16384 the entry store twice, 32768 no counter stores, 65536 the arrival-slot store twice, 131072 no counter
+//   loads, 262144 the match loop twice
 #ifdef VDS_PROF
 #define DN_ABL (g_ablate)
 #else
@@ -478,7 +602,7 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 template <int LPR, int TS, typename CT, int DM, bool PULL>
 __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &D, int t, int now, int q0, int k, int qb, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, unsigned *tab, int r, bool rowvalid, size_t b, size_t si,
-                                           int m, int A, long long cntv, int n, int Aring, const int2 *lds_drec, const int2 *lds_dq) {
+                                           int m, int A, long long cntv, int n, int Aring, const int2 *lds_drec, const int *lds_slot, bool prof, unsigned long long tprev, int pwave) {
     constexpr int J = TS / LPR;                 // slots per lane
     constexpr int NL = (J + 3) / 4;             // packed loc registers
     constexpr int NG = DN_ORDERS / LPR;         // result registers (orders jj * LPR + lg)
@@ -506,6 +630,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             e[0] = v.x; e[1] = v.y;
         }
     }
+    PROF_STAMP(3);          // idle list chunk loaded
     const int Amax = (abl & 2048) ? 0 : wave_max_of_groups<LPR>(PULL ? Aring : A);       // (ring entries)
     const int Ntot = PULL ? n + Amax : Amax;                                          // arrival slots to rank (wave-uniform)
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
@@ -542,6 +667,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             e[0] = v.x; e[1] = v.y;
         }
     }
+    PROF_STAMP(4);          // arrivals ranked, merged
     // packed loc bytes; slots at and behind position mnew are dead (loc byte = nc, the dead column)
     const unsigned ncrep = (unsigned)nc * 0x01010101u;
     unsigned L[NL];
@@ -555,6 +681,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         const unsigned deadmask = (unsigned)(0xFFFFFFFFull << (8 * nv));           // bytes nv.. are dead (nv = 4: none)
         L[i] = bfi(deadmask, ncrep, v);
     }
+    PROF_STAMP_NW(5);       // loc bytes
     // 5. match loop (:912-973, own-cluster scan :924-933)
     int recy = 0;
     if (lane < k) recy = lds_rec[lane].y;
@@ -562,6 +689,17 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     int res[NG];
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) res[jj] = IMAX;
+#ifdef VDS_PROF
+    unsigned Lsave[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) Lsave[i] = L[i];
+    for (int pass = 0; pass < ((abl & 262144) ? 2 : 1); ++pass) {
+    if (pass) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) L[i] = Lsave[i];
+        navail = mnew; evals = 0;
+    }
+#endif
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
         if (jj * LPR >= k || (abl & 4)) break;
@@ -589,6 +727,10 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             navail -= hit ? 1 : 0;
         }
     }
+#ifdef VDS_PROF
+    }
+#endif
+    PROF_STAMP(6);          // match loop
     // 6. order-preserving compaction of the survivors (:963) through the row's table, written back with whole-chunk stores from
     //    the first changed position on
     int alive = 0, firstdead = IMAX;
@@ -621,6 +763,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             *reinterpret_cast<uint2 *>(idle + lbase) = *reinterpret_cast<const uint2 *>(tab + lbase);
         }
     }
+    PROF_STAMP(7);          // compaction + write-back
     // 7. results (:947-965): vehicle ids through the LDS crossbar, the arrival posts (ring-slot atomic, then the entry)
     int wsum = 0, vsum = 0, rej = 0;
     int2 *out_r = D.out + (size_t)r * S.Oq + (q0 - qb);
@@ -643,14 +786,17 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         }
         const int vid = matched ? (int)(went >> 8) : -1;
         if (has && !(abl & 8)) out_r[j] = make_int2(vid, matched ? wait : -1);
-        int2 dq = make_int2(-1, 0);
-        if (PULL) dq = lds_dq[j < k ? j : 0];
-        if (PULL && dq.x >= 0) {
-            // :954-960 with a static arrival slot: a plain store of {veh << 8 | arrival slot - a0} (rejected: all ones) - every
+        int slot = -1;
+        if (PULL) slot = lds_slot[j < k ? j : 0];
+        if (PULL && slot >= 0) {
+            // :954-960 with a static arrival slot: a plain store of pull_entry(veh, arrival slot) (pull_reject: no vehicle) - every
             // processed order writes its slot, so what a destination bucket reads is always of this episode
             const int rel = wait + rr.w;
             const int d = rel <= 0 ? 1 : ticks_until_fast(S, rel);
-            if (has && !(abl & 1)) D.arr[(size_t)dq.x * S.R + r] = matched ? (((unsigned)vid << 8) | (unsigned)(d - dq.y)) : 0xFFFFFFFFu;
+            if (has && !(abl & 1)) D.arr[(size_t)slot * S.R + r] = matched ? pull_entry(vid, t + d) : pull_reject(t);
+#ifdef VDS_PROF
+            if (has && (abl & 65536)) reinterpret_cast<unsigned *>(D.ring_min)[(size_t)slot * S.R + r] = (unsigned)vid;      // the slot store once more (shadow table)
+#endif
         } else if (matched && !(abl & 1)) {
             // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery), entered into the destination's arrival table
             const int rel = wait + rr.w;
@@ -691,6 +837,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_IDLE ? mfin : (lg == HDR_IDLE_PRE ? mnew : k);
         if (!(abl & 32768)) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, k, rej, wsum, vsum, evals, A);
     }
+    PROF_STAMP(8);          // results, arrival slots, header, counters
 }
 
 // waves per SIMD the kernel is scheduled for: 16-lane groups hold at most 8 + 2 table registers (<= 64 VGPRs: 8 wavefronts per
@@ -715,11 +862,11 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     constexpr int RPW = WAVE / LPR;             // rows per wavefront
     constexpr int NTHR = DN_ROWS * LPR;
     extern __shared__ int lds_dyn[];
-    // dynamic LDS: order records int4[64] | their arrival-slot records int2[64] | candidate records int2[DN_CAND] (both PULL only)
+    // dynamic LDS: order records int4[64] | their arrival-slot indices int[64] | candidate records int2[DN_CAND] (both PULL only)
     //              | per-row tables [16][DN_TAB] u32 | cost block (row stride n_c + 1)
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
-    int2 *lds_dq = reinterpret_cast<int2 *>(lds_rec + DN_ORDERS);
-    int2 *lds_drec = lds_dq + (PULL ? DN_ORDERS : 0);
+    int *lds_slot = reinterpret_cast<int *>(lds_rec + DN_ORDERS);
+    int2 *lds_drec = reinterpret_cast<int2 *>(lds_slot + (PULL ? DN_ORDERS : 0));
     unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
     CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * DN_TAB);
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
@@ -734,6 +881,14 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     const int rslot = chunk * DN_ROWS + wave * RPW + g;
     const int r = (DM == 1 && S.rperm != nullptr) ? S.rperm[rslot] : rslot;
     bool rowvalid = r >= 0 && r < S.R;
+#ifdef VDS_PROF
+    const bool prof = (g_ablate & 128) != 0;
+    unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#else
+    const bool prof = false;
+    unsigned long long tprev = 0ull;
+#endif
+    const int pwave = (int)((blockIdx.x * (NTHR / WAVE) + wave) & (PROF_WAVES - 1));
     int q0, k, now, qb = 0;
     int clo = 0, n = 0, qdb = 0;                // PULL: the bucket's candidates = d_rec[clo .. clo + n), D.arr rows clo - qdb ...
     if (DM == 1) {
@@ -778,24 +933,29 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
         m = h0.x;
         far = h0.w | hin;
         A = D.ring_cnt[si] & 0xFFFF;
-        if (LPR >= CNT_WORDS && lg < CNT_WORDS) cntv = D.cnt[b * CNT_WORDS + lg];
+        if (LPR >= CNT_WORDS && lg < CNT_WORDS && !(DN_ABL & 131072)) cntv = D.cnt[b * CNT_WORDS + lg];
     }
+    int Aring = A;
     if (PULL && wg_ok) {
         const unsigned *ar = D.arr + (size_t)(clo - qdb) * S.R + (rowvalid ? r : 0);
+        const unsigned never = pull_reject(t - 1);          // (a byte slot t does not have)
+        int ap = 0;
         for (int i0 = 0; i0 < n; i0 += 4 * LPR) {          // four loads in flight per lane
             unsigned v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = i0 + u * LPR + lg;
-                v[u] = 0xFFFFFFFFu;
+                v[u] = never;
                 if (idx < n && rowvalid) v[u] = ar[(size_t)idx * S.R];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = i0 + u * LPR + lg;
                 if (idx < n) tab[idx] = v[u];
+                ap += (v[u] & 0xFFu) == ((unsigned)t & 0xFFu) ? 1 : 0;
             }
         }
+        A = Aring + grp_sum<LPR>(ap);       // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
     }
     if (DN_ABL & 256) { if (m + far + A + (int)cntv == 0x7FFFFFF1) D.err[1] = 1; return; }
     // 2. stage the cluster's cost block, the bucket's order records and - PULL - the candidates' static records in LDS
@@ -805,23 +965,17 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
         const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
         int4 rec = make_int4(0, 0, 0, 0);
-        int2 dq = make_int2(-1, 0);
+        int slot = -1;
         const bool mine = (int)threadIdx.x < min(k, DN_ORDERS);
-        if (mine) { rec = S.so_rec[q0 + threadIdx.x]; if (PULL) dq = S.so_dq[q0 + threadIdx.x]; }
+        if (mine) { rec = S.so_rec[q0 + threadIdx.x]; if (PULL) slot = S.so_slot[q0 + threadIdx.x]; }
         if (!(DN_ABL & 1024)) for (int i = threadIdx.x; i < n4; i += NTHR) lds4[i] = blk4[i];
-        if (mine) { lds_rec[threadIdx.x] = rec; if (PULL) lds_dq[threadIdx.x] = dq; }
+        if (mine) { lds_rec[threadIdx.x] = rec; if (PULL) lds_slot[threadIdx.x] = slot; }
     }
     if (PULL && wg_ok)
         for (int i = threadIdx.x; i < n; i += NTHR) lds_drec[i] = S.d_rec[clo + i];
+    PROF_STAMP(0);          // scalar loads, header words, candidate entries, staging loads: all arrived
     __syncthreads();
-    // arrivals of the slot: PULL: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
-    int Aring = A;
-    if (PULL) {
-        int ap = 0;
-        if (wg_ok)
-            for (int idx = lg; idx < n; idx += LPR) ap += (int)(tab[idx] & 0xFFu) == t - (lds_drec[idx].y & 0xFFFF) ? 1 : 0;
-        A = Aring + grp_sum<LPR>(ap);
-    }
+    PROF_STAMP_NW(1);       // barrier
     const int mnew0 = m + A;
     const bool bad = rowvalid && (!wg_ok || far != 0 || Aring > S.dense_keys || Aring > S.ring_cap || A > DN_TAB || mnew0 > S.dense_tab || mnew0 > S.idle_cap || S.dense_force_slow ||
                                   (PULL && (A - Aring > S.dense_keys * 2 || n + Aring > DN_TAB)));
@@ -830,16 +984,17 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     if (bad) { rowvalid = false; m = 0; A = 0; Aring = 0; }
     const bool any = ballot(rowvalid) != 0;
     const int mmax = wave_max_of_groups<LPR>(m + A);
+    PROF_STAMP_NW(2);       // arrival count, row classification
     if (any) {
         const int nn = wg_ok ? n : 0;
-        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_dq);
-        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_dq);
-        else dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_dq);
+        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_slot, prof, tprev, pwave);
+        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_slot, prof, tprev, pwave);
+        else dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_slot, prof, tprev, pwave);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int l0 = __ffsll((long long)rest) - 1;
-        dense_bucket_slow<CT>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc);
+        dense_bucket_slow<CT>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc, k > 0 ? lds_blk : (const CT *)nullptr);
     }
 }
 
@@ -874,7 +1029,7 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     P.tick_minutes = S.tick_minutes; P.now0 = S.now0; P.tick_div_limit = S.tick_div_limit; P.tick_magic = S.tick_magic;
     P.r_lo = r_lo; P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
     P.Sdev = S.self_dev; P.Ddev = S.state_dev; P.ring_min = D.ring_min;
-    P.arr = D.arr; P.so_dq = S.so_dq; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
+    P.arr = D.arr; P.so_slot = S.so_slot; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
     const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R);
     const int rchunks = (slots + DN_ROWS - 1) / DN_ROWS;
     const dim3 grid(S.C * rchunks);
