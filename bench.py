@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-neighbour-leg", action="store_true", help="skip the extra configs[3] (neighbour search) leg")
     ap.add_argument("--check", action="store_true", help="verify replica 0 against the oracle after the run")
     ap.add_argument("--distinct-days", type=int, default=16, help="extra leg: the same workload with this many different order days (0/1 = skip)")
+    ap.add_argument("--no-distinct-all", dest="distinct_all", action="store_false", help="skip the leg with one order day per replica")
+    ap.add_argument("--no-hooked-leg", dest="hooked", action="store_false", help="skip the hooked-slot leg (step -> obs -> policy -> dispatch -> advance)")
     a = ap.parse_args()
 
     import torch
@@ -128,12 +130,22 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # one rank per GPU (the driver's launch).  VDS_BENCH_BACKEND=gloo: the tests' way to run the SAME N > 1 path with two ranks on
+    # a box with one GPU (RCCL refuses two ranks on one device): ranks then share devices round-robin
+    backend = os.environ.get("VDS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run the RCCL path is exercised even at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     R = a.replicas
     if a.workload == "cfg2":
@@ -204,6 +216,17 @@ def main():
         ev1.record(stream)
         ev1.synchronize()
         day_ms = ev0.elapsed_time(ev1)
+        # the same day as ONE chain of launches over all replicas (VDS_RUN_GROUPS=1: what rocprofv3 --stats of profiles/<tag>/ times
+        # kernel by kernel), same event-pair method, same process, same box: the line carries the two-chain gain itself
+        groups_default = env.run_groups()
+        one_chain_day_ms = day_ms
+        if groups_default > 1:
+            env.set_run_groups(1, 0)
+            env.reset_again(); env.run(T); env.reset_again()
+            ev0.record(stream); env.run(T); ev1.record(stream); ev1.synchronize()
+            one_chain_day_ms = ev0.elapsed_time(ev1)
+            env.set_run_groups(0, -1)              # library default again
+            env.reset_again(); env.run(T)
         env.reset_again()                          # counting pass (untimed): the same day, observed slot by slot
         idle_loaded = torch.zeros((), dtype=torch.int64, device="cuda")
         busy_buckets = torch.zeros((), dtype=torch.int64, device="cuda")
@@ -224,9 +247,10 @@ def main():
             side = workloads.profile_side_data(ROOT, a.workload, R, kern)
             traffic = side.get("hbm_bytes_per_launch")
             traffic_build = side.get("traffic_build")
-            same_build = traffic is not None and traffic_build == build_id
+            same_build = traffic is not None and traffic_build is not None and traffic_build.split("+")[0] == build_id.split("+")[0]      # (the kernel half of the id: host-only edits keep the evidence)
             # frac: HBM bytes per launch / average launch duration / 8 TB/s.  The bytes are the rocprofv3 PMC figure
-            # (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes) when it was measured on THIS build
+            # (profiles/traffic.json: read requests by size + WRITE_SIZE, separate passes, calibrated against known byte counts in
+            # profiles/ubench/bytes_calib.json) when it was measured on THIS build's kernels
             # (vds_build_id); otherwise the bytes the data layout has to move - a lower bound - and the line says so
             basis_bytes = traffic if same_build else lay_bytes
             roofline = {"bound": "hbm", "kernel": kern, "build": build_id,
@@ -234,6 +258,7 @@ def main():
                         "frac": basis_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
                         "frac_basis": "pmc-traffic (profiles/traffic.json, same build)" if same_build else "layout-bytes (no PMC figure for this build)",
                         "traffic": traffic, "traffic_build": traffic_build, "traffic_build_matches": bool(same_build),
+                        "traffic_basis": side.get("traffic_basis"), "traffic_source": side.get("traffic_source"),
                         "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                         "layout_bytes_per_launch": lay_bytes, "layout_frac": lay_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
                         # SURVEY 8(d)'s accounting unit (16 B per evaluation as if cost / location / idle entry came
@@ -246,7 +271,12 @@ def main():
                         # event_pair_avg_launch_ms: ONE launch over all replicas by itself (the eager, profiled pass: an event pair
                         # per launch) - the figure rocprofv3 --stats of profiles/<tag>/kernel_stats.csv (VDS_RUN_GROUPS=1) shows
                         "avg_launch_ms": avg_s * 1e3, "launches": launches, "day_kernel_ms": day_ms,
-                        "run_groups": env.run_groups(), "event_pair_avg_launch_ms": float(ms.mean()),
+                        "run_groups": groups_default, "event_pair_avg_launch_ms": float(ms.mean()),
+                        # one chain (one launch per tick over all replicas), one event pair around the day: the per-launch figure
+                        # a kernel trace can confirm (profiles/<tag>/kernel_stats.csv: avg x launches <= this day)
+                        "one_chain_day_kernel_ms": one_chain_day_ms, "one_chain_ms_per_tick": one_chain_day_ms / launches,
+                        "frac_one_chain": basis_bytes / (one_chain_day_ms * 1e-3 / launches) / 1e9 / HBM_PEAK_GBS,
+                        "two_chain_gain": one_chain_day_ms / day_ms,
                         "match_evals_per_s": work["evals"] / (day_ms * 1e-3)}
             lim = side.get("limiter")
             if lim:
@@ -258,7 +288,7 @@ def main():
                                        "valu_insts_per_launch": lim["valu_insts_per_launch"],
                                        "cycles_per_valu_inst": lim["cycles_per_valu_inst"],
                                        "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source"),
-                                       "build": lim.get("build"), "build_matches": lim.get("build") == build_id}
+                                       "build": lim.get("build"), "build_matches": (lim.get("build") or "").split("+")[0] == build_id.split("+")[0]}
 
     # ---- per-replica order days (rank 0, N = 1): the headline replays ONE day in every replica, which lets 16 replicas
     #      share staged order records and keeps per-order control flow wave-uniform.  The same workload with D distinct
@@ -287,6 +317,26 @@ def main():
             per_days[label] = {"value": T2 * R * nd / dt2, "ms_per_step": dt2 / nd * 1e3, "steps": nd}
             env2.close()
         per_days["value"] = per_days["interleaved"]["value"]
+        # every replica its OWN day (the ordinary RL case: R different episodes), days drawn from a pool of R distinct days
+        if a.distinct_all:
+            daysR = workloads.distinct_days(w, R)
+            env2 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
+            env2.load_order_days(daysR, np.arange(R, dtype=np.int32))
+            env2.reset(init)
+            T2 = env2.T
+            env2.reset_again(); env2.run(T2)
+            torch.cuda.synchronize()
+            nd = max(2, min(a.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(nd):
+                env2.reset_again(); env2.run(T2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            env2.sync()
+            per_days["distinct_%d" % R] = {"value": T2 * R * nd / dt2, "ms_per_step": dt2 / nd * 1e3, "steps": nd, "kernel": env2.main_kernel(),
+                                           "slow_path_buckets_last_day": int(env2.work().get("slow_path_buckets", 0)),
+                                           "vs_shared_day": (T2 * R * nd / dt2) / (T * R * world * a.steps / elapsed)}
+            env2.close()
 
     # ---- neighbour-search mode (rank 0, N = 1, only next to the headline workload): BASELINE configs[3] - the same city with
     #      NeighborCanServer and a 2000 m service radius (DFS depth 2) - a few days, so that the line also shows the second tick path
@@ -310,6 +360,98 @@ def main():
                "kernel": env4.main_kernel(), "run_groups": env4.run_groups(),
                "evidence": "profiles/r03_cfg4_hybrid (bench.py --workload cfg4 --check: roofline, parity)"}
         env4.close()
+
+    # ---- the hooked slot (rank 0, N = 1): what an RL loop over R cities costs per slot - the reference's hook order
+    #      (simulator.py:1057-1087: Match -> Reward / state hooks -> SupplyExpect -> DispatchFunction :893-898 -> next Update) with
+    #      observations, policy and actions on the device: step -> obs_torch -> a small torch policy -> apply_dispatch_torch (K = 8
+    #      moves per city and slot) -> advance.  Timed next to the same loop without the hook (step -> advance) and the hook-less
+    #      vds_run above.
+    hooked = None
+    if rank == 0 and world == 1 and a.hooked and a.workload == "cfg2":
+        K = 8
+        n2c = np.asarray(w.city.node2cluster)
+        some_node_of = torch.tensor([int(np.flatnonzero(n2c == c)[0]) if (n2c == c).any() else 0 for c in range(env.C)], dtype=torch.int32, device="cuda")
+        zeros_k = torch.zeros((R, K), dtype=torch.int32, device="cuda")
+        minus1 = torch.full((R, K), -1, dtype=torch.int32, device="cuda")
+
+        def policy(ob):
+            idle, supply, demand = ob[1], ob[2], ob[3]
+            surplus = idle + supply - demand                             # [R, C] int32
+            src = torch.topk(surplus, K, dim=1).indices                  # the K richest clusters of every city (distinct)
+            dst = torch.topk(surplus, K, dim=1, largest=False).indices   # ... move one idle vehicle each towards the K poorest
+            ok = (idle.gather(1, src) > 0) & (surplus.gather(1, src) - surplus.gather(1, dst) > 4)
+            return torch.stack([torch.where(ok, src.int(), minus1), zeros_k, some_node_of[dst]], dim=2).contiguous()
+
+        # three hooks: (a) a FIXED action tensor (what the boundary itself costs: k_pack_obs + k_dispatch_dense next to the tick),
+        # (b) the torch policy captured once as a CUDA graph over the library's observation block (static address) and replayed
+        # per slot (one submission), (c) the same policy issued eagerly (a dozen torch launches per slot: host-bound)
+        obs_static = env.obs_torch()
+        fixed_actions = torch.stack([minus1, zeros_k, some_node_of[:K].repeat(R, 1)], dim=2).contiguous()
+        fixed_actions[:, 0, 0] = torch.arange(R, device="cuda", dtype=torch.int32) % env.C      # one move per city and slot (skipped where the list is empty: idle_pos 0)
+        actions_static = torch.zeros((R, K, 3), dtype=torch.int32, device="cuda")
+        pol_graph, graph_error = None, None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    actions_static.copy_(policy(obs_static))
+            stream.wait_stream(side)
+            torch.cuda.synchronize()
+            pol_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(pol_graph):
+                actions_static.copy_(policy(obs_static))
+        except Exception as e:       # (a reported extra)
+            pol_graph = None
+            graph_error = repr(e)
+
+        def hooked_day(kind):
+            env.reset_again()
+            for _ in range(T):
+                env.step()
+                if kind == "fixed":
+                    env.obs_torch()
+                    env.apply_dispatch_torch(fixed_actions)
+                elif kind == "graph":
+                    env.obs_torch()                         # k_pack_obs into the static block
+                    pol_graph.replay()
+                    env.apply_dispatch_torch(actions_static)
+                elif kind == "eager":
+                    env.apply_dispatch_torch(policy(env.obs_torch()))
+                env.advance()
+
+        res = {}
+        kinds = [("step_advance_only", "none"), ("engine_hook_fixed_actions", "fixed")] + ([("torch_policy_graph", "graph")] if pol_graph is not None else []) + [("torch_policy_eager", "eager")]
+        for label, kind in kinds:
+            hooked_day(kind); torch.cuda.synchronize()            # warm
+            try:
+                env.sync()
+            except Exception:                                     # (a move from an empty list is skipped and reported once: not an error here)
+                pass
+            nd = 2
+            t1 = time.perf_counter()
+            for _ in range(nd):
+                hooked_day(kind)
+            t_issue = time.perf_counter() - t1                    # host time to ISSUE the days (the stream runs behind)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            try:
+                env.sync()
+            except Exception:
+                pass
+            res[label] = {"slot_us": dt / (nd * T) * 1e6, "host_issue_us_per_slot": t_issue / (nd * T) * 1e6, "value": T * R * nd / dt,
+                          "dispatches_last_day": int(env.work().get("dispatches", 0))}
+        hookless_us = elapsed / a.steps / T * 1e6
+        best = "torch_policy_graph" if "torch_policy_graph" in res else "torch_policy_eager"
+        hooked = {"unit": "env-steps*replicas/s", "value": res[best]["value"], "K": K, "days": 2, "policy": best,
+                  "slot_us": res[best]["slot_us"], "hookless_run_tick_us": hookless_us,
+                  "engine_hook_vs_hookless_tick": res["engine_hook_fixed_actions"]["slot_us"] / hookless_us,
+                  "policy_slot_vs_hookless_tick": res[best]["slot_us"] / hookless_us,
+                  "variants": res,
+                  "note": "per slot: vds_step (one tick launch over all replicas) -> k_pack_obs -> policy -> k_dispatch_dense -> vds_advance; wall "
+                          "time of 2 days incl. the per-day reset; engine_hook_fixed_actions = the boundary without a policy"}
+        if graph_error:
+            hooked["policy_graph_error"] = graph_error
 
     check = None
     if a.check and rank == 0:
@@ -356,6 +498,8 @@ def main():
             out["per_replica_days"] = per_days
         if nbr is not None:
             out["neighbour_search"] = nbr
+        if hooked is not None:
+            out["hooked_slot"] = hooked
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))

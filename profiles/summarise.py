@@ -20,7 +20,7 @@ shutil.copy(st, os.path.join(dst, "kernel_stats.csv"))
 out = {"_note": "rocprofv3 --pmc, one pass per group (FETCH_SIZE | WRITE_SIZE | SQ_* ...), per-launch means for kernels matching '%s'; "
                 "FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads by up to 2x on gfx950 "
                 "(MI355X_MICROARCH.md, HBM section); SQ_*_CYCLES are quad-cycles summed over waves" % kern}
-for name in ("fetch", "write", "sq", "sq2"):
+for name in ("fetch", "write", "rdreq", "wrreq", "sq", "sq2"):
     fs = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
     if not fs:
         continue

@@ -106,7 +106,7 @@ def run_case(seed, case, idle_cap=None):
     lr = np.random.default_rng(90_000 + seed)
     fg, kw = cfg["force_generic"], {}
     if fg == 0:
-        kw["dense_debug"] = (int(lr.choice([16, 8, 4])), int(lr.choice([0, 0, 8, 24, 40])), int(lr.choice([0, 0, 2, 5])), int(lr.random() < 0.1) | (2 if lr.random() < 0.3 else 0))
+        kw["dense_debug"] = (int(lr.choice([16, 8])), int(lr.choice([0, 0, 8, 24, 40])), int(lr.choice([0, 0, 2, 5])), int(lr.random() < 0.1) | (2 if lr.random() < 0.3 else 0))
     env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
                              tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
                              force_generic=fg, idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V), **kw)

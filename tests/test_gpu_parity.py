@@ -149,22 +149,21 @@ MODES = {
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
     "dfs_v2": {"force_generic": 3},          # neighbour search by lower-bound rounds (k_tick_replica2: what the hybrid tick falls back to)
-    # dense tick (k_tick_dense: the default without neighbour search) - 16 / 8 / 4 lanes per replica; tiny fast-path tables
+    # dense tick (k_tick_dense: the default without neighbour search; 8 lanes per replica by default) - 16 lanes per replica; tiny fast-path tables
     # (buckets that outgrow them take dense_bucket_slow); slow path only; far tables.  With neighbour search or a live pickup
     # window the library keeps the wide layout (these fixtures then repeat the default run).
-    "dense8": {"dense_debug": (8, 0, 0, 0)},
-    "dense4": {"dense_debug": (4, 0, 0, 0)},
+    "dense16": {"dense_debug": (16, 0, 0, 0)},
     "dense_tiny": {"dense_debug": (16, 8, 2, 0)},
     "dense_tiny8": {"dense_debug": (8, 12, 3, 0)},
-    "dense_tiny4": {"dense_debug": (4, 20, 1, 0)},
+    "dense_tiny20": {"dense_debug": (8, 20, 1, 0)},
     "dense_slow": {"dense_debug": (16, 0, 0, 1)},
-    "dense_far": {"dense_debug": (8, 0, 0, 0), "ring_ticks": 2},
+    "dense_far": {"dense_debug": (16, 0, 0, 0), "ring_ticks": 2},
     # the same with the arrival ring instead of static arrival slots (what the dense tick does when arrivals can lie more than
     # DENSE_PULL_WMAX slots behind their earliest slot): force_slow bit 1
     "dense_ring": {"dense_debug": (16, 0, 0, 2)},
     "dense_ring8_tiny": {"dense_debug": (8, 12, 3, 2)},
     "dense_ring_slow": {"dense_debug": (16, 0, 0, 3)},
-    "dense_ring_far": {"dense_debug": (4, 0, 0, 2), "ring_ticks": 2},
+    "dense_ring_far": {"dense_debug": (8, 0, 0, 2), "ring_ticks": 2},
     "rows": {"force_generic": 5},            # wide layout + the row-mapped kernel where the dense tick is the default
     "rows_far": {"force_generic": 5, "ring_ticks": 2},
 }

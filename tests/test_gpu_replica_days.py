@@ -15,7 +15,7 @@ from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth, workloads
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"fast": dict(), "generic": dict(force_generic=1), "rows": dict(force_generic=5), "gen2": dict(force_generic=3), "dense8": dict(dense_debug=(8, 0, 0, 0)), "dense4_tiny": dict(dense_debug=(4, 12, 2, 0)), "dense_ring": dict(dense_debug=(16, 0, 0, 2))}
+MODES = {"fast": dict(), "generic": dict(force_generic=1), "rows": dict(force_generic=5), "gen2": dict(force_generic=3), "dense16": dict(dense_debug=(16, 0, 0, 0)), "dense8_tiny": dict(dense_debug=(8, 12, 2, 0)), "dense_ring": dict(dense_debug=(16, 0, 0, 2))}
 
 
 def synth_days(g, n_days, seed):
@@ -48,6 +48,9 @@ def mk_oracle(g, day):
 
 
 @pytest.mark.parametrize("name,mode", [("tiny_kmeans", "fast"), ("tiny_kmeans", "generic"), ("tiny_grid", "fast"),
+                                       # (mixed days inside a group of 16 replicas: the dense tick's per-row order streams, day mode 2)
+                                       ("tiny_kmeans", "dense16"), ("tiny_kmeans", "dense8_tiny"), ("tiny_kmeans", "dense_ring"), ("tiny_grid", "dense16"),
+                                       ("tiny_grid", "dense8_tiny"),
                                        ("tiny_kmeans", "rows"), ("tiny_kmeans_dfs2", "fast"), ("tiny_kmeans_dfs2", "gen2"), ("tiny_kmeans_dfs2", "generic"),
                                        ("tiny_window6", "fast"), ("tiny_empty_clusters_dfs2", "fast")])
 def test_every_replica_replays_its_own_day(name, mode):
@@ -114,6 +117,62 @@ def test_every_replica_replays_its_own_day(name, mode):
     # the same days again (episode restart), through vds_run
     env.reset_again(); env.run(env.T)
     assert (env.total_counters() == tot).all()
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "dense16", "dense8_tiny", "dense_ring", "rows"])
+@pytest.mark.parametrize("V", [32, 33, 64, 96, 127, 128, 129])
+def test_full_tables_rows_with_and_without_an_order_at_each_step(V, mode):
+    """Constructed case for the class of bug the round-3 fuzz found by luck (a row WITHOUT an order at a match step, next to rows
+    with one, while its register table is FULL, lost the vehicle in the table's last slot): sixteen replicas, every one on its own
+    day, all V vehicles parked in one cluster so that its idle list fills the 32- / 64- / 128-entry tables exactly (and one short /
+    one beyond), orders that come and go per replica and slot - at every step of the match loop some rows of a wavefront have an
+    order and others have none.  Every replica against its own oracle, per tick: counters, observations, list order."""
+    g = dict(load_golden("tiny_kmeans"))
+    N, R = int(g["N"]), 16
+    n2c = g["node2cluster"]
+    c0 = int(np.bincount(n2c[n2c >= 0]).argmax())
+    nodes = np.flatnonzero(n2c == c0)
+    g["V"] = np.int64(V)
+    init = np.stack([nodes[(np.arange(V) * (r + 1) + r) % nodes.size] for r in range(R)]).astype(np.int32)
+    days = []
+    for r in range(R):
+        rel, pk, dl = [], [], []
+        for t in range(14):
+            n = 0 if (t + r) % 4 == 0 else 1 + (t * 7 + r * 3) % 6
+            if r == 5 and t >= 6: n = 0                      # a day that ends early: its row stands still
+            for i in range(n):
+                rel.append(10 * t + (i % 10)); pk.append(int(nodes[(3 * t + 5 * i + r) % nodes.size])); dl.append(int(nodes[(7 * t + i + 2 * r) % nodes.size]))
+        rel.append(rel[-1] + 1); pk.append(int(nodes[0])); dl.append(int(nodes[0]))      # (the last order is never processed, :914)
+        days.append((np.array(rel, np.int32), np.array(pk, np.int32), np.array(dl, np.int32)))
+    env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=V, depth_limit=0, neighbor_can_server=False,
+                             **{**engine_settings(g), **MODES[mode]})
+    env.load_order_days(days, np.arange(R, dtype=np.int32))
+    assert env.main_kernel() == ("k_tick_rows" if mode == "rows" else "k_tick_dense")
+    env.reset(init)
+    oracles = []
+    for r in range(R):
+        o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], 0, False, days[r][0], days[r][1], days[r][2], V, **engine_settings(g))
+        o.reset(init[r]); oracles.append(o)
+    for t in range(env.T):
+        env.step()
+        ob, cn = env.obs(), env.counters()
+        for r, o in enumerate(oracles):
+            if t >= o.num_ticks: continue
+            o.begin_tick()
+            oo, oc = o.obs(), o.counters()
+            for a, b in (("idle_pre", "idle_pre"), ("idle_now", "idle_post"), ("supply", "supply"), ("cl_orders", "cl_orders"), ("inflight", "inflight")):
+                np.testing.assert_array_equal(ob[a][r], oo[b], err_msg="tick %d replica %d obs %s" % (t, r, a))
+            assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["evals"]), (t, r)
+            check_lists(env, r, o, t)
+            o.end_tick()
+        env.advance()
+    env.sync()
+    od = env.orders()
+    for r, o in enumerate(oracles):
+        exp = o.orders()
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(od[k][r][:exp[k].size], exp[k], err_msg="replica %d %s" % (r, k))
     env.close()
 
 

@@ -157,6 +157,56 @@ def test_new_order_tables_on_one_handle_update_the_day_graph_in_place(name, grou
     env.close()
 
 
+def test_day_graph_life_cycle_many_handles_two_alive_on_their_own_streams():
+    """Branched executable graphs are never destroyed (csrc/vds_api.hip: graph pool): handles come and go - create / run / another
+    day (same slots: in-place update; other slots: another shape) / run in parts / destroy - fifty times, always two handles alive
+    at once on their own torch streams with their days in flight together, plain and hybrid tick.  Every day equals the
+    one-group run of the same inputs; the pool stays bounded by shapes x handles alive at once (nothing is destroyed, nothing
+    accumulates per handle)."""
+    import torch
+    from vehicles_dispatch_simulator_amd import _lib
+    lib = _lib.load()
+    R = 40
+    cases = []
+    for name, groups in (("tiny_kmeans_dfs2", 3), ("tiny_kmeans", 2)):
+        g = load_golden(name)
+        days = synth_days(g, 3, seed=31)
+        init = _init(g, R, 900)
+        refs = []
+        for d in days:                               # one-group reference results of every day
+            ref = mk_env(g, R); ref.load_orders(*d); ref.set_run_groups(1, 0); ref.reset(init); ref.run(ref.T); ref.sync()
+            refs.append((ref.counters().copy(), {k: np.array(v) for k, v in ref.orders().items()}))
+            ref.close()
+        cases.append((g, groups, days, init, refs))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    pool_sizes = []
+    for rep in range(25):
+        envs = []
+        for i, (g, groups, days, init, refs) in enumerate(cases):
+            env = mk_env(g, R, stream=streams[i].cuda_stream)
+            env.load_orders(*days[rep % 3]); env.set_run_groups(groups, rep % 3); env.reset(init)
+            assert env.run_groups() == groups
+            envs.append(env)
+        for env in envs: env.run(env.T)              # both days in flight together
+        for env, (g, groups, days, init, refs) in zip(envs, cases):
+            env.sync()
+            np.testing.assert_array_equal(env.counters(), refs[rep % 3][0])
+        # another day on the same handles, run in two parts around a hooked step
+        for env, (g, groups, days, init, refs) in zip(envs, cases):
+            env.load_orders(*days[(rep + 1) % 3]); env.reset(init)
+            k = env.T // 2
+            env.run(k); env.step(); env.advance(); env.run(env.T - k - 1)
+        for env, (g, groups, days, init, refs) in zip(envs, cases):
+            env.sync()
+            cn, od = refs[(rep + 1) % 3]
+            np.testing.assert_array_equal(env.counters(), cn)
+            got = env.orders()
+            for key in od: np.testing.assert_array_equal(got[key], od[key], err_msg=key)
+        for env in envs: env.close()
+        pool_sizes.append(lib.vds_debug_graph_pool_size())
+    assert max(pool_sizes) <= 48 and pool_sizes[-1] == pool_sizes[-4] == pool_sizes[-7], pool_sizes       # steady: no growth over two more 3-cycles
+
+
 def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_256_replicas():
     g = load_golden("tiny_kmeans")
     day = synth_days(g, 1, seed=8)

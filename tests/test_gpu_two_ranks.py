@@ -51,3 +51,32 @@ def test_two_ranks_share_the_job(neighbor):
     got = np.array(out["totals"], dtype=np.int64)
     assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2] and got[4] == exp[4], (got.tolist(), exp.tolist())
     assert out["rank0_orders"] == first_rank_orders
+
+
+def test_bench_py_itself_with_two_ranks():
+    """The driver's N > 1 launch line with bench.py ITSELF as the program (not a test worker): two ranks, replicas sharded by
+    global index, weak scaling (R per rank fixed), one counter all-reduce per day, max-over-ranks timing, rank 0 prints the
+    line.  Both ranks sit on this box's one GPU, so the collective runs over gloo (VDS_BENCH_BACKEND); everything else is the
+    code an 8-GPU node runs (scripts/run_8gpu.sh).  The all-reduced totals of the last day equal the CPU oracle's sums over all
+    2 R replicas."""
+    Rr = 24
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--replicas", str(Rr), "--no-cpu-baseline", "--no-neighbour-leg", "--distinct-days", "0", "--no-hooked-leg", "--no-distinct-all"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VDS_BENCH_BACKEND="gloo")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["replicas_total"] == 2 * Rr and out["config"]["replicas_per_gpu"] == Rr
+    assert out["collective"]["world_size"] == 2 and out["collective"]["backend"] == "gloo" and out["collective"]["allreduce_calls"] >= 3
+    assert out["value"] > 0 and abs(out["value"] - 148 * 2 * Rr * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    w = workloads.didi_day("cfg2")
+    init = w.vehicle_nodes(2 * Rr)               # global replica seeds: rank 1 owns replicas Rr .. 2 Rr - 1
+    exp = dict(order_num=0, reject_num=0, wait_sum=0, evals=0)
+    for r in range(2 * Rr):
+        o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server,
+                   w.release_min, w.pickup, w.delivery, w.vehicles)
+        o.reset(init[r]); o.run_day()
+        oc = o.counters()
+        for k in exp: exp[k] += oc[k]
+    assert out["aggregate_counters_last_day"] == exp

@@ -8,9 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <unistd.h>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -126,6 +126,7 @@ struct vds_handle {
     // depend on (tables, capacities, stream) has changed
     hipGraphExec_t run_exec = nullptr;
     int run_t0 = -1, run_n = 0, run_G = 1;
+    unsigned long long run_shape = 0;        // graph_shape of run_exec (grouped graphs: the key it is parked under)
     bool run_stale = false;                  // tables / capacities changed since the graph was built: same shape -> hipGraphExecUpdate
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
@@ -235,26 +236,73 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
 #endif
 #define RUN_GROUPS_MAX 16
 
-// hipGraphExecDestroy of a graph WITH PARALLEL BRANCHES (the replica groups of vds_run) needs a quiet device and a quiet
-// runtime: destroyed right after hipStreamSynchronize - or later, while another such graph runs - it races with the runtime's
-// completion handler (ROCm 7.0 libamdhip64: the HSA signal-handler thread is still releasing commands: abort / SIGSEGV in
+// Executable day graphs WITH PARALLEL BRANCHES (the replica groups of vds_run) are never destroyed while the process lives.
+// hipGraphExecDestroy of such a graph races with the HIP runtime's completion handler (ROCm 7.0 libamdhip64: abort / SIGSEGV in
 // free() under amd::roc::VirtualGPU::updateCommandsState, 5 of 6 runs of profiles/r03_run_groups/crash_probe.py; captured and
-// explicitly built graphs alike; hipDeviceSynchronize alone does not help: profiles/r03_run_groups/notes.md).  What held in every run: device synchronised, then
-// a pause, then the destruction.  It happens once per re-built day graph (new order tables, new run shape, vds_destroy).
-#define GRAPH_QUIET_US 50000
+// explicitly built graphs alike: profiles/r03_run_groups/notes.md; a graph that is never destroyed: 0 of 12).  Round 3 destroyed
+// them after hipDeviceSynchronize + a 50 ms pause - a probability, and a stall of every other stream of the device.  Now a handle
+// that lets go of such a graph (vds_destroy, vds_set_stream, a day graph of another shape) PARKS it in a process-wide pool keyed by
+// its shape (device, node count, kernel functions of the first tick); the next handle that needs a graph of that shape takes it and
+// re-targets it in place (hipGraphExecUpdate: new tables, new replica ranges).  No vds_* call synchronises the device or sleeps.
+// What stays allocated: one executable graph (host memory only: ~150-450 kernel nodes) per shape and per handle that held one at
+// the same time.  Single-chain graphs (one group) are destroyed as before: they never showed the race (0 of 6).
+struct ParkedGraph { int device; unsigned long long shape; hipGraphExec_t exec; };
+static std::mutex g_graph_pool_mu;
+static std::vector<ParkedGraph> g_graph_pool;
+
+static void graph_pool_put(int device, unsigned long long shape, hipGraphExec_t exec) {
+    std::lock_guard<std::mutex> lk(g_graph_pool_mu);
+    g_graph_pool.push_back(ParkedGraph{device, shape, exec});
+}
+static hipGraphExec_t graph_pool_take(int device, unsigned long long shape) {
+    std::lock_guard<std::mutex> lk(g_graph_pool_mu);
+    for (size_t i = 0; i < g_graph_pool.size(); ++i) {
+        if (g_graph_pool[i].device == device && g_graph_pool[i].shape == shape) {
+            hipGraphExec_t e = g_graph_pool[i].exec;
+            g_graph_pool.erase(g_graph_pool.begin() + (long)i);
+            return e;
+        }
+    }
+    return nullptr;
+}
+// shape of a day graph: node count + the kernel functions (template instantiations) of its first nodes + launch geometry that an
+// update may not change safely (block size, dynamic LDS)
+static unsigned long long graph_shape(hipGraph_t g, int n_ticks, int G) {
+    unsigned long long hsh = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { hsh = (hsh ^ v) * 1099511628211ull; };
+    size_t n = 0;
+    if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    size_t n_edges = 0;
+    if (hipGraphGetEdges(g, nullptr, nullptr, &n_edges) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    mix(n); mix(n_edges); mix((unsigned long long)n_ticks); mix((unsigned long long)G);
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const size_t first = std::min(n, (size_t)(2 * G));
+    for (size_t i = 0; i < first; ++i) {
+        hipKernelNodeParams kp{};
+        if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        mix((unsigned long long)(uintptr_t)kp.func); mix(kp.blockDim.x); mix(kp.sharedMemBytes);
+    }
+    return hsh ? hsh : 1;
+}
+extern "C" int vds_debug_graph_pool_size() {      // executable graphs parked right now (tests)
+    std::lock_guard<std::mutex> lk(g_graph_pool_mu);
+    return (int)g_graph_pool.size();
+}
+
 static void drop_run_graph(vds_handle *h) {
     if (h->run_exec) {
         if (h->run_stream) (void)hipStreamSynchronize(h->run_stream);      // (it may still be running)
-        if (h->run_G > 1) { (void)hipDeviceSynchronize(); usleep(GRAPH_QUIET_US); }
-        (void)hipGraphExecDestroy(h->run_exec);
+        if (h->run_G > 1) graph_pool_put(h->cfg.device, h->run_shape, h->run_exec);
+        else (void)hipGraphExecDestroy(h->run_exec);
         h->run_exec = nullptr;
     }
-    h->run_t0 = -1; h->run_n = 0; h->run_G = 1; h->run_stale = false;
+    h->run_t0 = -1; h->run_n = 0; h->run_G = 1; h->run_stale = false; h->run_shape = 0;
 }
 
 // lanes per replica of k_tick_dense unless VDS_DENSE_LPR / vds_debug_dense say otherwise
 #ifndef DENSE_LPR_DEFAULT
-#define DENSE_LPR_DEFAULT 16
+#define DENSE_LPR_DEFAULT 8
 #endif
 
 // Brings the device-resident copies of h->S / h->D up to date (on the handle's stream, ordered before the launches that follow).
@@ -969,15 +1017,16 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[day_of_internal[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
         int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
     }
-    // ---- dense layout (k_tick_dense: 4-byte idle entries, 8-byte arrival entries): the plain tick with one order day per workgroup
-    //      chunk (day modes 0 / 1), ids that fit the packed keys.  vds_config.force_generic 5 keeps the wide layout and k_tick_rows.
-    S.dense = (h->dense_static_ok && (n_days == 1 || S.chunk_days) && Omax < (1 << DENSE_ID_BITS)) ? 1 : 0;
+    // ---- dense layout (k_tick_dense: 4-byte idle entries, 8-byte arrival entries): the plain tick - one shared day, one day per
+    //      workgroup chunk or one day per replica (day modes 0 / 1 / 2) -, ids that fit the packed keys.  vds_config.force_generic 5
+    //      keeps the wide layout and k_tick_rows.
+    S.dense = (h->dense_static_ok && Omax < (1 << DENSE_ID_BITS)) ? 1 : 0;
     // (static arrival slots: the all-ones vehicle field marks a rejected order)
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
         if (env_int("VDS_DENSE", 1) == 0) S.dense = 0;
         const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", DENSE_LPR_DEFAULT);
-        S.dense_lpr = (lpr == 4 || lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
+        S.dense_lpr = (lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
         S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, 128) : 128;
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
         S.dense_force_slow = h->dbg_dense_slow & 1;
@@ -1438,11 +1487,25 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
             updated = hipGraphExecUpdate(h->run_exec, g, &bad, &res) == hipSuccess;
             if (!updated) (void)hipGetLastError();
         }
+        const unsigned long long shape = G > 1 ? graph_shape(g, n_ticks, G) : 0ull;
         if (!updated) {
             drop_run_graph(h);
-            const hipError_t ei = hipGraphInstantiate(&h->run_exec, g, nullptr, nullptr, 0);
-            if (ei != hipSuccess) { (void)hipGraphDestroy(g); h->run_exec = nullptr; (void)hipGetLastError(); return run_eager(h, n_ticks); }
+            // a parked executable graph of this shape (another handle's, or this handle's from before): re-targeted in place
+            if (G > 1 && shape != 0) {
+                hipGraphExec_t parked = graph_pool_take(h->cfg.device, shape);
+                if (parked) {
+                    hipGraphNode_t bad = nullptr;
+                    hipGraphExecUpdateResult res;
+                    if (hipGraphExecUpdate(parked, g, &bad, &res) == hipSuccess) h->run_exec = parked;
+                    else { (void)hipGetLastError(); graph_pool_put(h->cfg.device, shape, parked); }
+                }
+            }
+            if (!h->run_exec) {
+                const hipError_t ei = hipGraphInstantiate(&h->run_exec, g, nullptr, nullptr, 0);
+                if (ei != hipSuccess) { (void)hipGraphDestroy(g); h->run_exec = nullptr; (void)hipGetLastError(); return run_eager(h, n_ticks); }
+            }
         }
+        h->run_shape = shape;
         (void)hipGraphDestroy(g);
         h->run_t0 = t0; h->run_n = n_ticks; h->run_stream = h->stream; h->run_G = G; h->run_stale = false;
     }

@@ -1027,15 +1027,25 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                 const int *df = S.d_first + d2.x;
                 const int TA = S.n_days <= 1 ? S.T + S.H : d2.z;
                 const int lo = df[(size_t)max(tr - S.pull_W + 1, 0) * S.C + c], hi = df[(size_t)min(tr + S.pull_hmax + 1, TA) * S.C + c];
-                for (int i = lo; i < hi; ++i) {
-                    const int2 rec = S.d_rec[i];
-                    const int tins = (rec.y & 0xFFFF) - (int)((unsigned)rec.y >> 24);
-                    if (tins > tr) continue;                     // not processed yet: the entry is not of this episode
-                    const unsigned e = D.arr[(size_t)(i - d2.y) * S.R + r];
-                    if (pull_is_reject(e)) continue;
-                    const int ahead = pull_slots_ahead(e, tr);
-                    infl += ahead > 0 ? 1 : 0;
-                    supply += ahead == 1 ? 1 : 0;
+                // (eight entries in flight per thread: the loop is a chain of dependent-free loads, 60 - 100 per bucket at configs[1])
+                for (int i0 = lo; i0 < hi; i0 += 8) {
+                    int ry[8];
+                    unsigned e[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = min(i0 + u, hi - 1);
+                        ry[u] = S.d_rec[i].y;
+                        e[u] = D.arr[(size_t)(i - d2.y) * S.R + r];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int tins = (ry[u] & 0xFFFF) - (int)((unsigned)ry[u] >> 24);
+                        // (tins > tr: not processed yet - the entry is not of this episode)
+                        const bool live = i0 + u < hi && tins <= tr && !pull_is_reject(e[u]);
+                        const int ahead = pull_slots_ahead(e[u], tr);
+                        infl += (live && ahead > 0) ? 1 : 0;
+                        supply += (live && ahead == 1) ? 1 : 0;
+                    }
                 }
             }
             tile[0][ty][tx] = h[HDR_IDLE_PRE];

@@ -599,9 +599,13 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 #endif
 
 // PULL: m / A as everywhere (A = all arrivals of the slot), Aring = those that sit in the ring slot, n = the bucket's candidates
+// DM == 2 (every replica its own order day): q0 / k / qb / n and the candidate records `lds_drec` (then a global pointer) are
+// PER ROW, kmax = the largest k of the wavefront's rows (the match loop runs that long; a row without an order at a step takes
+// nothing), the orders' pickup rows come from `pick` (u16 row offsets into the cost block, [64] per row, written by the prologue)
+// and their records from so_rec in HBM.
 template <int LPR, int TS, typename CT, int DM, bool PULL>
-__device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &D, int t, int now, int q0, int k, int qb, const CT *lds_blk, int nc,
-                                           const int4 *lds_rec, unsigned *tab, int r, bool rowvalid, size_t b, size_t si,
+__device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &D, int t, int now, int q0, int k, int kmax, int qb, const CT *lds_blk, int nc,
+                                           const int4 *lds_rec, const unsigned short *pick, unsigned *tab, int r, bool rowvalid, size_t b, size_t si,
                                            int m, int A, long long cntv, int n, int Aring, const int2 *lds_drec, const int *lds_slot, bool prof, unsigned long long tprev, int pwave) {
     constexpr int J = TS / LPR;                 // slots per lane
     constexpr int NL = (J + 3) / 4;             // packed loc registers
@@ -618,7 +622,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     unsigned e[J];
 #pragma unroll
     for (int s = 0; s < J; ++s) e[s] = 0u;
-    if (k > 0 && lbase < m && !(abl & 2048)) {
+    if (kmax > 0 && lbase < m && !(abl & 2048)) {
         if (J >= 4) {
 #pragma unroll
             for (int s = 0; s < J; s += 4) {
@@ -635,7 +639,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     const int Ntot = PULL ? n + Amax : Amax;                                          // arrival slots to rank (wave-uniform)
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
-    if (k == 0) {
+    if (kmax == 0) {
         // no order in this (tick, cluster) bucket: the list is not read - the ranked arrivals are appended behind it in HBM
         if (Ntot > 0) {
             if (PULL) merge_pull_any<LPR, 0>(ring, tab, lds_drec, lg, 0, n, Aring, Ntot, t, tbase, nullptr);
@@ -684,7 +688,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     PROF_STAMP_NW(5);       // loc bytes
     // 5. match loop (:912-973, own-cluster scan :924-933)
     int recy = 0;
-    if (lane < k) recy = lds_rec[lane].y;
+    if (DM != 2 && lane < k) recy = lds_rec[lane].y;
     int navail = mnew, evals = 0;
     int res[NG];
 #pragma unroll
@@ -702,28 +706,36 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 #endif
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
-        if (jj * LPR >= k || (abl & 4)) break;
-        const int kk = __builtin_amdgcn_readfirstlane(min(LPR, k - jj * LPR));
+        if (jj * LPR >= kmax || (abl & 4)) break;
+        const int kk = __builtin_amdgcn_readfirstlane(min(LPR, kmax - jj * LPR));
         // lanes lg == ji of every group
         unsigned long long jmask = LPR == 16 ? 0x0001000100010001ull : (LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull);
         for (int ji = 0; ji < kk; ++ji, jmask <<= 1) {
-            const int p = rdlane(recy, jj * LPR + ji) & 0xFFFF;
-            const CT *row = lds_blk + p * (nc + 1);
+            const CT *row;
+            bool active = true;                 // (DM == 2: the row has an order at this step)
+            if (DM == 2) {
+                active = jj * LPR + ji < k;
+                row = lds_blk + pick[jj * LPR + ji];
+            } else {
+                const int p = rdlane(recy, jj * LPR + ji) & 0xFFFF;
+                row = lds_blk + p * (nc + 1);
+            }
             int best = IMAX;
 #pragma unroll
             for (int s = 0; s < J; ++s) best = min(best, (int)(((unsigned)row[byte_of(L[s >> 2], s & 3)] << 7) | (unsigned)s));
             best += lbase;
             const int rmin = grp_min<LPR>(best);
             // the winner's slot leaves the table: its loc byte becomes the dead column.  (No vehicle left: rmin names a dead
-            // slot, which is marked dead again.)
+            // slot, which is marked dead again.  A row WITHOUT an order at this step must not mark anything: its minimum names a
+            // live slot.)
             const int wrel = (rmin & 127) - lbase;
-            const unsigned bm = 0xFFu << ((wrel & 3) << 3);
+            const unsigned bm = (DM == 2 && !active) ? 0u : 0xFFu << ((wrel & 3) << 3);
             const int hi = wrel >> 2;
 #pragma unroll
             for (int i = 0; i < NL; ++i) L[i] = bfi(hi == i ? bm : 0u, ncrep, L[i]);
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(res[jj]) : "v"(res[jj]), "v"(rmin), "s"(jmask));      // res[jj] = lg == ji ? rmin : res[jj]
-            const bool hit = (rmin >> 7) != DEAD;
-            evals += navail;
+            const bool hit = active && (rmin >> 7) != DEAD;
+            evals += active ? navail : 0;
             navail -= hit ? 1 : 0;
         }
     }
@@ -769,10 +781,12 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     int2 *out_r = D.out + (size_t)r * S.Oq + (q0 - qb);
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
-        if (jj * LPR >= k) break;
+        if (jj * LPR >= kmax) break;
         const int j = jj * LPR + lg;
         const bool has = rowvalid && j < k;
-        const int4 rr = lds_rec[j < k ? j : 0];
+        int4 rr;
+        if (DM == 2) { rr = make_int4(0, 0, 0, 0); if (has) rr = S.so_rec[q0 + j]; }
+        else rr = lds_rec[j < k ? j : 0];
         const int rv = res[jj];
         const bool matched = has && (rv >> 7) != DEAD;
         const int wait = rv >> 7;
@@ -787,7 +801,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         const int vid = matched ? (int)(went >> 8) : -1;
         if (has && !(abl & 8)) out_r[j] = make_int2(vid, matched ? wait : -1);
         int slot = -1;
-        if (PULL) slot = lds_slot[j < k ? j : 0];
+        if (PULL) { if (DM == 2) { if (has) slot = S.so_slot[q0 + j]; } else slot = lds_slot[j < k ? j : 0]; }
         if (PULL && slot >= 0) {
             // :954-960 with a static arrival slot: a plain store of pull_entry(veh, arrival slot) (pull_reject: no vehicle) - every
             // processed order writes its slot, so what a destination bucket reads is always of this episode
@@ -862,10 +876,10 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     constexpr int RPW = WAVE / LPR;             // rows per wavefront
     constexpr int NTHR = DN_ROWS * LPR;
     extern __shared__ int lds_dyn[];
-    // dynamic LDS: order records int4[64] | their arrival-slot indices int[64] | candidate records int2[DN_CAND] (both PULL only)
+    // dynamic LDS: order records int4[64] (DM == 2: pickup offsets u16[16][64]) | their arrival-slot indices int[64] | candidate records int2[DN_CAND] (both PULL only)
     //              | per-row tables [16][DN_TAB] u32 | cost block (row stride n_c + 1)
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
-    int *lds_slot = reinterpret_cast<int *>(lds_rec + DN_ORDERS);
+    int *lds_slot = reinterpret_cast<int *>(lds_rec + (DM == 2 ? DN_ROWS * DN_ORDERS * 2 / 16 : DN_ORDERS));      // (DM == 2: the area holds u16 [16][64] pickup offsets)
     int2 *lds_drec = reinterpret_cast<int2 *>(lds_slot + (PULL ? DN_ORDERS : 0));
     unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
     CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * DN_TAB);
@@ -881,6 +895,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     const int rslot = chunk * DN_ROWS + wave * RPW + g;
     const int r = (DM == 1 && S.rperm != nullptr) ? S.rperm[rslot] : rslot;
     bool rowvalid = r >= 0 && r < S.R;
+    unsigned short *pick = reinterpret_cast<unsigned short *>(lds_rec) + (wave * RPW + g) * DN_ORDERS;      // DM == 2: the row's pickup rows (the lds_rec area, 2 KB)
 #ifdef VDS_PROF
     const bool prof = (g_ablate & 128) != 0;
     unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -891,7 +906,29 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     const int pwave = (int)((blockIdx.x * (NTHR / WAVE) + wave) & (PROF_WAVES - 1));
     int q0, k, now, qb = 0;
     int clo = 0, n = 0, qdb = 0;                // PULL: the bucket's candidates = d_rec[clo .. clo + n), D.arr rows clo - qdb ...
-    if (DM == 1) {
+    const int2 *drec_row = nullptr;             // DM == 2: the row's candidate records in HBM
+    if (DM == 2) {
+        // every row its own day: the row's descriptors (the lanes of a group load the same words)
+        q0 = 0; k = 0; now = S.now0 + t * S.tick_minutes;
+        if (rowvalid) {
+            const int4 dd = S.replica_desc[r];
+            rowvalid = t < dd.z;
+            now = dd.y + t * S.tick_minutes;
+            qb = dd.w;
+            if (rowvalid) {
+                const int *bo = S.bkt_off + dd.x + (size_t)t * S.C + c;
+                q0 = bo[0]; k = bo[1] - q0;
+                if (PULL) {
+                    const int4 d2 = S.replica_desc2[r];
+                    const int *df = S.d_first + d2.x;
+                    clo = df[(size_t)max(t - S.pull_W, 0) * S.C + c];
+                    n = df[(size_t)(t + 1) * S.C + c] - clo;
+                    qdb = d2.y;
+                    drec_row = S.d_rec + clo;
+                }
+            }
+        }
+    } else if (DM == 1) {
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
         const int r0 = chunk * DN_ROWS;         // (a group's first slot is never padding)
         const int rd = S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1);
@@ -922,7 +959,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     }
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
-    const bool wg_ok = k <= DN_ORDERS && n <= DN_CAND;
+    const bool wg_ok = k <= DN_ORDERS && n <= DN_CAND;          // (DM == 2: per row)
     unsigned *tab = tab_all + (wave * RPW + g) * DN_TAB;
     // 1. bucket header words; PULL: the raw entries of the bucket's candidates, parked in the row's table
     int m = 0, far = 0, A = 0;
@@ -960,7 +997,15 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     if (DN_ABL & 256) { if (m + far + A + (int)cntv == 0x7FFFFFF1) D.err[1] = 1; return; }
     // 2. stage the cluster's cost block, the bucket's order records and - PULL - the candidates' static records in LDS
     const char *blk_g = S.blk + cd.y;
-    if (k > 0) {
+    if (DM == 2) {
+        // the cost block (some row of the workgroup almost always has an order); every row's pickup rows as offsets into it
+        const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
+        int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
+        const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
+        for (int i = threadIdx.x; i < n4; i += NTHR) lds4[i] = blk4[i];
+        if (wg_ok)
+            for (int j = lg; j < k; j += LPR) pick[j] = (unsigned short)((S.so_rec[q0 + j].y & 0xFFFF) * (nc + 1));
+    } else if (k > 0) {
         const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
         const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
@@ -971,7 +1016,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
         if (!(DN_ABL & 1024)) for (int i = threadIdx.x; i < n4; i += NTHR) lds4[i] = blk4[i];
         if (mine) { lds_rec[threadIdx.x] = rec; if (PULL) lds_slot[threadIdx.x] = slot; }
     }
-    if (PULL && wg_ok)
+    if (PULL && DM != 2 && wg_ok)
         for (int i = threadIdx.x; i < n; i += NTHR) lds_drec[i] = S.d_rec[clo + i];
     PROF_STAMP(0);          // scalar loads, header words, candidate entries, staging loads: all arrived
     __syncthreads();
@@ -986,15 +1031,18 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     const int mmax = wave_max_of_groups<LPR>(m + A);
     PROF_STAMP_NW(2);       // arrival count, row classification
     if (any) {
-        const int nn = wg_ok ? n : 0;
-        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_slot, prof, tprev, pwave);
-        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_slot, prof, tprev, pwave);
-        else dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, k, qb, lds_blk, nc, lds_rec, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, lds_drec, lds_slot, prof, tprev, pwave);
+        const int nn = (wg_ok && rowvalid) ? n : 0;
+        const int kr = (DM == 2 && !rowvalid) ? 0 : k;
+        const int kmax = DM == 2 ? wave_max_of_groups<LPR>(kr) : k;
+        const int2 *drec = DM == 2 ? drec_row : lds_drec;
+        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int l0 = __ffsll((long long)rest) - 1;
-        dense_bucket_slow<CT>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc, k > 0 ? lds_blk : (const CT *)nullptr);
+        dense_bucket_slow<CT>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc, (DM == 2 || k > 0) ? lds_blk : (const CT *)nullptr);
     }
 }
 
@@ -1012,10 +1060,10 @@ static void emit_dense(const Emit &e, void (*k)(DenseArgs, int), dim3 grid, dim3
 
 template <int LPR, bool PULL>
 static void emit_dense_lpr(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
-    const int dm = S.n_days <= 1 ? 0 : 1;
+    const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 block(DN_ROWS * LPR);
-    if (S.blk8s) emit_dense(e, dm ? k_tick_dense<true, 1, LPR, PULL> : k_tick_dense<true, 0, LPR, PULL>, grid, block, lds, P, t);
-    else emit_dense(e, dm ? k_tick_dense<false, 1, LPR, PULL> : k_tick_dense<false, 0, LPR, PULL>, grid, block, lds, P, t);
+    if (S.blk8s) emit_dense(e, dm == 2 ? k_tick_dense<true, 2, LPR, PULL> : (dm ? k_tick_dense<true, 1, LPR, PULL> : k_tick_dense<true, 0, LPR, PULL>), grid, block, lds, P, t);
+    else emit_dense(e, dm == 2 ? k_tick_dense<false, 2, LPR, PULL> : (dm ? k_tick_dense<false, 1, LPR, PULL> : k_tick_dense<false, 0, LPR, PULL>), grid, block, lds, P, t);
 }
 
 // S.self_dev / S.state_dev: device-resident copies of S and D (kept current by vds_api.hip: dev_copy_sync) for the slow path
@@ -1034,14 +1082,15 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const int rchunks = (slots + DN_ROWS - 1) / DN_ROWS;
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
-    const size_t lds = DN_ORDERS * 16 + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * DN_TAB * 4 + bb;
+    // (one order day per replica: the order-record area holds the rows' pickup offsets instead, u16 [16][64] = 2 KB)
+    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * DN_TAB * 4 + bb;
+    // (4 lanes per replica - 16 replicas per wavefront, 32 + 8 table registers - was built and measured in round 4: 143 us per tick at
+    // configs[1] against 53 / 59 us with 8 / 16 lanes: not instantiated any more)
     if (S.pull) {
         if (S.dense_lpr == 8) emit_dense_lpr<8, true>(e, S, P, t, grid, lds);
-        else if (S.dense_lpr == 4) emit_dense_lpr<4, true>(e, S, P, t, grid, lds);
         else emit_dense_lpr<16, true>(e, S, P, t, grid, lds);
     } else {
         if (S.dense_lpr == 8) emit_dense_lpr<8, false>(e, S, P, t, grid, lds);
-        else if (S.dense_lpr == 4) emit_dense_lpr<4, false>(e, S, P, t, grid, lds);
         else emit_dense_lpr<16, false>(e, S, P, t, grid, lds);
     }
 }

@@ -31,7 +31,12 @@ def allreduce_counters(tensor, group=None):
     collective is issued even for a world of one, so a single-rank launch exercises the same RCCL path)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+        if tensor.is_cuda and dist.get_backend(group) != "nccl":
+            host = tensor.cpu()                  # gloo (tests: two ranks on one GPU) reduces host memory
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            tensor.copy_(host)
+        else:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
         global ALLREDUCE_CALLS
         ALLREDUCE_CALLS += 1
     return tensor
@@ -45,6 +50,8 @@ def max_over_ranks(value: float, device=None) -> float:
         return value
     if device is None and dist.get_backend() == "nccl":
         device = "cuda"               # RCCL reduces device tensors only
+    if dist.get_backend() != "nccl":
+        device = None
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

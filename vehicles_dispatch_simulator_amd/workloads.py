@@ -159,6 +159,8 @@ def profile_side_data(root: str, workload: str, replicas: int, kernel: str) -> d
                     if key is None:
                         out["hbm_bytes_per_launch"] = e.get("hbm_bytes_per_launch")
                         out["traffic_build"] = e.get("build")
+                        out["traffic_basis"] = e.get("read_bytes_basis", "FETCH_SIZE x 2 (upper bound)") + " + WRITE_SIZE"
+                        out["traffic_source"] = e.get("source")
                     else:
                         out[key] = e
         except Exception:
