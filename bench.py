@@ -387,7 +387,9 @@ def main():
         # per slot (one submission), (c) the same policy issued eagerly (a dozen torch launches per slot: host-bound)
         obs_static = env.obs_torch()
         fixed_actions = torch.stack([minus1, zeros_k, some_node_of[:K].repeat(R, 1)], dim=2).contiguous()
-        fixed_actions[:, 0, 0] = torch.arange(R, device="cuda", dtype=torch.int32) % env.C      # one move per city and slot (skipped where the list is empty: idle_pos 0)
+        ar = torch.arange(R, device="cuda", dtype=torch.int32)
+        fixed_actions[:, 0, 0] = ar % env.C                   # one move per city and slot (skipped where the list is empty: idle_pos 0) ...
+        fixed_actions[:, 0, 2] = some_node_of[((ar + 97) % env.C).long()]      # ... to another cluster of that city
         actions_static = torch.zeros((R, K, 3), dtype=torch.int32, device="cuda")
         pol_graph, graph_error = None, None
         try:
@@ -410,14 +412,14 @@ def main():
             for _ in range(T):
                 env.step()
                 if kind == "fixed":
-                    env.obs_torch()
+                    env.obs_torch(inflight=False)
                     env.apply_dispatch_torch(fixed_actions)
                 elif kind == "graph":
-                    env.obs_torch()                         # k_pack_obs into the static block
+                    env.obs_torch(inflight=False)           # k_pack_obs into the static block (the policy reads idle, supply, demand)
                     pol_graph.replay()
                     env.apply_dispatch_torch(actions_static)
                 elif kind == "eager":
-                    env.apply_dispatch_torch(policy(env.obs_torch()))
+                    env.apply_dispatch_torch(policy(env.obs_torch(inflight=False)))
                 env.advance()
 
         res = {}

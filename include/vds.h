@@ -74,8 +74,9 @@ typedef struct vds_config {
     int32_t force_generic;            /* 0 = fastest.  Without neighbour search that is k_tick_dense on the dense state
                                          layout (4-byte idle entries, 8-byte arrival entries) when V < 2^24, every cluster has
                                          <= 255 nodes, costs fit the packed keys (0 <= cost < 2^23, none above the pickup
-                                         window), ring_ticks <= 32, fewer than 2^25 orders per day and every aligned group of
-                                         16 replicas replays one day; otherwise k_tick_rows on the wide layout.  With
+                                         window), ring_ticks <= 32 and fewer than 2^25 orders per day - one shared order day,
+                                         one day per group of 16 replicas or one day per replica alike; otherwise k_tick_rows
+                                         on the wide layout.  With
                                          neighbour search: the hybrid tick (k_tick_rows in stamp mode + k_dfs_walk).
                                          Testing / fallbacks: 1 = generic one-wavefront-per-bucket kernel (k_tick) / serial
                                          neighbour search (k_match_dfs); 3 = neighbour search by lower-bound rounds
@@ -93,7 +94,12 @@ int vds_destroy(vds_handle *h);
 /* Message of the last failing call on h (h == NULL: last vds_create failure). */
 const char *vds_last_error(const vds_handle *h);
 
-/* Issue all device work of h on `hip_stream` (a hipStream_t; NULL = the library's own stream). */
+/* Issue all device work of h on `hip_stream` (a hipStream_t; NULL = the library's own stream - a blocking stream: it and the
+ * legacy default stream wait for each other; VDS_STREAM_LEGACY_DEFAULT = the legacy default stream itself, hipStream_t 0, which
+ * is PyTorch's default stream on ROCm: engine launches and the caller's kernels then share one stream.  A day replayed by
+ * vds_run on the legacy default stream is not captured as a single-chain graph - stream capture refuses that stream - it is
+ * issued launch by launch; replica groups, built node by node, run there as everywhere). */
+#define VDS_STREAM_LEGACY_DEFAULT ((void *)(intptr_t)-1)
 int vds_set_stream(vds_handle *h, void *hip_stream);
 
 /* Static tables CreateAllInstantiate (:303-354) leaves behind: self.Map (:305), the
@@ -196,13 +202,17 @@ int vds_run(vds_handle *h, int32_t n_ticks);
 
 /* Scheduling of vds_run (no reference counterpart, results do not depend on it): the replicas run as `groups` independent
  * groups (replicas never interact inside :1048-1091 without hooks) - in neighbour-search mode (hybrid tick) the stamp-mode
- * k_tick_rows of one group under the k_dfs_walk of the others, without neighbour search two chains of half-size k_tick_rows
- * launches whose kernel boundaries overlap.  Defaults: plain tick 2 groups from 256 replicas on, hybrid tick 2 from 512 and
+ * k_tick_rows of one group under the k_dfs_walk of the others, without neighbour search two chains of half-size k_tick_dense
+ * (k_tick_rows) launches whose kernel boundaries overlap.  Defaults: plain tick 2 groups from 256 replicas on, hybrid tick 2 from 512 and
  * 3 from 1024 replicas on.  stagger 2: the groups' k_tick_rows launches are
  * serialised round-robin by extra graph edges (keeps the groups out of phase), 1: first tick only, 0: free-running.
  * groups <= 0 / stagger < 0: library default (environment VDS_RUN_GROUPS / VDS_RUN_STAGGER).  1 <= groups <= 16.
  * The groups are parallel branches of the hipGraph vds_run replays (runs of >= 8 slots); eager runs (VDS_RUN_GRAPH=0, short
- * runs, profiling) keep one launch pair per tick over all replicas. */
+ * runs, profiling) keep one launch pair per tick over all replicas.  An executable graph with parallel branches is never
+ * destroyed while the process lives (its destruction races with the HIP runtime's completion handler): a handle that lets go of
+ * one parks it in a process-wide pool, the next handle that needs that shape re-targets it in place (hipGraphExecUpdate).  No
+ * vds_* call synchronises the device or sleeps; what stays allocated is host memory of one graph per shape and per handle that
+ * held one at the same time. */
 int vds_set_run_groups(vds_handle *h, int32_t groups, int32_t stagger);
 /* The group count vds_run uses as the handle stands (1: one launch (pair) per tick over all replicas). */
 int vds_get_run_groups(vds_handle *h);
@@ -227,6 +237,11 @@ int vds_read_obs(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *s
 /* Device-resident copy of the same observations for zero-copy consumers (RL agents): packs
  * them into int32 [5][R][C] (order as above) and returns the device pointer. */
 int vds_obs_device(vds_handle *h, void **dev_ptr);
+/* The same for a subset of the planes: bit k of `planes` = plane k (1 idle_pre, 2 idle_now, 4 supply = SupplyExpect :880-891,
+ * 8 cl_orders, 16 inflight); planes that are not asked for keep whatever the block held.  Without `inflight` (a count over the
+ * cluster's whole VehiclesArrivetime table, :1011) the pass reads only what the next slot's SupplyExpect needs - what a per-slot
+ * hook (:1057-1087) that does not look at len(VehiclesArrivetime) should call. */
+int vds_obs_device_planes(vds_handle *h, int32_t planes, void **dev_ptr);
 
 /* counters: int64 [R * VDS_NUM_COUNTERS]. */
 int vds_read_counters(vds_handle *h, int64_t *out);

@@ -163,6 +163,36 @@ def test_handles_on_their_own_streams_advance_independently():
         e.close()
 
 
+def test_legacy_default_stream_can_be_bound_explicitly():
+    """vds_set_stream(VDS_STREAM_LEGACY_DEFAULT): engine launches on hipStream_t 0 itself - PyTorch's default stream on ROCm - so a
+    policy's tensor operations and the engine's kernels are ordered by one stream.  vds_run (stream capture refuses that stream:
+    the day is issued launch by launch), hooked steps with a torch-side read in between, and the results equal the oracle's."""
+    import torch
+    g = load_golden("tiny_kmeans")
+    R, V, N = 5, int(g["V"]), int(g["N"])
+    init = np.stack([g["veh_node"]] + [synth.init_vehicle_nodes(random.Random(90 + r), N, V, g["node2cluster"] >= 0) for r in range(1, R)])
+    env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=V, stream="legacy")
+    env.load_orders(g["o_release_min"], g["o_pickup"], g["o_delivery"])
+    env.reset(init)
+    seen = []
+    for t in range(env.T // 2):
+        env.step()
+        seen.append(env.obs_torch(inflight=False)[1].sum())      # a torch op on the default stream, right behind the tick: no sync in between
+        env.advance()
+    env.run(env.T - env.T // 2)
+    env.sync()
+    got = env.orders()
+    np.testing.assert_array_equal(got["vehicle"][0], g["o_vehicle"])
+    np.testing.assert_array_equal(got["wait"][0], g["o_wait"])
+    assert int(torch.stack(seen).sum().item()) > 0
+    env.set_stream(None)                                         # back to the library's own stream: another day, same results
+    env.reset_again(); env.run(env.T); env.sync()
+    again = env.orders()
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(again[k], got[k])
+    env.close()
+
+
 def test_another_day_on_the_same_handle():
     """vds_load_orders again (Reload, simulator.py:130-212): the day changes, the static tables and - while they
     still fit - the state tables stay; results equal those of a fresh handle / the oracle, in both directions."""

@@ -298,6 +298,21 @@ def test_zero_copy_torch_observations_match_host_read():
     assert dev.shape == (5, 4, int(g["C"])) and dev.dtype == torch.int32 and dev.is_cuda
     for i, k in enumerate(("idle_pre", "idle_now", "supply", "cl_orders", "inflight")):
         np.testing.assert_array_equal(dev[i].cpu().numpy(), host[k])
+    # a subset of the planes (vds_obs_device_planes): the other planes keep what they held, the wanted ones are exact per slot
+    for t in range(10):
+        env.step()
+        host = env.obs()                            # (all five planes)
+        stale = env.obs_torch().clone()
+        stale[4] = -7
+        env.obs_torch()[4] = -7
+        part = env.obs_torch(inflight=False)
+        torch.cuda.synchronize()
+        for i, k in enumerate(("idle_pre", "idle_now", "supply", "cl_orders")):
+            np.testing.assert_array_equal(part[i].cpu().numpy(), host[k], err_msg="%d %s" % (t, k))
+        assert (part[4] == -7).all()
+        env.advance()
+    with pytest.raises(Exception, match="planes"):
+        env.obs_device_ptr(0)
     # per-replica counters, zero copy (device order: orders, rejects, wait, matched value, evals, arrivals, dispatch, cost)
     cn = env.counters()
     ct = env.counters_torch()

@@ -31,7 +31,7 @@ int dfs_walk_pool(const Static &);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
                      const int *, const int *, const int *, const int *, hipStream_t);
 void launch_dispatch_dense(const Static &, const State &, int, int, const int *, int, hipStream_t);
-void launch_pack_obs(const Static &, const State &, int, int, int *, hipStream_t);
+void launch_pack_obs(const Static &, const State &, int, int, int, int *, hipStream_t);
 void launch_reduce_counters(const Static &, const State &, long long *, long long *, hipStream_t);
 void launch_selftest_dpp(const int *, int *, int *, int *, int *, int, hipStream_t);
 void set_ablate_tick(int, hipStream_t);
@@ -40,6 +40,7 @@ void set_ablate_dfs(int, hipStream_t);
 void read_prof_dfs(unsigned long long *, hipStream_t);
 void set_ablate_dense(int, hipStream_t);
 void read_prof_dense(unsigned long long *, hipStream_t);
+void read_span_dense(unsigned long long *, int, hipStream_t);
 void emit_tick_dense(const Emit &, const Static &, const State &, int, int, int);
 }  // namespace vds
 
@@ -166,11 +167,13 @@ static const size_t GUARD_FRONT = 0, GUARD_BACK = 0;
 static const bool GUARDED = false;
 #endif
 struct GuardRec { void *base; size_t bytes; };
-static std::map<void *, GuardRec> g_guards;      // user pointer -> allocation (guarded build only)
+static std::map<void *, GuardRec> g_guards;      // user pointer -> allocation (guarded build only; shared by all handles and threads:
+static std::mutex g_guards_mu;                   //  every access under this lock)
 
 static void dev_free(void *p) {
     if (!p) return;
     if (GUARDED) {
+        std::lock_guard<std::mutex> lk(g_guards_mu);
         auto it = g_guards.find(p);
         if (it != g_guards.end()) { (void)hipFree(it->second.base); g_guards.erase(it); return; }
     }
@@ -188,6 +191,7 @@ static int dev_alloc(vds_handle *h, T **p, size_t n) {
     if (GUARDED) {
         (void)hipMemset(base, 0xA5, GUARD_FRONT);
         (void)hipMemset(base + GUARD_FRONT + bytes, 0xA5, GUARD_BACK);
+        std::lock_guard<std::mutex> lk(g_guards_mu);
         g_guards[(void *)(base + GUARD_FRONT)] = GuardRec{(void *)base, bytes};
     }
     *p = reinterpret_cast<T *>(base + GUARD_FRONT);
@@ -467,7 +471,11 @@ int vds_set_stream(vds_handle *h, void *hip_stream) {
     if (h) drop_run_graph(h);
     if (!h) return VDS_EINVAL;
     (void)hipStreamSynchronize(h->stream);
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    // VDS_STREAM_LEGACY_DEFAULT: the legacy default stream itself (hipStream_t 0) - what PyTorch's default stream is on ROCm, so
+    // that engine launches and a policy's kernels are ordered by being on ONE stream, not by the implicit synchronisation
+    // between the null stream and the library's blocking stream
+    if (hip_stream == VDS_STREAM_LEGACY_DEFAULT) h->stream = nullptr;
+    else h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return VDS_OK;
 }
 
@@ -789,13 +797,13 @@ static int alloc_state(vds_handle *h, int O) {
     if ((rc = dev_alloc(h, &D.ring_cnt, (size_t)H * B))) return rc;
     if ((rc = dev_alloc(h, &D.fl, B * far_cap))) return rc;
     if ((rc = dev_alloc(h, &D.inbox, 2 * B * far_cap))) return rc;
-    if ((rc = dev_alloc(h, &D.err, 4))) return rc;
+    if ((rc = dev_alloc(h, &D.err, 16))) return rc;      // [0] sticky error bits, [2] buckets off the fast path, [4..15] instrumented build: why
     if ((rc = dev_alloc(h, &D.work, 2 + 2 * B))) return rc;
     if ((rc = dev_alloc(h, &h->d_veh_node, (size_t)R * V))) return rc;
     if ((rc = dev_alloc(h, &h->d_obs, 5 * (size_t)R * C))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt_per, (size_t)R * CNT_WORDS))) return rc;
     if ((rc = dev_alloc(h, &h->d_cnt_tot, CNT_WORDS))) return rc;
-    HIPCHK(h, hipMemset(D.err, 0, 4 * sizeof(int)));
+    HIPCHK(h, hipMemset(D.err, 0, 16 * sizeof(int)));
     HIPCHK(h, hipMemset(D.work, 0, 2 * sizeof(int)));
     return VDS_OK;
 }
@@ -1025,9 +1033,14 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
         if (env_int("VDS_DENSE", 1) == 0) S.dense = 0;
-        const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", DENSE_LPR_DEFAULT);
+        // lanes per replica: 8 with one shared day (configs[1], one box: 52.8 vs 59.0 us per tick), 16 with order days per replica
+        // (other days fill other clusters: more rows beyond the 128-entry tables, and every such row holds up the 7 / 3 other rows
+        // of its wavefront - 16 days 18.6 vs 12.2 ms per day, one day per replica 26.8 vs 21.8: profiles/r04/probe_days2.py)
+        const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", n_days > 1 ? 16 : DENSE_LPR_DEFAULT);
         S.dense_lpr = (lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
-        S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, 128) : 128;
+        // entries of a bucket the fast path holds: 128; 256 with order days per replica at 16 lanes per replica and byte costs (emit_tick_dense)
+        const int tab_max = (n_days > 1 && S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0) ? 256 : 128;
+        S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, tab_max) : tab_max;
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
         S.dense_force_slow = h->dbg_dense_slow & 1;
         S.pull = (S.dense && S.V < (1 << 24) - 1 && !(h->dbg_dense_slow & 2) && env_int("VDS_DENSE_PULL", 1) != 0) ? 1 : 0;
@@ -1185,7 +1198,7 @@ int vds_num_ticks(const vds_handle *h, int32_t *T) {
 
 static int reset_device(vds_handle *h) {
     const Static &S = h->S;
-    HIPCHK(h, hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->D.err, 0, 16 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
     // D.out needs no clearing: every processed order's slot is written (match or reject) before
@@ -1625,14 +1638,17 @@ static int apply_dispatch_impl(vds_handle *h, int32_t n, const int32_t *replica,
     return VDS_OK;
 }
 
-int vds_obs_device(vds_handle *h, void **dev_ptr) {
+int vds_obs_device_planes(vds_handle *h, int32_t planes, void **dev_ptr) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_obs_device: call vds_reset first");
+    if (planes <= 0 || planes > 31) return fail(h, VDS_EINVAL, "vds_obs_device_planes: planes is a mask of the five planes (1 .. 31)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    launch_pack_obs(h->S, h->D, h->last_stepped < 0 ? 0 : h->last_stepped, h->last_stepped >= 0 ? 1 : 0, h->d_obs, h->stream);
+    launch_pack_obs(h->S, h->D, h->last_stepped < 0 ? 0 : h->last_stepped, h->last_stepped >= 0 ? 1 : 0, planes, h->d_obs, h->stream);
     HIPCHK(h, hipGetLastError());
     if (dev_ptr) *dev_ptr = h->d_obs;
     return VDS_OK;
 }
+
+int vds_obs_device(vds_handle *h, void **dev_ptr) { return vds_obs_device_planes(h, 31, dev_ptr); }
 
 static int read_obs_impl(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {
     int rc = vds_obs_device(h, nullptr);
@@ -1940,14 +1956,16 @@ int vds_debug_check_guards(vds_handle *h) {
     if (!GUARDED) return 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // (returns the number of damaged tables, >= 0, or a negative VDS_E* code: the two cannot be confused)
     int bad = 0;
     std::vector<unsigned char> buf(std::max<size_t>(GUARD_FRONT, GUARD_BACK));
+    std::lock_guard<std::mutex> lk(g_guards_mu);
     for (const auto &kv : g_guards) {
         const char *base = (const char *)kv.second.base;
         bool ok = true;
-        if (hipMemcpy(buf.data(), base, GUARD_FRONT, hipMemcpyDeviceToHost) != hipSuccess) return VDS_EHIP;
+        if (hipMemcpy(buf.data(), base, GUARD_FRONT, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, VDS_EHIP, "vds_debug_check_guards: reading a guard zone failed");
         for (size_t i = 0; i < GUARD_FRONT && ok; ++i) ok = buf[i] == 0xA5;
-        if (hipMemcpy(buf.data(), base + GUARD_FRONT + kv.second.bytes, GUARD_BACK, hipMemcpyDeviceToHost) != hipSuccess) return VDS_EHIP;
+        if (hipMemcpy(buf.data(), base + GUARD_FRONT + kv.second.bytes, GUARD_BACK, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, VDS_EHIP, "vds_debug_check_guards: reading a guard zone failed");
         for (size_t i = 0; i < GUARD_BACK && ok; ++i) ok = buf[i] == 0xA5;
         if (!ok) { ++bad; fprintf(stderr, "libvds guard: table of %zu bytes at %p was written out of bounds\n", kv.second.bytes, (void *)(base + GUARD_FRONT)); }
     }
@@ -1958,9 +1976,28 @@ int vds_debug_check_guards(vds_handle *h) {
 // check itself has something to find.  Other builds: VDS_EINVAL.
 int vds_debug_poke_guard(vds_handle *h) {
     if (!h || !GUARDED || !h->D.hdr) return VDS_EINVAL;
+    std::lock_guard<std::mutex> lk(g_guards_mu);
     auto it = g_guards.find((void *)h->D.hdr);
     if (it == g_guards.end()) return VDS_EINVAL;
     HIPCHK(h, hipMemset((char *)it->second.base + GUARD_FRONT + it->second.bytes + 5, 0, 1));
+    return VDS_OK;
+}
+
+// instrumented build: launch spans of k_tick_dense ([2 chains][256 slots]{first wavefront in, last out} on the 100 MHz s_memtime
+// clock; flag 1048576 of vds_debug_ablate switches the stamps on); out may be null (reset only)
+int vds_debug_read_span(vds_handle *h, uint64_t *out1024, int32_t reset) {
+    if (!h) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    read_span_dense((unsigned long long *)out1024, reset, h->stream);
+    return VDS_OK;
+}
+
+// the 16 words of the device error block ([4..15]: slow-path reasons of the instrumented build, vds_tick_dense.hip)
+int vds_debug_read_err(vds_handle *h, int32_t *out16) {
+    if (!h || !h->have_static || !out16) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out16, h->D.err, 16 * sizeof(int), hipMemcpyDeviceToHost));
     return VDS_OK;
 }
 

@@ -1002,7 +1002,9 @@ __global__ __launch_bounds__(64) void k_dispatch(Static S, State D, int t, int n
 // Read-side helpers.
 // obs [5][R][C]: idle_pre, idle_now, supply, cl_orders, inflight.  `t` = tick last stepped.
 // stepped: a slot has been stepped since the reset (t = the last one); otherwise t = 0 and nothing has been processed yet
-__global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int stepped, int *obs) {
+// planes: bit k = plane k is wanted (planes that are not keep what the block held).  Without `inflight` (bit 4) the 32 ring counters
+// of every bucket are not read and the scan of the static arrival slots stops at the orders that can arrive by the next slot.
+__global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int stepped, int planes, int *obs) {
     // state is cluster-major ([C][R]), the observation block replica-major ([5][R][C]): 16 x 16 tiles through LDS so
     // that both the reads (16 consecutive replicas) and the writes (16 consecutive clusters) are 64-byte runs
     __shared__ int tile[5][16][17];
@@ -1016,8 +1018,10 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
             const size_t b = (size_t)c * S.R + r;
             const int *h = D.hdr + b * HDR_WORDS;
             const int tr = S.n_days <= 1 ? t : min(t, day_view(S, r).T - 1);      // a replica whose day is over stopped at its own last tick
+            const bool want_infl = (planes & 16) != 0;
             int infl = h[HDR_FL] + h[HDR_INBOX0 + ((tr + 1) & 1)];
-            for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
+            if (want_infl)
+                for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
             // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
             int supply = (int)((unsigned)D.ring_cnt[(size_t)((tr + 1) & (S.H - 1)) * RC + b] >> 16);
             if (S.pull && stepped) {
@@ -1026,7 +1030,8 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                 const int4 d2 = S.n_days <= 1 ? make_int4(0, 0, 0x7FFFFFFF, 0) : S.replica_desc2[r];
                 const int *df = S.d_first + d2.x;
                 const int TA = S.n_days <= 1 ? S.T + S.H : d2.z;
-                const int lo = df[(size_t)max(tr - S.pull_W + 1, 0) * S.C + c], hi = df[(size_t)min(tr + S.pull_hmax + 1, TA) * S.C + c];
+                // (arrival slot a0 + delta, delta in [0, W]: due by the next slot means a0 in [tr + 1 - W, tr + 1]; on its way: a0 up to tr + hmax)
+                const int lo = df[(size_t)max(tr - S.pull_W + 1, 0) * S.C + c], hi = df[(size_t)min(tr + (want_infl ? S.pull_hmax + 1 : 2), TA) * S.C + c];
                 // (eight entries in flight per thread: the loop is a chain of dependent-free loads, 60 - 100 per bucket at configs[1])
                 for (int i0 = lo; i0 < hi; i0 += 8) {
                     int ry[8];
@@ -1062,7 +1067,8 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
         if (r < S.R && c < S.C && ext >= 0) {
             const size_t i = (size_t)ext * S.C + c;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) obs[k * RCX + i] = tile[k][tx][ty];
+            for (int k = 0; k < 5; ++k)
+                if (planes & (1 << k)) obs[k * RCX + i] = tile[k][tx][ty];
         }
     }
 }
@@ -1298,8 +1304,8 @@ void launch_dispatch_dense(const Static &S, const State &D, int t, int K, const 
     hipLaunchKernelGGL(k_dispatch_dense, dim3(S.R), dim3(64), 0, st, S, D, t, K, actions, seq_base);
 }
 
-void launch_pack_obs(const Static &S, const State &D, int t, int stepped, int *obs, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_obs, dim3((S.R + 15) / 16, (S.C + 15) / 16), dim3(256), 0, st, S, D, t, stepped, obs);
+void launch_pack_obs(const Static &S, const State &D, int t, int stepped, int planes, int *obs, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_obs, dim3((S.R + 15) / 16, (S.C + 15) / 16), dim3(256), 0, st, S, D, t, stepped, planes, obs);
 }
 
 void launch_reduce_counters(const Static &S, const State &D, long long *per, long long *tot, hipStream_t st) {

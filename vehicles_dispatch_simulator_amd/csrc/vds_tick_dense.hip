@@ -28,6 +28,25 @@ namespace vds {
 
 VDS_PROF_ACCESSORS(dense)
 
+// Instrumented build: when every launch of the tick starts and ends - first wavefront in, last wavefront out, on the 100 MHz
+// constant clock s_memtime reads on every CU - per slot and per replica group (chain) of vds_run.  What a kernel trace cannot show
+// for the two concurrent chains of a grouped day (tracing serialises the queues): profiles/r04/inflight.py.
+#define SPAN_TICKS 256
+#ifdef VDS_PROF
+static __device__ unsigned long long g_span[2 * SPAN_TICKS * 2];      // [chain][slot]{first start, last end}
+void read_span_dense(unsigned long long *out, int reset, hipStream_t st) {
+    (void)hipStreamSynchronize(st);
+    static unsigned long long host[2 * SPAN_TICKS * 2];
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(host));
+    if (reset) {
+        for (int i = 0; i < 2 * SPAN_TICKS; ++i) { host[2 * i] = ~0ull; host[2 * i + 1] = 0ull; }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span), host, sizeof(host));
+    }
+}
+#else
+void read_span_dense(unsigned long long *, int, hipStream_t) { }
+#endif
+
 #define DN_ROWS 16           // replicas per workgroup (= the granularity of replica groups / day groups everywhere else)
 #define DN_TAB 128           // idle entries per bucket the fast path holds
 #define DN_KEYS 64           // arrivals per bucket per tick the fast path ranks
@@ -505,37 +524,40 @@ __device__ __forceinline__ void merge_arrivals_any(const uint2 *ring, unsigned *
     else merge_arrivals<LPR, DN_KEYS / LPR, J>(ring, tab, lg, m, A, Amax, tbase, e);
 }
 
-// The same with static arrival slots (PULL): arrival slot a of a lane is candidate idx = a * LPR + lg of the bucket's n candidates
-// (raw D.arr entries parked in tab[0 .. n) by the prologue, their static records in lds_drec) or, behind them, entry idx - n of
-// the ring slot (dispatched vehicles).  A candidate arrives when its entry's low byte is slot t's.
-template <int LPR, int NA, int J>
-__device__ __forceinline__ void merge_pull(const uint2 *ring, unsigned *tab, const int2 *lds_drec, int lg, int m, int n, int Aring, int Ntot, int t,
-                                           unsigned tbase, const unsigned *e) {
-    unsigned ent[NA], key[NA];
-    int rank[NA];
+// The same with static arrival slots (PULL).  Only about a quarter of a slot's candidate orders arrive NOW (their arrival window
+// is W + 1 slots wide), so the prologue of the kernel - which loads the candidates' raw D.arr entries anyway - parks only the
+// arriving ones in the row's table, packed: raw entry in tab[i], candidate index in tab[DN_TH + i], i < Ac (DN_TH = half the
+// table; more arrivals than that: slow path).  Here lane lg takes arrivals lg, lg + LPR, ...: the static record of its candidates
+// (key, destination node byte), behind them the ring's entries (dispatched vehicles), keys into tab[0 .. A), padded "absent" up to
+// the wavefront's largest A; every key is ranked among the A keys (dict insertion order), then the table takes the list chunks
+// and the arrivals behind position m.
+#define DN_TH (DN_TAB / 2)
+template <int LPR, int NAP, int J>
+__device__ __forceinline__ void pull_rank_place(const uint2 *ring, unsigned *tab, const int2 *drec, int lg, int m, int Ac, int A, int Amax, unsigned tbase, const unsigned *e) {
+    unsigned key[NAP], ent[NAP];
+    int rank[NAP];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+    for (int a = 0; a < NAP; ++a) {
         const int idx = a * LPR + lg;
-        ent[a] = 0u; key[a] = 0xFFFFFFFFu; rank[a] = 0;
-        if (idx < n) {
+        key[a] = 0xFFFFFFFFu; ent[a] = 0u; rank[a] = 0;
+        if (idx < Ac) {
             const unsigned raw = tab[idx];
-            if ((raw & 0xFFu) == ((unsigned)t & 0xFFu)) {
-                const int2 rec = lds_drec[idx];
-                key[a] = (unsigned)rec.x - tbase; ent[a] = (raw & 0xFFFFFF00u) | ((unsigned)(rec.y >> 16) & 0xFFu);
-            }
-        } else if (idx - n < Aring) {
-            const uint2 r8 = ring[idx - n];
+            const int2 rec = drec[tab[DN_TH + idx]];
+            key[a] = (unsigned)rec.x - tbase; ent[a] = (raw & 0xFFFFFF00u) | ((unsigned)(rec.y >> 16) & 0xFFu);
+        } else if (idx < A) {
+            const uint2 r8 = ring[idx - Ac];
             key[a] = r8.y - tbase; ent[a] = r8.x;
         }
     }
-    wave_order();          // every raw entry has been read: the table takes the keys
-#pragma unroll
-    for (int a = 0; a < NA; ++a) tab[a * LPR + lg] = key[a];
     wave_order();
-    for (int i = 0; i < Ntot; ++i) {
+#pragma unroll
+    for (int a = 0; a < NAP; ++a)
+        if (a * LPR + lg < Amax) tab[a * LPR + lg] = key[a];          // (slots in [A, Amax): "absent")
+    wave_order();
+    for (int i = 0; i < Amax; ++i) {
         const unsigned kk = tab[i];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) rank[a] += kk < key[a] ? 1 : 0;
+        for (int a = 0; a < NAP; ++a) rank[a] += kk < key[a] ? 1 : 0;
     }
     wave_order();          // every key has been read: the table now takes the list
     if (J > 0) {
@@ -551,19 +573,16 @@ __device__ __forceinline__ void merge_pull(const uint2 *ring, unsigned *tab, con
         wave_order();
     }
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
-        if (key[a] != 0xFFFFFFFFu) tab[m + rank[a]] = ent[a];
+    for (int a = 0; a < NAP; ++a)
+        if (a * LPR + lg < A) tab[m + rank[a]] = ent[a];
     wave_order();
 }
 template <int LPR, int J>
-__device__ __forceinline__ void merge_pull_any(const uint2 *ring, unsigned *tab, const int2 *lds_drec, int lg, int m, int n, int Aring, int Ntot, int t,
-                                               unsigned tbase, const unsigned *e) {
-    if (Ntot <= LPR) merge_pull<LPR, 1, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
-    else if (Ntot <= 2 * LPR) merge_pull<LPR, 2, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
-    else if (Ntot <= 4 * LPR) merge_pull<LPR, 4, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
-    else if (Ntot <= 8 * LPR || LPR == 16) merge_pull<LPR, 8, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
-    else if (Ntot <= 16 * LPR || LPR == 8) merge_pull<LPR, (LPR <= 8 ? 16 : 8), J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
-    else merge_pull<LPR, (LPR == 4 ? 32 : 8), J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+__device__ __forceinline__ void pull_rank_place_any(const uint2 *ring, unsigned *tab, const int2 *drec, int lg, int m, int Ac, int A, int Amax, unsigned tbase, const unsigned *e) {
+    if (Amax <= LPR) pull_rank_place<LPR, 1, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
+    else if (Amax <= 2 * LPR) pull_rank_place<LPR, 2, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
+    else if (Amax <= 4 * LPR || LPR == 16) pull_rank_place<LPR, 4, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
+    else pull_rank_place<LPR, 8, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
 }
 
 // counters of one bucket: lanes 0..7 of a 16- / 8-lane group hold the preloaded words (cntv), 4-lane groups add in place
@@ -591,7 +610,7 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 //   only, 64 posts: entry store only, 256 nothing after the header loads, 512 empty kernel, 1024 no cost-block staging,
 //   2048 no list / arrival loads and no merge; state-preserving: 4096 every post twice (second into a shadow table), 8192 the
 //   atomic twice, 16384 the entry store twice, 32768 no counter stores, 65536 the arrival-slot store twice, 131072 no counter
-//   loads, 262144 the match loop twice
+//   loads, 262144 the match loop twice, 1048576 launch spans (g_span: first wavefront in / last out per slot and chain)
 #ifdef VDS_PROF
 #define DN_ABL (g_ablate)
 #else
@@ -611,6 +630,9 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     constexpr int NL = (J + 3) / 4;             // packed loc registers
     constexpr int NG = DN_ORDERS / LPR;         // result registers (orders jj * LPR + lg)
     constexpr int DEAD = sizeof(CT) == 1 ? 0xFF : DENSE_DEAD_COST;
+    constexpr int PB = TS > 128 ? 8 : 7;        // bits of the list position inside a candidate key (cost << PB | position); 256-entry tables: byte costs only
+    constexpr int PM = (1 << PB) - 1;
+    static_assert(TS <= 128 || sizeof(CT) == 1, "256-entry tables need byte costs");
     const int lane = lane_id();
     const int lg = lane & (LPR - 1);
     const int gbase = lane & ~(LPR - 1);
@@ -636,13 +658,17 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     }
     PROF_STAMP(3);          // idle list chunk loaded
     const int Amax = (abl & 2048) ? 0 : wave_max_of_groups<LPR>(PULL ? Aring : A);       // (ring entries)
-    const int Ntot = PULL ? n + Amax : Amax;                                          // arrival slots to rank (wave-uniform)
+    // arrivals to rank: the most of a row of this wavefront (wave-uniform; PULL: arriving candidates + ring entries)
+    const int Ntot = PULL ? ((abl & 2048) ? 0 : wave_max_of_groups<LPR>(A)) : Amax;
+#ifdef VDS_PROF
+    if (lane == 0) { atomicAdd(&D.err[12], 1); if (Ntot > 4 * LPR) atomicAdd(&D.err[13], 1); if (Ntot > 8 * LPR) atomicAdd(&D.err[14], 1); if (TS == 128) atomicAdd(&D.err[15], 1); }
+#endif
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
     if (kmax == 0) {
         // no order in this (tick, cluster) bucket: the list is not read - the ranked arrivals are appended behind it in HBM
         if (Ntot > 0) {
-            if (PULL) merge_pull_any<LPR, 0>(ring, tab, lds_drec, lg, 0, n, Aring, Ntot, t, tbase, nullptr);
+            if (PULL) pull_rank_place_any<LPR, 0>(ring, tab, lds_drec, lg, 0, A - Aring, A, Ntot, tbase, nullptr);
             else merge_arrivals_any<LPR, 0>(ring, tab, lg, 0, A, Amax, tbase, nullptr);
             if (rowvalid) {
                 for (int idx = lg; idx < A; idx += LPR) idle[m + idx] = tab[idx];
@@ -657,7 +683,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     }
     // 4. arrivals ranked by dict insertion key; list + arrivals merged in the row's table, merged chunks read back
     if (Ntot > 0) {
-        if (PULL) merge_pull_any<LPR, J>(ring, tab, lds_drec, lg, m, n, Aring, Ntot, t, tbase, e);
+        if (PULL) pull_rank_place_any<LPR, J>(ring, tab, lds_drec, lg, m, A - Aring, A, Ntot, tbase, e);
         else merge_arrivals_any<LPR, J>(ring, tab, lg, m, A, Amax, tbase, e);
         if (rowvalid && lg == 0 && (PULL ? Aring : A) > 0) D.ring_cnt[si] = 0;
         if (J >= 4) {
@@ -722,19 +748,19 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             }
             int best = IMAX;
 #pragma unroll
-            for (int s = 0; s < J; ++s) best = min(best, (int)(((unsigned)row[byte_of(L[s >> 2], s & 3)] << 7) | (unsigned)s));
+            for (int s = 0; s < J; ++s) best = min(best, (int)(((unsigned)row[byte_of(L[s >> 2], s & 3)] << PB) | (unsigned)s));
             best += lbase;
             const int rmin = grp_min<LPR>(best);
             // the winner's slot leaves the table: its loc byte becomes the dead column.  (No vehicle left: rmin names a dead
             // slot, which is marked dead again.  A row WITHOUT an order at this step must not mark anything: its minimum names a
             // live slot.)
-            const int wrel = (rmin & 127) - lbase;
+            const int wrel = (rmin & PM) - lbase;
             const unsigned bm = (DM == 2 && !active) ? 0u : 0xFFu << ((wrel & 3) << 3);
             const int hi = wrel >> 2;
 #pragma unroll
             for (int i = 0; i < NL; ++i) L[i] = bfi(hi == i ? bm : 0u, ncrep, L[i]);
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(res[jj]) : "v"(res[jj]), "v"(rmin), "s"(jmask));      // res[jj] = lg == ji ? rmin : res[jj]
-            const bool hit = active && (rmin >> 7) != DEAD;
+            const bool hit = active && (rmin >> PB) != DEAD;
             evals += active ? navail : 0;
             navail -= hit ? 1 : 0;
         }
@@ -788,9 +814,9 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         if (DM == 2) { rr = make_int4(0, 0, 0, 0); if (has) rr = S.so_rec[q0 + j]; }
         else rr = lds_rec[j < k ? j : 0];
         const int rv = res[jj];
-        const bool matched = has && (rv >> 7) != DEAD;
-        const int wait = rv >> 7;
-        const int wpos = rv & 127;
+        const bool matched = has && (rv >> PB) != DEAD;
+        const int wait = rv >> PB;
+        const int wpos = rv & PM;
         const int src = (gbase + (wpos / J)) << 2;       // winner's entry: e[wpos % J] of group lane wpos / J
         unsigned went = 0;
 #pragma unroll
@@ -868,9 +894,18 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 
 #define DN_CAND 128          // static arrival slots (candidates) per bucket per tick the fast path takes (= DN_TAB: they are parked in the row's table)
 
-template <bool U8, int DM, int LPR, bool PULL>
-__global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4)) void k_tick_dense(DenseArgs P, int t) {
+// TABMAX: entries of a row's LDS table = the longest list (after the slot's arrivals) the fast path takes: 128, or 256 (16 lanes per
+// replica and byte costs only: 16 table registers per lane like the 8-lane / 128-entry form, scheduled for 6 wavefronts per SIMD) -
+// what order days per replica run with: other days fill other clusters, and a row beyond the table holds up its wavefront
+template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB>
+__global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
+    static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
     const DenseArgs &S = P, &D = P;
+#ifdef VDS_PROF
+    const int span_i = ((P.r_lo != 0 ? 1 : 0) * SPAN_TICKS + (t & (SPAN_TICKS - 1))) * 2;
+    if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMin(&g_span[span_i], (unsigned long long)__builtin_amdgcn_s_memtime());
+    struct SpanEnd { int i; __device__ ~SpanEnd() { if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMax(&g_span[i + 1], (unsigned long long)__builtin_amdgcn_s_memtime()); } } span_end{span_i};
+#endif
     if (DN_ABL & 512) return;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     constexpr int RPW = WAVE / LPR;             // rows per wavefront
@@ -882,7 +917,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     int *lds_slot = reinterpret_cast<int *>(lds_rec + (DM == 2 ? DN_ROWS * DN_ORDERS * 2 / 16 : DN_ORDERS));      // (DM == 2: the area holds u16 [16][64] pickup offsets)
     int2 *lds_drec = reinterpret_cast<int2 *>(lds_slot + (PULL ? DN_ORDERS : 0));
     unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
-    CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * DN_TAB);
+    CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * TABMAX);
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
     const int4 cd = S.cdesc_dense[blockIdx.x / nchunks];        // {n_c, byte offset of the block, cluster, 0}
@@ -960,7 +995,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
     const bool wg_ok = k <= DN_ORDERS && n <= DN_CAND;          // (DM == 2: per row)
-    unsigned *tab = tab_all + (wave * RPW + g) * DN_TAB;
+    unsigned *tab = tab_all + (wave * RPW + g) * TABMAX;
     // 1. bucket header words; PULL: the raw entries of the bucket's candidates, parked in the row's table
     int m = 0, far = 0, A = 0;
     long long cntv = 0;
@@ -974,9 +1009,12 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     }
     int Aring = A;
     if (PULL && wg_ok) {
+        // the candidates' raw entries; those that say "slot t" are parked in the row's table, packed in candidate order (position
+        // among the group's lanes from the ballot of the step): raw entry in tab[i], candidate index in tab[DN_TH + i]
         const unsigned *ar = D.arr + (size_t)(clo - qdb) * S.R + (rowvalid ? r : 0);
         const unsigned never = pull_reject(t - 1);          // (a byte slot t does not have)
-        int ap = 0;
+        const int gsh = lane & ~(LPR - 1);
+        int Ac = 0;
         for (int i0 = 0; i0 < n; i0 += 4 * LPR) {          // four loads in flight per lane
             unsigned v[4];
 #pragma unroll
@@ -988,11 +1026,14 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = i0 + u * LPR + lg;
-                if (idx < n) tab[idx] = v[u];
-                ap += (v[u] & 0xFFu) == ((unsigned)t & 0xFFu) ? 1 : 0;
+                const bool now_ = (v[u] & 0xFFu) == ((unsigned)t & 0xFFu);
+                const unsigned gm = (unsigned)(ballot(now_) >> gsh) & ((1u << LPR) - 1u);
+                const int pos = Ac + __popc(gm & ((1u << lg) - 1u));
+                if (now_ && pos < DN_TH) { tab[pos] = v[u]; tab[DN_TH + pos] = (unsigned)idx; }
+                Ac += __popc(gm);
             }
         }
-        A = Aring + grp_sum<LPR>(ap);       // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
+        A = Aring + Ac;       // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
     }
     if (DN_ABL & 256) { if (m + far + A + (int)cntv == 0x7FFFFFF1) D.err[1] = 1; return; }
     // 2. stage the cluster's cost block, the bucket's order records and - PULL - the candidates' static records in LDS
@@ -1022,8 +1063,15 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
     __syncthreads();
     PROF_STAMP_NW(1);       // barrier
     const int mnew0 = m + A;
-    const bool bad = rowvalid && (!wg_ok || far != 0 || Aring > S.dense_keys || Aring > S.ring_cap || A > DN_TAB || mnew0 > S.dense_tab || mnew0 > S.idle_cap || S.dense_force_slow ||
-                                  (PULL && (A - Aring > S.dense_keys * 2 || n + Aring > DN_TAB)));
+    const bool bad = rowvalid && (!wg_ok || far != 0 || Aring > S.dense_keys || Aring > S.ring_cap || A > DN_TAB || mnew0 > min(S.dense_tab, TABMAX) || mnew0 > S.idle_cap || S.dense_force_slow ||
+                                  (PULL && (A - Aring > S.dense_keys * 2 || A > DN_TH)));
+#ifdef VDS_PROF
+    if (bad && lg == 0) {       // why the row leaves the fast path (first reason that applies): vds_debug_read_err [4..11]
+        const int why = k > DN_ORDERS ? 4 : (n > DN_CAND ? 5 : (far != 0 ? 6 : ((Aring > S.dense_keys || Aring > S.ring_cap) ? 7 : (A > DN_TAB ? 8 : ((mnew0 > min(S.dense_tab, TABMAX) || mnew0 > S.idle_cap) ? 9 :
+                        ((PULL && A - Aring > S.dense_keys * 2) ? 10 : 11))))));      // (11: more than DN_TH arrivals)
+        atomicAdd(&D.err[why], 1);
+    }
+#endif
     const unsigned long long badrows = ballot(bad && lg == 0);
     if (badrows != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(badrows));      // buckets that leave the fast path: vds_read_work
     if (bad) { rowvalid = false; m = 0; A = 0; Aring = 0; }
@@ -1037,7 +1085,8 @@ __global__ __launch_bounds__(DN_ROWS * LPR, LPR == 16 ? DN_MIN_WAVES16 : (LPR ==
         const int2 *drec = DM == 2 ? drec_row : lds_drec;
         if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
         else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
-        else dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else if (TABMAX <= 128 || mmax <= 128) dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else dense_body<LPR, (TABMAX > 128 ? 256 : 128), CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
@@ -1056,6 +1105,16 @@ static void emit_dense(const Emit &e, void (*k)(DenseArgs, int), dim3 grid, dim3
     hipKernelNodeParams p{};
     p.func = reinterpret_cast<void *>(k); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds; p.kernelParams = args; p.extra = nullptr;
     *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
+}
+
+// 256-entry tables: order days per replica, 16 lanes per replica, byte costs (see k_tick_dense)
+static bool dense_tab256(const Static &S) { return S.n_days > 1 && S.dense_lpr == 16 && S.blk8s != nullptr && S.dense_tab > 128; }
+
+template <bool PULL>
+static void emit_dense_256(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
+    const dim3 block(DN_ROWS * 16);
+    if (S.chunk_days) emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256>, grid, block, lds, P, t);
+    else emit_dense(e, k_tick_dense<true, 2, 16, PULL, 256>, grid, block, lds, P, t);
 }
 
 template <int LPR, bool PULL>
@@ -1083,7 +1142,13 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
     // (one order day per replica: the order-record area holds the rows' pickup offsets instead, u16 [16][64] = 2 KB)
-    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * DN_TAB * 4 + bb;
+    const bool t256 = dense_tab256(S);
+    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * (t256 ? 256 : DN_TAB) * 4 + bb;
+    if (t256) {
+        if (S.pull) emit_dense_256<true>(e, S, P, t, grid, lds);
+        else emit_dense_256<false>(e, S, P, t, grid, lds);
+        return;
+    }
     // (4 lanes per replica - 16 replicas per wavefront, 32 + 8 table registers - was built and measured in round 4: 143 us per tick at
     // configs[1] against 53 / 59 us with 8 / 16 lanes: not instantiated any more)
     if (S.pull) {

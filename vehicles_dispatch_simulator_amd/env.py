@@ -64,9 +64,10 @@ class BatchedDispatchEnv:
         node2cluster, nbr_off, nbr_idx = _i32(node2cluster), _i32(nbr_off), _i32(nbr_idx)
         self.C = nbr_off.size - 1
         self.R, self.V = int(replicas), int(vehicles)
+        self.device = int(device)
         self.node2cluster = node2cluster
         if stream is not None:
-            self._chk(self._lib.vds_set_stream(self._h, C.c_void_p(stream)))
+            self.set_stream(stream)              # (an integer hipStream_t, or "legacy": see set_stream)
         if dense_debug is not None:       # test hook: (lanes per replica, idle entries / arrivals the fast path takes, force slow path)
             self._chk(self._lib.vds_debug_dense(self._h, *[int(x) for x in dense_debug]))
         self._chk(self._lib.vds_load_static(self._h, _p(cost), self.N, _p(node2cluster), self.C, _p(nbr_off), _p(nbr_idx), int(depth_limit)))
@@ -81,10 +82,13 @@ class BatchedDispatchEnv:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             bad = self._lib.vds_debug_check_guards(self._h) if hasattr(self._lib, "vds_debug_check_guards") else 0
+            msg = self._lib.vds_last_error(self._h).decode() if bad < 0 else ""
             self._lib.vds_destroy(self._h)
             self._h = C.c_void_p()
-            if bad:           # guarded build (make canary) only: some kernel wrote outside its table
+            if bad > 0:       # guarded build (make canary) only: some kernel wrote outside its table
                 raise Exception("libvds guard zones damaged: %d table(s) written out of bounds (see stderr)" % bad)
+            if bad < 0:       # the check itself failed (a HIP error): not a statement about the tables
+                raise Exception("libvds error %d while checking the guard zones: %s" % (bad, msg))
 
     def __del__(self):
         try:
@@ -92,7 +96,11 @@ class BatchedDispatchEnv:
         except Exception:
             pass
 
-    def set_stream(self, stream: Optional[int]):
+    def set_stream(self, stream):
+        """``stream``: a ``hipStream_t`` as an integer; ``None`` / 0 = the library's own (blocking) stream; ``"legacy"`` = the
+        legacy default stream itself (PyTorch's default stream on ROCm: ``VDS_STREAM_LEGACY_DEFAULT``)."""
+        if stream == "legacy":
+            stream = C.c_void_p(-1).value
         self._chk(self._lib.vds_set_stream(self._h, C.c_void_p(stream or 0)))
 
     # -- episode --------------------------------------------------------------------------
@@ -222,25 +230,28 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_read_obs(self._h, *[_p(a) for a in arrs]))
         return dict(zip(names, arrs))
 
-    def obs_device_ptr(self) -> int:
-        """Device pointer of the packed int32 [5][R][C] observation block (zero-copy consumers)."""
+    def obs_device_ptr(self, planes: int = 31) -> int:
+        """Device pointer of the packed int32 [5][R][C] observation block (zero-copy consumers); ``planes``: mask of the
+        planes to refresh (``vds_obs_device_planes``)."""
         p = C.c_void_p()
-        self._chk(self._lib.vds_obs_device(self._h, C.byref(p)))
+        self._chk(self._lib.vds_obs_device_planes(self._h, int(planes), C.byref(p)))
         return p.value
 
-    def obs_torch(self):
+    def obs_torch(self, inflight: bool = True):
         """The packed observation block as a zero-copy ``torch`` int32 tensor ``[5, R, C]`` on the GPU
         (``idle_pre, idle_now, supply, cl_orders, inflight``): what a batched RL agent consumes without a
-        host round trip.  The tensor aliases library memory and is overwritten by the next call."""
+        host round trip.  The tensor aliases library memory and is overwritten by the next call.
+        ``inflight=False`` leaves the fifth plane (``len(Cluster.VehiclesArrivetime)``) as it was: the pass then reads
+        a third of the arrival tables (per-slot hooks that do not use it)."""
         import torch
 
         class _Block:
             pass
 
         blk = _Block()
-        blk.__cuda_array_interface__ = {"shape": (5, self.R, self.C), "typestr": "<i4", "data": (self.obs_device_ptr(), False),
+        blk.__cuda_array_interface__ = {"shape": (5, self.R, self.C), "typestr": "<i4", "data": (self.obs_device_ptr(31 if inflight else 15), False),
                                         "version": 2, "strides": None}
-        return torch.as_tensor(blk, device="cuda")
+        return torch.as_tensor(blk, device=torch.device("cuda", self.device))
 
     def counters_torch(self):
         """Per-replica counters as a zero-copy ``torch`` int64 tensor ``[R, 8]`` on the GPU, in device order
@@ -256,7 +267,7 @@ class BatchedDispatchEnv:
 
         blk = _Block()
         blk.__cuda_array_interface__ = {"shape": (self.R, 8), "typestr": "<i8", "data": (p.value, False), "version": 2, "strides": None}
-        return torch.as_tensor(blk, device="cuda")
+        return torch.as_tensor(blk, device=torch.device("cuda", self.device))
 
     def counters(self) -> np.ndarray:
         out = np.zeros((self.R, _lib.NUM_COUNTERS), dtype=np.int64)

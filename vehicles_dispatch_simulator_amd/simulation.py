@@ -129,7 +129,10 @@ class Simulation(object):
         self.BatchedObs = None
         if self.BatchedHooks and "stream" not in device_kwargs:
             import torch          # the policy's tensors and the engine's launches share torch's current stream
-            device_kwargs = dict(device_kwargs, stream=torch.cuda.current_stream(int(Device)).cuda_stream)
+            cs = torch.cuda.current_stream(int(Device)).cuda_stream
+            # torch's default stream is the legacy default stream (handle 0): bound explicitly, so that ordering between the policy's
+            # tensors and the engine's launches never rests on implicit null-stream synchronisation (VDS_STREAM_LEGACY_DEFAULT)
+            device_kwargs = dict(device_kwargs, stream=cs if cs else "legacy")
         self._device_kwargs = device_kwargs
         self.env = None
         self._version = 0
