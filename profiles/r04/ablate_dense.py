@@ -12,7 +12,7 @@ T = env.T
 print(env.main_kernel(), env._lib.vds_build_id().decode())
 # state-preserving switches first (the day evolves as usual, timings are comparable); the others change what the later slots see
 names = [(0, "full"), (4096, "+ every ring post twice (shadow table)"), (8192, "+ the ring post's atomic twice"), (16384, "+ the ring post's entry store twice"),
-         (65536, "+ the arrival-slot store twice"), (262144, "+ the match loop twice"), (131072 | 32768, "no counter loads / stores"),
+         (65536, "+ the arrival-slot store twice"), (131072 | 32768, "no counter loads / stores"),
          (2, "no idle write-back (counts kept)"), (8, "no result stores"), (32768, "no counter stores"), (2 | 8 | 32768, "no write-back / result / counter stores"),
          (0, "full (again)"),
          (1, "[state-changing] no posts"), (4 | 1 | 2 | 8 | 16, "[state-changing] no match loop, no stores"),

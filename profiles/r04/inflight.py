@@ -1,5 +1,6 @@
 """How the two chains of a grouped day really overlap ("show the overlap without the tracer").  Instrumented build:
-every k_tick_dense launch stamps its first wavefront in / last wavefront out on the 100 MHz constant clock (s_memtime), per slot and
+every k_tick_dense launch stamps its first wavefront in / last wavefront out on the device-wide 100 MHz real-time counter
+(s_memrealtime), per slot and
 per chain; one day of configs[1] with the default vds_run (two chains), then one with one chain.
     VDS_LIB=$PWD/build/libvds_prof.so python profiles/r04/inflight.py [replicas]"""
 import os, sys

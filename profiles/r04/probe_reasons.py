@@ -13,6 +13,7 @@ if D > 1:
 else:
     env.load_orders(w.release_min, w.pickup, w.delivery)
 env.reset(w.vehicle_nodes(R))
+env._lib.vds_debug_ablate(env._h, 2097152)          # count the wavefronts of the fast body as well
 env.run(env.T); env.sync()
 e = np.zeros(16, dtype=np.int32)
 env._lib.vds_debug_read_err(env._h, e.ctypes.data)

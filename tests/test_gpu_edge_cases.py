@@ -292,3 +292,37 @@ def test_slow_path_buckets_are_counted(fg):
     env.run(20)
     assert env.work()["slow_path_buckets"] >= 2 * 15
     env.close()
+
+
+def test_dense_tick_switches_to_wide_rows_when_the_slow_path_is_crowded(monkeypatch):
+    """k_tick_dense with one shared order day starts with 8 lanes per replica and 128-entry tables; when an episode hands more
+    than 0.1 % of its bucket-ticks to the slow path (here: 200 vehicles parked in one cluster of every replica) the handle takes
+    16 lanes per replica and 256-entry tables from the next-but-one episode start on (the counter travels through pinned host
+    memory, no synchronisation).  Every episode equals the oracle, before and after the switch; after it the crowded cluster is on
+    the fast path (no slow-path buckets).  VDS_DENSE_ADAPT=0 keeps the first form."""
+    g = dict(load_golden("tiny_kmeans")); g["V"] = np.int64(200)
+    R = 20
+    nodes5 = np.flatnonzero(g["node2cluster"] == 5)
+    init = np.stack([nodes5[(np.arange(200) * (r + 1)) % nodes5.size] for r in range(R)]).astype(np.int32)
+    exp = []
+    for r in range(R):
+        o = Oracle(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], 0, False, g["o_release_min"], g["o_pickup"], g["o_delivery"], 200)
+        o.reset(init[r]); o.run_day(); exp.append(o.orders())
+    for adapt in ("1", "0"):
+        monkeypatch.setenv("VDS_DENSE_ADAPT", adapt)
+        env = make_env(g, R, idle_cap=256)
+        assert env.main_kernel() == "k_tick_dense"
+        env.reset(init)
+        slow = []
+        for ep in range(5):
+            if ep: env.reset_again()
+            env.run(env.T); env.sync()
+            got = env.orders()
+            for r in range(R):
+                for k in ("status", "vehicle", "wait"):
+                    np.testing.assert_array_equal(got[k][r], exp[r][k], err_msg="episode %d replica %d %s" % (ep, r, k))
+            slow.append(env.work()["slow_path_buckets"])
+        assert slow[0] > 0 and slow[1] == slow[0]
+        if adapt == "1": assert slow[-1] == 0 and slow[-2] == 0, slow
+        else: assert slow[-1] == slow[0], slow
+        env.close()

@@ -128,6 +128,11 @@ struct vds_handle {
     hipGraphExec_t run_exec = nullptr;
     int run_t0 = -1, run_n = 0, run_G = 1;
     unsigned long long run_shape = 0;        // graph_shape of run_exec (grouped graphs: the key it is parked under)
+    // k_tick_dense, one shared order day: 8 or 16 lanes per replica by what the last episode did (adapt_dense)
+    int *pin_slow = nullptr;                 // pinned host word: buckets the last finished episode handed to the slow path
+    hipEvent_t pin_ev = nullptr;             // recorded behind the copy into pin_slow
+    long long pin_bucket_ticks = 0;          // bucket-ticks of that episode (0: nothing copied yet)
+    int dense_adapt = 0;                     // 0 undecided (8 lanes), 1 switched to 16 lanes / 256-entry tables; -1 fixed by the caller / environment
     bool run_stale = false;                  // tables / capacities changed since the graph was built: same shape -> hipGraphExecUpdate
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
@@ -460,6 +465,8 @@ int vds_destroy(vds_handle *h) {
     for (void *p : h->idle_allocs) dev_free(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     drop_run_graph(h);
+    if (h->pin_ev) (void)hipEventDestroy(h->pin_ev);
+    if (h->pin_slow) (void)hipHostFree(h->pin_slow);
     if (h->d_S) (void)hipFree(h->d_S);
     if (h->d_D) (void)hipFree(h->d_D);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1039,7 +1046,10 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", n_days > 1 ? 16 : DENSE_LPR_DEFAULT);
         S.dense_lpr = (lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
         // entries of a bucket the fast path holds: 128; 256 with order days per replica at 16 lanes per replica and byte costs (emit_tick_dense)
-        const int tab_max = (n_days > 1 && S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0) ? 256 : 128;
+        const int tab_max = (S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0) ? 256 : 128;
+        // (another day on the handle: the choice between 8 and 16 lanes per replica is open again, unless the caller fixed it)
+        h->dense_adapt = (h->dbg_dense_lpr > 0 || h->dbg_dense_tab > 0 || getenv("VDS_DENSE_LPR") || env_int("VDS_DENSE_ADAPT", 1) == 0) ? -1 : 0;
+        h->pin_bucket_ticks = 0;
         S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, tab_max) : tab_max;
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
         S.dense_force_slow = h->dbg_dense_slow & 1;
@@ -1196,7 +1206,46 @@ int vds_num_ticks(const vds_handle *h, int32_t *T) {
     return VDS_OK;
 }
 
+// k_tick_dense with one shared order day runs 8 lanes per replica (8 replicas per wavefront): fastest while rows beyond the
+// 128-entry tables are rare.  Where they are not - a few clusters holding more than 128 idle vehicles in EVERY replica, e.g.
+// configs[4]: all 8 rows of those clusters' wavefronts take the slow path one after the other and become the tail of every launch
+// (115 vs 77 us per tick) - 16 lanes per replica with 256-entry tables are faster.  Which case a workload is shows in the slow-path
+// counter of an episode: every episode start copies the counter of the episode that just ended into pinned host memory
+// (asynchronously), looks at the value the PREVIOUS start left there (an event says whether that copy has landed: no
+// synchronisation), and switches once when more than DENSE_ADAPT_RATE of the bucket-ticks left the fast path.  Results do not
+// depend on the choice (tests: both forms against the oracle).  VDS_DENSE_ADAPT=0, VDS_DENSE_LPR or vds_debug_dense fix the form.
+#ifndef DENSE_ADAPT_RATE
+#define DENSE_ADAPT_RATE 0.001
+#endif
+static void adapt_dense(vds_handle *h) {
+    Static &S = h->S;
+    if (!S.dense || h->dfs_mode || S.n_days > 1 || h->dense_adapt != 0 || !S.blk8s) return;
+    if (!h->pin_slow) {
+        if (hipHostMalloc((void **)&h->pin_slow, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError(); h->dense_adapt = -1; return;
+        }
+        *h->pin_slow = 0;
+    }
+    if (h->pin_bucket_ticks > 0 && hipEventQuery(h->pin_ev) == hipSuccess) {
+        if ((double)*h->pin_slow > DENSE_ADAPT_RATE * (double)h->pin_bucket_ticks) {
+            const char *t256 = getenv("VDS_DENSE_TAB256");
+            S.dense_lpr = 16; S.dense_tab = (t256 && *t256 == '0') ? 128 : 256;
+            h->dense_adapt = 1;
+            h->run_stale = true;               // the day graph holds the other kernel
+            return;
+        }
+    }
+    (void)hipGetLastError();
+    // the episode that ends here (h->t slots of it were run)
+    if (h->have_reset && h->t > 0) {
+        if (hipMemcpyAsync(h->pin_slow, h->D.err + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipEventRecord(h->pin_ev, h->stream) == hipSuccess)
+            h->pin_bucket_ticks = (long long)h->t * S.R * S.C;
+        else { (void)hipGetLastError(); h->pin_bucket_ticks = 0; }
+    }
+}
+
 static int reset_device(vds_handle *h) {
+    adapt_dense(h);
     const Static &S = h->S;
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 16 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));

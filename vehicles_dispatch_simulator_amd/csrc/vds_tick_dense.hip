@@ -23,23 +23,32 @@
 // Rows the tables cannot hold (> 128 entries, > 64 arrivals), rows with far arrivals and buckets with > 64 orders are finished
 // by the same wavefront with dense_bucket_slow (any size, straight from HBM).
 #include "vds_kernels_common.h"
+#include <algorithm>
 
 namespace vds {
 
 VDS_PROF_ACCESSORS(dense)
 
 // Instrumented build: when every launch of the tick starts and ends - first wavefront in, last wavefront out, on the 100 MHz
-// constant clock s_memtime reads on every CU - per slot and per replica group (chain) of vds_run.  What a kernel trace cannot show
+// real-time counter (s_memrealtime: one time base for the whole device; s_memtime counts per XCD with unrelated offsets) - per slot and per replica group (chain) of vds_run.  What a kernel trace cannot show
 // for the two concurrent chains of a grouped day (tracing serialises the queues): profiles/r04/inflight.py.
 #define SPAN_TICKS 256
 #ifdef VDS_PROF
-static __device__ unsigned long long g_span[2 * SPAN_TICKS * 2];      // [chain][slot]{first start, last end}
-void read_span_dense(unsigned long long *out, int reset, hipStream_t st) {
+#define SPAN_WAYS 64          // stamps of a launch are spread over this many words (12 288 same-address atomics per launch would be the launch)
+static __device__ unsigned long long g_span[2 * SPAN_TICKS * SPAN_WAYS * 2];      // [chain][slot][way]{first start, last end}
+void read_span_dense(unsigned long long *out, int reset, hipStream_t st) {       // out: [chain][slot]{first start, last end}
     (void)hipStreamSynchronize(st);
-    static unsigned long long host[2 * SPAN_TICKS * 2];
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(host));
+    static unsigned long long host[2 * SPAN_TICKS * SPAN_WAYS * 2];
+    if (out) {
+        (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_span), sizeof(host));
+        for (int i = 0; i < 2 * SPAN_TICKS; ++i) {
+            unsigned long long lo = ~0ull, hi = 0ull;
+            for (int w = 0; w < SPAN_WAYS; ++w) { lo = std::min(lo, host[(i * SPAN_WAYS + w) * 2]); hi = std::max(hi, host[(i * SPAN_WAYS + w) * 2 + 1]); }
+            out[2 * i] = lo; out[2 * i + 1] = hi;
+        }
+    }
     if (reset) {
-        for (int i = 0; i < 2 * SPAN_TICKS; ++i) { host[2 * i] = ~0ull; host[2 * i + 1] = 0ull; }
+        for (int i = 0; i < 2 * SPAN_TICKS * SPAN_WAYS; ++i) { host[2 * i] = ~0ull; host[2 * i + 1] = 0ull; }
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span), host, sizeof(host));
     }
 }
@@ -51,6 +60,9 @@ void read_span_dense(unsigned long long *, int, hipStream_t) { }
 #define DN_TAB 128           // idle entries per bucket the fast path holds
 #define DN_KEYS 64           // arrivals per bucket per tick the fast path ranks
 #define DN_ORDERS 64         // orders per (cluster, tick) bucket the fast path matches
+#define DN_TPAD 4            // words between the rows' LDS tables: the rows of a wavefront read THEIR table at one index in the same
+                             // instruction (ranking loop, packed arrivals) - a row stride of 128 words would put all of them on one bank
+                             // (A/B on one box, 3 x 400 days per arm: 7.18 vs 7.23 ms per day - no measurable difference)
 
 // Kernel arguments of the fast path: only what it reads (the whole Static / State pair as by-value arguments costs ~100 SGPR
 // spills, each reload a VALU instruction).  The slow path - rare - reads the device-resident copies behind Sdev / Ddev.
@@ -610,7 +622,7 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 //   only, 64 posts: entry store only, 256 nothing after the header loads, 512 empty kernel, 1024 no cost-block staging,
 //   2048 no list / arrival loads and no merge; state-preserving: 4096 every post twice (second into a shadow table), 8192 the
 //   atomic twice, 16384 the entry store twice, 32768 no counter stores, 65536 the arrival-slot store twice, 131072 no counter
-//   loads, 262144 the match loop twice, 1048576 launch spans (g_span: first wavefront in / last out per slot and chain)
+//   loads, 2097152 count the wavefronts by ranking width / table size (vds_debug_read_err [12..15]), 1048576 launch spans (g_span: first wavefront in / last out per slot and chain)
 #ifdef VDS_PROF
 #define DN_ABL (g_ablate)
 #else
@@ -661,7 +673,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     // arrivals to rank: the most of a row of this wavefront (wave-uniform; PULL: arriving candidates + ring entries)
     const int Ntot = PULL ? ((abl & 2048) ? 0 : wave_max_of_groups<LPR>(A)) : Amax;
 #ifdef VDS_PROF
-    if (lane == 0) { atomicAdd(&D.err[12], 1); if (Ntot > 4 * LPR) atomicAdd(&D.err[13], 1); if (Ntot > 8 * LPR) atomicAdd(&D.err[14], 1); if (TS == 128) atomicAdd(&D.err[15], 1); }
+    if ((g_ablate & 2097152) && lane == 0) { atomicAdd(&D.err[12], 1);      // (24 576 same-address atomics per launch: only on request) if (Ntot > 4 * LPR) atomicAdd(&D.err[13], 1); if (Ntot > 8 * LPR) atomicAdd(&D.err[14], 1); if (TS == 128) atomicAdd(&D.err[15], 1); }
 #endif
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
@@ -719,17 +731,6 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     int res[NG];
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) res[jj] = IMAX;
-#ifdef VDS_PROF
-    unsigned Lsave[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) Lsave[i] = L[i];
-    for (int pass = 0; pass < ((abl & 262144) ? 2 : 1); ++pass) {
-    if (pass) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) L[i] = Lsave[i];
-        navail = mnew; evals = 0;
-    }
-#endif
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
         if (jj * LPR >= kmax || (abl & 4)) break;
@@ -765,9 +766,6 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             navail -= hit ? 1 : 0;
         }
     }
-#ifdef VDS_PROF
-    }
-#endif
     PROF_STAMP(6);          // match loop
     // 6. order-preserving compaction of the survivors (:963) through the row's table, written back with whole-chunk stores from
     //    the first changed position on
@@ -902,9 +900,9 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
     const DenseArgs &S = P, &D = P;
 #ifdef VDS_PROF
-    const int span_i = ((P.r_lo != 0 ? 1 : 0) * SPAN_TICKS + (t & (SPAN_TICKS - 1))) * 2;
-    if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMin(&g_span[span_i], (unsigned long long)__builtin_amdgcn_s_memtime());
-    struct SpanEnd { int i; __device__ ~SpanEnd() { if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMax(&g_span[i + 1], (unsigned long long)__builtin_amdgcn_s_memtime()); } } span_end{span_i};
+    const int span_i = (((P.r_lo != 0 ? 1 : 0) * SPAN_TICKS + (t & (SPAN_TICKS - 1))) * SPAN_WAYS + (int)(blockIdx.x & (SPAN_WAYS - 1))) * 2;
+    if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMin(&g_span[span_i], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    struct SpanEnd { int i; __device__ ~SpanEnd() { if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMax(&g_span[i + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } span_end{span_i};
 #endif
     if (DN_ABL & 512) return;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
@@ -917,7 +915,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
     int *lds_slot = reinterpret_cast<int *>(lds_rec + (DM == 2 ? DN_ROWS * DN_ORDERS * 2 / 16 : DN_ORDERS));      // (DM == 2: the area holds u16 [16][64] pickup offsets)
     int2 *lds_drec = reinterpret_cast<int2 *>(lds_slot + (PULL ? DN_ORDERS : 0));
     unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
-    CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * TABMAX);
+    CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * (TABMAX + DN_TPAD));
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
     const int4 cd = S.cdesc_dense[blockIdx.x / nchunks];        // {n_c, byte offset of the block, cluster, 0}
@@ -995,7 +993,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
     const bool wg_ok = k <= DN_ORDERS && n <= DN_CAND;          // (DM == 2: per row)
-    unsigned *tab = tab_all + (wave * RPW + g) * TABMAX;
+    unsigned *tab = tab_all + (wave * RPW + g) * (TABMAX + DN_TPAD);
     // 1. bucket header words; PULL: the raw entries of the bucket's candidates, parked in the row's table
     int m = 0, far = 0, A = 0;
     long long cntv = 0;
@@ -1108,12 +1106,13 @@ static void emit_dense(const Emit &e, void (*k)(DenseArgs, int), dim3 grid, dim3
 }
 
 // 256-entry tables: order days per replica, 16 lanes per replica, byte costs (see k_tick_dense)
-static bool dense_tab256(const Static &S) { return S.n_days > 1 && S.dense_lpr == 16 && S.blk8s != nullptr && S.dense_tab > 128; }
+static bool dense_tab256(const Static &S) { return S.dense_lpr == 16 && S.blk8s != nullptr && S.dense_tab > 128; }
 
 template <bool PULL>
 static void emit_dense_256(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
     const dim3 block(DN_ROWS * 16);
-    if (S.chunk_days) emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256>, grid, block, lds, P, t);
+    if (S.n_days <= 1) emit_dense(e, k_tick_dense<true, 0, 16, PULL, 256>, grid, block, lds, P, t);
+    else if (S.chunk_days) emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256>, grid, block, lds, P, t);
     else emit_dense(e, k_tick_dense<true, 2, 16, PULL, 256>, grid, block, lds, P, t);
 }
 
@@ -1143,7 +1142,7 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
     // (one order day per replica: the order-record area holds the rows' pickup offsets instead, u16 [16][64] = 2 KB)
     const bool t256 = dense_tab256(S);
-    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * (t256 ? 256 : DN_TAB) * 4 + bb;
+    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * ((t256 ? 256 : DN_TAB) + DN_TPAD) * 4 + bb;
     if (t256) {
         if (S.pull) emit_dense_256<true>(e, S, P, t, grid, lds);
         else emit_dense_256<false>(e, S, P, t, grid, lds);
