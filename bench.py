@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--no-neighbour-leg", action="store_true", help="skip the extra configs[3] (neighbour search) leg")
     ap.add_argument("--check", action="store_true", help="verify replica 0 against the oracle after the run")
     ap.add_argument("--distinct-days", type=int, default=16, help="extra leg: the same workload with this many different order days (0/1 = skip)")
-    ap.add_argument("--no-distinct-all", dest="distinct_all", action="store_false", help="skip the leg with one order day per replica")
+    ap.add_argument("--no-distinct-all", dest="distinct_all", action="store_false", help="skip the leg with one order stream per replica")
+    ap.add_argument("--distinct-all-days", type=int, default=128, help="distinct days of that leg (replica r replays day r %% N)")
     ap.add_argument("--no-hooked-leg", dest="hooked", action="store_false", help="skip the hooked-slot leg (step -> obs -> policy -> dispatch -> advance)")
     a = ap.parse_args()
 
@@ -317,11 +318,15 @@ def main():
             per_days[label] = {"value": T2 * R * nd / dt2, "ms_per_step": dt2 / nd * 1e3, "steps": nd}
             env2.close()
         per_days["value"] = per_days["interleaved"]["value"]
-        # every replica its OWN day (the ordinary RL case: R different episodes), days drawn from a pool of R distinct days
+        # one order stream PER REPLICA (day mode 2 of k_tick_dense: the ordinary RL case - every city its own episode): the replica ->
+        # day map mixes days inside every group of 16 replicas and leaves fewer than 13 replicas per day, so the library can
+        # neither keep nor regroup them into one-day workgroups.  128 distinct days by default (8 replicas per day; generating
+        # and loading R = 1024 different days of 200k orders takes ~45 s of host time: --distinct-all-days 1024 does it)
         if a.distinct_all:
-            daysR = workloads.distinct_days(w, R)
+            nda = max(R // 12 + 1, min(a.distinct_all_days, R))
+            daysR = workloads.distinct_days(w, nda)
             env2 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
-            env2.load_order_days(daysR, np.arange(R, dtype=np.int32))
+            env2.load_order_days(daysR, (np.arange(R) % nda).astype(np.int32))
             env2.reset(init)
             T2 = env2.T
             env2.reset_again(); env2.run(T2)
@@ -333,7 +338,7 @@ def main():
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             env2.sync()
-            per_days["distinct_%d" % R] = {"value": T2 * R * nd / dt2, "ms_per_step": dt2 / nd * 1e3, "steps": nd, "kernel": env2.main_kernel(),
+            per_days["one_stream_per_replica"] = {"distinct_days": nda, "value": T2 * R * nd / dt2, "ms_per_step": dt2 / nd * 1e3, "steps": nd, "kernel": env2.main_kernel(),
                                            "slow_path_buckets_last_day": int(env2.work().get("slow_path_buckets", 0)),
                                            "vs_shared_day": (T2 * R * nd / dt2) / (T * R * world * a.steps / elapsed)}
             env2.close()

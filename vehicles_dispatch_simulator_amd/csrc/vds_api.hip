@@ -99,7 +99,7 @@ struct vds_handle {
     int O = 0;              // all orders incl. never-processed ones
     int lds_ints = 0;
     // host mirrors
-    std::vector<int> node2cluster, node_local, cl_off, cl_nodes, cost_host;
+    std::vector<int> node2cluster, node_local, cl_off, cl_nodes, cost_host, corder_host;
     std::vector<DayHost> days;         // the loaded order days
     std::vector<int> replica_day;        // [R_ext] by the caller's replica index
     // Order days per replica with a map that mixes days inside aligned groups of 16: the replicas are stored REGROUPED by day
@@ -644,6 +644,7 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
         for (int c = 0; c < C; ++c) corder[c] = c;
         std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return cdesc[a].x > cdesc[b].x; });
         if ((rc = upload(h, &d, corder))) return rc; S.corder = d;
+        h->corder_host = corder;
         std::vector<int4> cdo(C);
         // byte copy of the blocks for the fast kernel (filled below once the cost range is known)
         std::vector<long long> b8off(C + 1, 0);
@@ -1060,6 +1061,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     //      orders that can arrive now instead of receiving atomically appended ring entries.
     S.so_slot = nullptr; S.d_rec = nullptr; S.d_first = nullptr; S.replica_desc2 = nullptr; S.pull_W = 0; S.pull_hmax = 0;
     int Od_max = 0;
+    std::vector<int> d_first_keep;       // (one shared day: for the per-bucket descriptors below)
     if (S.pull) {
         const int Hc = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
         const int tk = S.tick_minutes;
@@ -1124,6 +1126,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
             for (int r = 0; r < S.R; ++r) rd2[r] = day_of_internal[r] < n_days ? ddesc2[day_of_internal[r]] : make_int4(0, 0, 0, 0);
             int4 *d4r; if ((rc = upload(h, &d4r, rd2))) return rc; S.replica_desc2 = d4r;
             h->pull_desc = ddesc2;
+            d_first_keep = d_first;
             h->pull_drec = d_rec;
             h->pull_slot_q.assign(d_rec.size(), 0);
             for (size_t q = 0; q < so_slot.size(); ++q) {
@@ -1135,12 +1138,33 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         }
     }
     h->pull_Od_max = Od_max;
+    // per-bucket descriptors of the dense tick with one shared day (Static.tdesc)
+    S.tdesc = nullptr;
+    if (S.dense && n_days == 1 && (int)h->corder_host.size() == C) {
+        const DayDesc &de = ddesc[0];
+        std::vector<int4> td((size_t)std::max(de.T, 1) * C, make_int4(0, 0, 0, 0));
+        for (int t = 0; t < de.T; ++t)
+            for (int ci = 0; ci < C; ++ci) {
+                const int c = h->corder_host[ci];
+                const int q0 = bkt_off[de.bkt_base + (size_t)t * C + c], k = bkt_off[de.bkt_base + (size_t)t * C + c + 1] - q0;
+                int clo = 0, n = 0;
+                if (S.pull) {
+                    clo = d_first_keep[(size_t)std::max(t - S.pull_W, 0) * C + c];
+                    n = d_first_keep[(size_t)(t + 1) * C + c] - clo;
+                }
+                td[(size_t)t * C + ci] = make_int4(q0, k, clo, n);
+            }
+        struct Sink3 { vds_handle *h; ~Sink3() { h->alloc_sink = nullptr; } } sink3{h};
+        h->alloc_sink = &h->order_allocs;
+        int4 *dtd; if ((rc = upload(h, &dtd, td))) return rc; S.tdesc = dtd;
+    }
     h->alloc_sink = nullptr;
     if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;
     h->alloc_sink = &h->order_allocs;            // results: [R][Oq]
     rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1));
     h->D.arr = nullptr;
-    if (!rc && S.pull) rc = dev_alloc(h, &h->D.arr, (size_t)S.R * std::max(h->pull_Od_max, 1));       // [Od][R]
+    S.arr_slots = std::max(h->pull_Od_max, 1);
+    if (!rc && S.pull) rc = dev_alloc(h, &h->D.arr, (size_t)S.R * S.arr_slots);       // [Od][R] (arr_index)
     h->alloc_sink = nullptr;
     if (rc) return rc;
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
@@ -1925,7 +1949,7 @@ static int read_lists_impl(vds_handle *h, int32_t replica, int32_t *idle_off, in
             const int4 d2 = h->pull_desc[dday];
             const size_t nslot = (size_t)d2.w;
             std::vector<unsigned> col(std::max<size_t>(nslot, 1));
-            if (nslot) HIPCHK(h, hipMemcpy2D(col.data(), sizeof(unsigned), h->D.arr + replica, (size_t)R * sizeof(unsigned), sizeof(unsigned), nslot, hipMemcpyDeviceToHost));
+            if (nslot) HIPCHK(h, hipMemcpy2D(col.data(), sizeof(unsigned), h->D.arr + arr_index(S.R, 0, replica), (size_t)R * sizeof(unsigned), sizeof(unsigned), nslot, hipMemcpyDeviceToHost));
             std::vector<int2> res((size_t)std::max(DH.Oq, 1));
             if (DH.Oq > 0) HIPCHK(h, hipMemcpy(res.data(), h->D.out + (size_t)replica * S.Oq, (size_t)DH.Oq * sizeof(int2), hipMemcpyDeviceToHost));
             // destination cluster of a slot: the slots are sorted by it; walk d_first of slot row 0

@@ -132,6 +132,7 @@ struct Static {
     const struct State *state_dev;   // what the rarely taken slow path of k_tick_dense reads instead of by-value kernel arguments
     // static arrival slots ("pull", see below): 1 = order-carrying arrivals go through D.arr instead of the ring
     int pull, pull_W, pull_hmax;     // W: most slots an arrival can lie behind its earliest slot a0; hmax: longest trip in slots (dmin)
+    int arr_slots;                   // slots of the longest day: D.arr is [arr_slots][R] (arr_index)
     const int *so_slot;              // [Oq] per sorted order: slot index in its day's D.arr rows (-1: ring / far path)
     const int2 *d_rec;               // per slot, sorted by (destination cluster, a0, id): {dense_key(insert tick, 0, id), a0 | dest_local << 16 | dmin << 24}
     const int *d_first;              // per day [(TA + 1) x C]: first slot (absolute d_rec position) of cluster c with a0 >= a
@@ -141,6 +142,9 @@ struct Static {
     const unsigned char *blk8s;      // (dense, byte costs <= 254) the same as bytes, column n_c = 0xFF: the loc byte of a taken / absent
                                      // entry names that column, so the entry loses every comparison without a test in the match loop
     const int4 *cdesc_dense;         // [C] {n_c, offset into blk8s / blk32s, cluster, 0}, heaviest cluster first
+    const int4 *tdesc;               // (dense, one shared order day) [T][C] in cdesc_dense's cluster order: {first sorted order, orders, first
+                                     // candidate slot, candidate slots} of the (slot, cluster) bucket - one scalar load next to cdesc_dense's
+                                     // instead of four that depend on it (the workgroup's prologue is a chain of dependent loads)
 };
 
 // where a host-side launcher puts its kernel: on a stream, or as a kernel node of an explicitly built hipGraph
@@ -165,7 +169,7 @@ struct State {
     int2 *out;
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
-    unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] pull_entry / pull_reject
+    unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] pull_entry / pull_reject (arr_index)
     int *ring_min;       // dense layout: [H][C][R][ring_cap] arrival minute of a DISPATCHED vehicle's entry (order-carrying entries: recomputed
                          // from the order's result on the read side); written by the dispatch kernels only, never read by a tick
 };
@@ -181,13 +185,18 @@ struct State {
 // hdr / cnt / ring_cnt / fl / inbox / out keep their layouts (far entries stay int4 {veh, id, arrive, meta}).
 // Static arrival slots ("pull").  An order's arrival slot is its (static) processing slot + d, d = ceil((PickupWaitTime + OrderValue) /
 // slot length) (:954-960): only the wait - at most the largest cost inside the pickup cluster - is dynamic, so the arrival lies in
-// [a0, a0 + W] with a0 = processing slot + d(wait 0) static.  Every processed order owns ONE u32 per replica in D.arr[slot][R],
+// [a0, a0 + W] with a0 = processing slot + d(wait 0) static.  Every processed order owns ONE u32 per replica in D.arr (arr_index),
 // slots sorted by (destination cluster, a0, id): the matching bucket stores pull_entry(veh, arrival slot) (pull_reject: no
 // vehicle) with a plain store - no atomic, no position to wait for, 16 consecutive replicas = one 64-byte line - and the
 // destination bucket of slot t reads the entries of its orders with a0 in [t - W, t] (a contiguous range, known from static
 // tables) and takes those whose arrival-slot byte is t's (every candidate was processed less than 128 slots ago).  Dict insertion order = the orders' (insert tick, id) keys (static, d_rec).  Dispatched
 // vehicles (hooks) and orders whose trip may outlive the ring horizon keep the ring / far path.  Used when W <= DENSE_PULL_WMAX.
 #define DENSE_PULL_WMAX 3
+// D.arr is [arr_slots][R] u32: the candidates of a bucket are consecutive slots, a workgroup (16 / 32 consecutive replicas) reads
+// and writes 64 / 128 contiguous bytes per slot, and the 4 KB of one slot's R = 1024 replicas are read by the cluster's workgroups
+// at about the same time.  (Blocked by 32 replicas - [R / 32][arr_slots][32], every workgroup streaming its own contiguous run of
+// n slots - was built and measured in round 4: configs[1] 7.05 vs 6.92 ms per day on one box, 16 days 8.67 vs 8.84: not kept.)
+__host__ __device__ inline size_t arr_index(int R, int slot, int r) { return (size_t)slot * (size_t)R + (size_t)r; }
 __host__ __device__ inline unsigned pull_entry(int veh, int arrival_slot) { return ((unsigned)veh << 8) | ((unsigned)arrival_slot & 0xFFu); }
 // rejected at slot t: a byte no slot in (t, t + 128) has
 __host__ __device__ inline unsigned pull_reject(int t) { return 0xFFFFFF00u | ((unsigned)(t + 128) & 0xFFu); }

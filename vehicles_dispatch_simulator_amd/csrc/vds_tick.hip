@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                     for (int u = 0; u < 8; ++u) {
                         const int i = min(i0 + u, hi - 1);
                         ry[u] = S.d_rec[i].y;
-                        e[u] = D.arr[(size_t)(i - d2.y) * S.R + r];
+                        e[u] = D.arr[arr_index(S.R, i - d2.y, r)];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {

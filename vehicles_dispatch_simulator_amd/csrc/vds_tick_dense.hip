@@ -60,6 +60,9 @@ void read_span_dense(unsigned long long *, int, hipStream_t) { }
 #define DN_TAB 128           // idle entries per bucket the fast path holds
 #define DN_KEYS 64           // arrivals per bucket per tick the fast path ranks
 #define DN_ORDERS 64         // orders per (cluster, tick) bucket the fast path matches
+#ifndef DN_ROWS32
+#define DN_ROWS32 1          // 32-row workgroups where they apply (k_tick_dense)
+#endif
 #define DN_TPAD 4            // words between the rows' LDS tables: the rows of a wavefront read THEIR table at one index in the same
                              // instruction (ranking loop, packed arrivals) - a row stride of 128 words would put all of them on one bank
                              // (A/B on one box, 3 x 400 days per arm: 7.18 vs 7.23 ms per day - no measurable difference)
@@ -71,12 +74,13 @@ struct DenseArgs {
     int *hdr; long long *cnt; unsigned *idle; uint2 *ring; int *ring_cnt; int4 *inbox; int2 *out; int *err;
     // static / per-day tables
     const int4 *cdesc_dense; const char *blk; const int4 *so_rec; const int *bkt_off; const int4 *replica_desc; const int *rperm;
-    int R, C, H, idle_cap, ring_cap, in_cap, Oq;
+    int R, C, H, idle_cap, ring_cap, in_cap, Oq, arr_slots;
     int tick_minutes, now0, tick_div_limit; unsigned tick_magic;
-    int r_lo, dense_tab, dense_keys, dense_force_slow;
+    int r_lo, r_hi, dense_tab, dense_keys, dense_force_slow;      // rows (row slots with rperm) of this launch: [r_lo, r_hi)
     int *ring_min;                   // (instrumented build: shadow target of the doubled posts)
     // static arrival slots ("pull", vds_device.h)
     unsigned *arr; const int *so_slot; const int2 *d_rec; const int *d_first; const int4 *replica_desc2; int pull_W;
+    const int4 *tdesc;               // (one shared day) per-bucket descriptors, Static.tdesc
     const Static *Sdev; const State *Ddev;
 };
 __device__ __forceinline__ uint2 *ring2(const DenseArgs &D) { return D.ring; }
@@ -221,7 +225,7 @@ __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, i
             if (slot >= 0) {            // static arrival slot
                 const int rel = wait + rec.w;
                 const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
-                D.arr[(size_t)slot * S.R + r] = matched ? pull_entry(vid, t + d) : pull_reject(t);
+                D.arr[arr_index(S.R, slot, r)] = matched ? pull_entry(vid, t + d) : pull_reject(t);
             } else if (matched) post_arrival<true, true>(S, D, rec.z & 0xFFFF, r, t, now, vid, rec.x, now + wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
         wait_sum += wave_sum_i32(matched ? wait : 0);
@@ -301,7 +305,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
             if (I < ncand) {
                 const int idx = I * WAVE + lane_;
                 if (idx >= n) return false;
-                const unsigned raw = D.arr[(size_t)(clo - qdb + idx) * S.R + r];
+                const unsigned raw = D.arr[arr_index(S.R, clo - qdb + idx, r)];
                 const int2 rec = S.d_rec[clo + idx];
                 const int a0 = rec.y & 0xFFFF;
                 if ((raw & 0xFFu) != ((unsigned)t & 0xFFu)) return false;
@@ -441,7 +445,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
             if (slot >= 0) {            // static arrival slot
                 const int rel = res_wait + rec.w;
                 const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
-                D.arr[(size_t)slot * S.R + r] = res_veh >= 0 ? pull_entry(res_veh, t + d) : pull_reject(t);
+                D.arr[arr_index(S.R, slot, r)] = res_veh >= 0 ? pull_entry(res_veh, t + d) : pull_reject(t);
             } else if (res_veh >= 0) post_arrival<false, true>(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
     }
@@ -673,7 +677,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     // arrivals to rank: the most of a row of this wavefront (wave-uniform; PULL: arriving candidates + ring entries)
     const int Ntot = PULL ? ((abl & 2048) ? 0 : wave_max_of_groups<LPR>(A)) : Amax;
 #ifdef VDS_PROF
-    if ((g_ablate & 2097152) && lane == 0) { atomicAdd(&D.err[12], 1);      // (24 576 same-address atomics per launch: only on request) if (Ntot > 4 * LPR) atomicAdd(&D.err[13], 1); if (Ntot > 8 * LPR) atomicAdd(&D.err[14], 1); if (TS == 128) atomicAdd(&D.err[15], 1); }
+    // (24 576 same-address atomics per launch: only on request)
+    if ((g_ablate & 2097152) && lane == 0) { atomicAdd(&D.err[12], 1); if (Ntot > 4 * LPR) atomicAdd(&D.err[13], 1); if (Ntot > 8 * LPR) atomicAdd(&D.err[14], 1); if (TS == 128) atomicAdd(&D.err[15], 1); }
 #endif
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
@@ -831,9 +836,9 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             // processed order writes its slot, so what a destination bucket reads is always of this episode
             const int rel = wait + rr.w;
             const int d = rel <= 0 ? 1 : ticks_until_fast(S, rel);
-            if (has && !(abl & 1)) D.arr[(size_t)slot * S.R + r] = matched ? pull_entry(vid, t + d) : pull_reject(t);
+            if (has && !(abl & 1)) D.arr[arr_index(S.R, slot, r)] = matched ? pull_entry(vid, t + d) : pull_reject(t);
 #ifdef VDS_PROF
-            if (has && (abl & 65536)) reinterpret_cast<unsigned *>(D.ring_min)[(size_t)slot * S.R + r] = (unsigned)vid;      // the slot store once more (shadow table)
+            if (has && (abl & 65536)) reinterpret_cast<unsigned *>(D.ring_min)[arr_index(S.R, slot, r)] = (unsigned)vid;      // the slot store once more (shadow table)
 #endif
         } else if (matched && !(abl & 1)) {
             // :954-960  arrival = RealExpTime + wait + RoadCost(pickup, delivery), entered into the destination's arrival table
@@ -895,9 +900,13 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 // TABMAX: entries of a row's LDS table = the longest list (after the slot's arrivals) the fast path takes: 128, or 256 (16 lanes per
 // replica and byte costs only: 16 table registers per lane like the 8-lane / 128-entry form, scheduled for 6 wavefronts per SIMD) -
 // what order days per replica run with: other days fill other clusters, and a row beyond the table holds up its wavefront
-template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB>
-__global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
+// ROWS: replicas per workgroup - 16, or 32 with one shared day at 8 lanes per replica (256 threads: half the workgroups, the cost
+// block / order records / candidate records staged once for twice the rows, and the prologue's chain of dependent loads - the
+// largest part of the kernel, profiles/r04/r04_ablate_dense.txt - paid once per 32 rows)
+template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS>
+__global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
+    static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8), "32-row workgroups: one shared day, 8 lanes per replica");
     const DenseArgs &S = P, &D = P;
 #ifdef VDS_PROF
     const int span_i = (((P.r_lo != 0 ? 1 : 0) * SPAN_TICKS + (t & (SPAN_TICKS - 1))) * SPAN_WAYS + (int)(blockIdx.x & (SPAN_WAYS - 1))) * 2;
@@ -907,7 +916,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
     if (DN_ABL & 512) return;
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     constexpr int RPW = WAVE / LPR;             // rows per wavefront
-    constexpr int NTHR = DN_ROWS * LPR;
+    constexpr int NTHR = ROWS * LPR;
     extern __shared__ int lds_dyn[];
     // dynamic LDS: order records int4[64] (DM == 2: pickup offsets u16[16][64]) | their arrival-slot indices int[64] | candidate records int2[DN_CAND] (both PULL only)
     //              | per-row tables [16][DN_TAB] u32 | cost block (row stride n_c + 1)
@@ -915,19 +924,19 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
     int *lds_slot = reinterpret_cast<int *>(lds_rec + (DM == 2 ? DN_ROWS * DN_ORDERS * 2 / 16 : DN_ORDERS));      // (DM == 2: the area holds u16 [16][64] pickup offsets)
     int2 *lds_drec = reinterpret_cast<int2 *>(lds_slot + (PULL ? DN_ORDERS : 0));
     unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
-    CT *lds_blk = reinterpret_cast<CT *>(tab_all + DN_ROWS * (TABMAX + DN_TPAD));
+    CT *lds_blk = reinterpret_cast<CT *>(tab_all + ROWS * (TABMAX + DN_TPAD));
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
     const int4 cd = S.cdesc_dense[blockIdx.x / nchunks];        // {n_c, byte offset of the block, cluster, 0}
     const int c = cd.z, nc = cd.x;
-    const int chunk = blockIdx.x % nchunks + (S.r_lo >> 4);      // (vds_run launches the tick per replica group)
+    const int row0 = S.r_lo + (int)(blockIdx.x % nchunks) * ROWS;      // (vds_run launches the tick per replica group: rows [r_lo, r_hi))
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lane_id();
     const int g = lane / LPR, lg = lane & (LPR - 1);
     const int p = t & 1;
-    const int rslot = chunk * DN_ROWS + wave * RPW + g;
-    const int r = (DM == 1 && S.rperm != nullptr) ? S.rperm[rslot] : rslot;
-    bool rowvalid = r >= 0 && r < S.R;
+    const int rslot = row0 + wave * RPW + g;
+    const int r = (DM == 1 && S.rperm != nullptr) ? S.rperm[rslot < S.r_hi ? rslot : S.r_lo] : rslot;
+    bool rowvalid = rslot < S.r_hi && r >= 0 && r < S.R;
     unsigned short *pick = reinterpret_cast<unsigned short *>(lds_rec) + (wave * RPW + g) * DN_ORDERS;      // DM == 2: the row's pickup rows (the lds_rec area, 2 KB)
 #ifdef VDS_PROF
     const bool prof = (g_ablate & 128) != 0;
@@ -963,7 +972,7 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
         }
     } else if (DM == 1) {
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
-        const int r0 = chunk * DN_ROWS;         // (a group's first slot is never padding)
+        const int r0 = row0;                    // (a group's first slot is never padding)
         const int rd = S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1);
         const int4 dd = S.replica_desc[rd];
         rowvalid = rowvalid && t < dd.z;
@@ -982,13 +991,11 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
         now = dd.y + t * S.tick_minutes;
         qb = dd.w;
     } else {
-        q0 = S.bkt_off[(size_t)t * S.C + c];
-        k = S.bkt_off[(size_t)t * S.C + c + 1] - q0;
+        // one shared day: the bucket's descriptor sits next to the cluster's (same index, independent scalar loads)
+        const int4 td = S.tdesc[(size_t)t * S.C + blockIdx.x / nchunks];
+        q0 = td.x; k = td.y;
         now = S.now0 + t * S.tick_minutes;
-        if (PULL) {
-            clo = S.d_first[(size_t)max(t - S.pull_W, 0) * S.C + c];
-            n = S.d_first[(size_t)(t + 1) * S.C + c] - clo;
-        }
+        if (PULL) { clo = td.z; n = td.w; }
     }
     const size_t b = (size_t)c * S.R + (rowvalid ? r : 0);
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
@@ -1009,20 +1016,21 @@ __global__ __launch_bounds__(DN_ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR 
     if (PULL && wg_ok) {
         // the candidates' raw entries; those that say "slot t" are parked in the row's table, packed in candidate order (position
         // among the group's lanes from the ballot of the step): raw entry in tab[i], candidate index in tab[DN_TH + i]
-        const unsigned *ar = D.arr + (size_t)(clo - qdb) * S.R + (rowvalid ? r : 0);
+        const unsigned *ar = D.arr + arr_index(S.R, clo - qdb, rowvalid ? r : 0);      // slot s of this row: ar[s * R]
         const unsigned never = pull_reject(t - 1);          // (a byte slot t does not have)
         const int gsh = lane & ~(LPR - 1);
         int Ac = 0;
-        for (int i0 = 0; i0 < n; i0 += 4 * LPR) {          // four loads in flight per lane
-            unsigned v[4];
+        constexpr int NIF = 4;              // loads in flight per lane (8 at 8 lanes per replica - one round for up to 64 candidates - measured: 6.99 vs 6.92 ms per day, not kept)
+        for (int i0 = 0; i0 < n; i0 += NIF * LPR) {
+            unsigned v[NIF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NIF; ++u) {
                 const int idx = i0 + u * LPR + lg;
                 v[u] = never;
                 if (idx < n && rowvalid) v[u] = ar[(size_t)idx * S.R];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NIF; ++u) {
                 const int idx = i0 + u * LPR + lg;
                 const bool now_ = (v[u] & 0xFFu) == ((unsigned)t & 0xFFu);
                 const unsigned gm = (unsigned)(ballot(now_) >> gsh) & ((1u << LPR) - 1u);
@@ -1131,18 +1139,26 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     P.ring_cnt = D.ring_cnt; P.inbox = D.inbox; P.out = D.out; P.err = D.err;
     P.cdesc_dense = S.cdesc_dense; P.blk = S.blk8s ? reinterpret_cast<const char *>(S.blk8s) : reinterpret_cast<const char *>(S.blk32s);
     P.so_rec = S.so_rec; P.bkt_off = S.bkt_off; P.replica_desc = S.replica_desc; P.rperm = S.rperm;
-    P.R = S.R; P.C = S.C; P.H = S.H; P.idle_cap = S.idle_cap; P.ring_cap = S.ring_cap; P.in_cap = S.in_cap; P.Oq = S.Oq;
+    P.arr_slots = S.arr_slots; P.R = S.R; P.C = S.C; P.H = S.H; P.idle_cap = S.idle_cap; P.ring_cap = S.ring_cap; P.in_cap = S.in_cap; P.Oq = S.Oq;
     P.tick_minutes = S.tick_minutes; P.now0 = S.now0; P.tick_div_limit = S.tick_div_limit; P.tick_magic = S.tick_magic;
-    P.r_lo = r_lo; P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
+    P.r_lo = r_lo; P.r_hi = r_lo + (r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo); P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
     P.Sdev = S.self_dev; P.Ddev = S.state_dev; P.ring_min = D.ring_min;
+    P.tdesc = S.tdesc;
     P.arr = D.arr; P.so_slot = S.so_slot; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
-    const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R);
-    const int rchunks = (slots + DN_ROWS - 1) / DN_ROWS;
+    const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo;
+    const bool t256 = dense_tab256(S);
+    // 32-row workgroups: one shared day, 8 lanes per replica, byte costs, static arrival slots, at least 64 rows in the launch
+    const bool rows32 = S.n_days <= 1 && S.dense_lpr == 8 && !t256 && S.blk8s != nullptr && S.pull && slots >= 64 && DN_ROWS32;
+    const int rows = rows32 ? 32 : DN_ROWS;
+    const int rchunks = (slots + rows - 1) / rows;
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
     // (one order day per replica: the order-record area holds the rows' pickup offsets instead, u16 [16][64] = 2 KB)
-    const bool t256 = dense_tab256(S);
-    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + DN_ROWS * ((t256 ? 256 : DN_TAB) + DN_TPAD) * 4 + bb;
+    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + rows * ((t256 ? 256 : DN_TAB) + DN_TPAD) * 4 + bb;
+    if (rows32) {
+        emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, 32>, grid, dim3(32 * 8), lds, P, t);
+        return;
+    }
     if (t256) {
         if (S.pull) emit_dense_256<true>(e, S, P, t, grid, lds);
         else emit_dense_256<false>(e, S, P, t, grid, lds);
