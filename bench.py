@@ -105,7 +105,7 @@ def cpu_baseline_all_cores(w, init_rows, budget_s: float = 8.0, max_procs: int =
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed days (default 100: a 1.2 s timed region at configs[1])")
+    ap.add_argument("--steps", type=int, default=300, help="timed days (default 300: a 2.2 s timed region at configs[1])")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=1024, help="replicas PER GPU")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])

@@ -230,6 +230,34 @@ def test_plain_tick_groups_equal_the_oracle_and_are_the_default_from_256_replica
         env.close()
 
 
+@pytest.mark.parametrize("R,groups", [(70, 1), (112, 2), (112, 3), (129, 2), (200, 1)])
+def test_32_row_workgroups_ragged_replica_counts_and_group_boundaries(R, groups):
+    """One shared day at 8 lanes per replica from 64 replicas on: k_tick_dense takes 32 replicas per workgroup.  Replica counts
+    that are no multiple of 32 (the last workgroup's tail rows do not exist) and replica groups whose boundaries are multiples of
+    16 but not of 32 (a workgroup's tail rows belong to the NEXT group and must be left alone; the next group starts in the
+    middle of a 32-row block): every replica equals its oracle - per order, counters, list order - through vds_run (graph) and
+    through hooked steps."""
+    g = load_golden("tiny_kmeans")
+    day = synth_days(g, 1, seed=12)
+    init = _init(g, R, 500)
+    env = mk_env(g, R)
+    env.load_orders(*day[0])
+    assert env.main_kernel() == "k_tick_dense"
+    env.set_run_groups(groups, 0)
+    env.reset(init)
+    env.run(env.T)
+    env.sync()
+    _check(env, g, day, np.zeros(R, dtype=np.int32), init)
+    ref = env.counters().copy()
+    env.reset_again()
+    for _ in range(env.T):
+        env.step(); env.advance()
+    env.sync()
+    np.testing.assert_array_equal(env.counters(), ref)
+    _check(env, g, day, np.zeros(R, dtype=np.int32), init, replicas=[0, 31, 32, 47, 48, 63, 64, R - 1])
+    env.close()
+
+
 @pytest.mark.parametrize("name", ["tiny_kmeans_dfs2", "tiny_kmeans"])
 def test_day_maps_reloaded_on_one_handle_in_groups(name):
     """One handle, grouped runs: an interleaved replica -> day map (replicas stored regrouped by day, padded: more stored replicas

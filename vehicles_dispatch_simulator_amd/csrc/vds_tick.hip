@@ -95,9 +95,14 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
     int *mine = lds_dyn + wave * C;
     for (int i = threadIdx.x; i < RESET_WAVES * C; i += blockDim.x) lds_dyn[i] = 0;
     __syncthreads();
-    for (int base = v0; base < v1; base += WAVE) {
-        const int v = base + lane;
-        if (v < v1) atomicAdd(&mine[S.node2cluster[vn[v]]], 1);
+    for (int base = v0; base < v1; base += 4 * WAVE) {         // four chunks' dependent gathers (node, then cluster) in flight together
+        int nd[4], cl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int v = base + u * WAVE + lane; nd[u] = v < v1 ? vn[v] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cl[u] = nd[u] >= 0 ? S.node2cluster[nd[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (cl[u] >= 0) atomicAdd(&mine[cl[u]], 1);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -113,12 +118,24 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
         c4[0] = make_int4(0, 0, 0, 0); c4[1] = make_int4(0, 0, 0, 0); c4[2] = make_int4(0, 0, 0, 0); c4[3] = make_int4(0, 0, 0, 0);
     }
     __syncthreads();
+    // (the next chunk's gathers - node, then cluster and local index - are issued before this chunk is placed: the placement is a chain
+    // of ballots and an LDS cursor, the gathers two dependent trips to memory)
+    // two stages: the node of chunk i + 2, cluster / local index of chunk i + 1
+    int node_n = (v0 + lane < v1) ? vn[v0 + lane] : 0;
+    int node_nn = (v0 + WAVE + lane < v1) ? vn[v0 + WAVE + lane] : 0;
+    int cl_n = (v0 + lane < v1) ? S.node2cluster[node_n] : -1;
+    unsigned nl_n = (v0 + lane < v1) ? (unsigned)S.node_local[node_n] : 0u;
     for (int base = v0; base < v1; base += WAVE) {
         const int v = base + lane;
         const bool valid = v < v1;
-        const int node = valid ? vn[v] : 0;
-        const int cl = valid ? S.node2cluster[node] : -1;
-        const unsigned nl = valid ? (unsigned)S.node_local[node] : 0u;
+        const int cl = cl_n;
+        const unsigned nl = nl_n;
+        {
+            const bool v1x = v + WAVE < v1, v2x = v + 2 * WAVE < v1;
+            cl_n = v1x ? S.node2cluster[node_nn] : -1;
+            nl_n = v1x ? (unsigned)S.node_local[node_nn] : 0u;
+            node_nn = v2x ? vn[v + 2 * WAVE] : 0;
+        }
         // lanes of the same cluster, without a loop over the distinct clusters: one ballot per bit of the cluster id
         unsigned long long same = ballot(valid);
         for (int bit = 0; (1 << bit) < C; ++bit) {
