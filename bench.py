@@ -394,7 +394,10 @@ def main():
         fixed_actions = torch.stack([minus1, zeros_k, some_node_of[:K].repeat(R, 1)], dim=2).contiguous()
         ar = torch.arange(R, device="cuda", dtype=torch.int32)
         fixed_actions[:, 0, 0] = ar % env.C                   # one move per city and slot (skipped where the list is empty: idle_pos 0) ...
-        fixed_actions[:, 0, 2] = some_node_of[((ar + 97) % env.C).long()]      # ... to another cluster of that city
+        fixed_actions[:, 0, 2] = some_node_of[((ar + 97) % env.C).long()]      # ... to another cluster of that city,
+        fixed_back = fixed_actions.clone()                    # and back on the odd slots (no cluster fills up over the day)
+        fixed_back[:, 0, 0] = (ar + 97) % env.C
+        fixed_back[:, 0, 2] = some_node_of[(ar % env.C).long()]
         actions_static = torch.zeros((R, K, 3), dtype=torch.int32, device="cuda")
         pol_graph, graph_error = None, None
         try:
@@ -414,11 +417,11 @@ def main():
 
         def hooked_day(kind):
             env.reset_again()
-            for _ in range(T):
+            for ts in range(T):
                 env.step()
                 if kind == "fixed":
                     env.obs_torch(inflight=False)
-                    env.apply_dispatch_torch(fixed_actions)
+                    env.apply_dispatch_torch(fixed_actions if ts % 2 == 0 else fixed_back)
                 elif kind == "graph":
                     env.obs_torch(inflight=False)           # k_pack_obs into the static block (the policy reads idle, supply, demand)
                     pol_graph.replay()

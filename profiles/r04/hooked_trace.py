@@ -13,11 +13,13 @@ node_of = torch.tensor([int(np.flatnonzero(n2c == c)[0]) for c in range(env.C)],
 act = torch.full((R, K, 3), -1, dtype=torch.int32, device="cuda")
 act[:, :, 1] = 0
 act[:, :, 2] = node_of[:K][None, :]
-act[:, 0, 0] = torch.arange(R, device="cuda", dtype=torch.int32) % env.C
+ar = torch.arange(R, device="cuda", dtype=torch.int32)
+act[:, 0, 0] = ar % env.C
+act[:, 0, 2] = node_of[((ar + 97) % env.C).long()]
 for day in range(2):
     env.reset_again()
     for _ in range(env.T):
-        env.step(); env.obs_torch(); env.apply_dispatch_torch(act); env.advance()
+        env.step(); env.obs_torch(inflight=False); env.apply_dispatch_torch(act); env.advance()
 torch.cuda.synchronize()
 try:
     env.sync()

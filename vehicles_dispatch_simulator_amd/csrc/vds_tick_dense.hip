@@ -6,22 +6,28 @@
 // Dense layout (vds_device.h): idle entries are 4 bytes {veh << 8 | loc_local}, arrival-ring entries 8 bytes
 // {veh << 8 | dest_local, key}; half the bytes of the wide layout on the two tables a tick streams.
 //
-// Mapping.  A workgroup owns ONE cluster for 16 consecutive replicas ("rows"); the cluster's cost block - row stride n_c + 1,
-// the extra column holds the DEAD cost - and the bucket's order records are staged in LDS once.  A replica is advanced by a
-// group of LPR lanes (16, 8 or 4: 4 / 8 / 16 replicas per wavefront); lane l of a group holds list positions l*J .. l*J+J-1
-// (J = TS / LPR, table size TS = 32 / 64 / 128 chosen per wavefront).  What a lane keeps in registers during the match loop:
+// Mapping.  A workgroup owns ONE cluster for 16 consecutive replicas ("rows"; 32 with one shared order day at 8 lanes per replica);
+// the cluster's cost block - row stride n_c + 1, the extra column holds the DEAD cost - and the bucket's order records are staged
+// in LDS once.  A replica is advanced by a group of LPR lanes (8 or 16: 8 / 4 replicas per wavefront); lane l of a group holds
+// list positions l*J .. l*J+J-1 (J = TS / LPR, table size TS = 32 / 64 / 128 (/ 256 at 16 lanes) chosen per wavefront).  What a
+// lane keeps in registers during the match loop:
 //   e[J]     the packed entries (only read again by the results and the compaction),
 //   L[J/4]   their loc bytes, four per register.  A taken (or absent) entry's loc byte is n_c - the dead column - so it loses
 //            every comparison without a test in the loop and without a per-slot flag register.
 // Per order: J x (byte add + LDS byte read + shift-or) -> min3 tree -> DPP group minimum of (cost << 7 | position) = nearest
 // vehicle, ties to the lowest list position = the reference's first strict minimum (:932); the winner's byte is overwritten
 // with n_c by one v_bfi per packed register.
-// Arrivals of the slot (UpdateFunction) are ranked by 32-bit keys through LDS and appended behind the list IN LDS: the lanes
-// write their loaded chunks and the ranked arrivals into the row's table and read the merged chunks back, so no per-slot
-// select is needed.  After the loop the survivors are packed into the same table (order preserved, :963) and written back
-// with 16-byte stores.
-// Rows the tables cannot hold (> 128 entries, > 64 arrivals), rows with far arrivals and buckets with > 64 orders are finished
-// by the same wavefront with dense_bucket_slow (any size, straight from HBM).
+// Arrivals of the slot (UpdateFunction).  Order-carrying vehicles arrive through STATIC ARRIVAL SLOTS (vds_device.h): the
+// prologue loads the raw slots of the bucket's candidate orders (those whose arrival window covers slot t) and parks the ones
+// that say "slot t" in the row's LDS table, packed (ballot rank inside the lane group); dispatched vehicles (hooks) come through
+// the ring.  The slot's arrivals are ranked among themselves by their 32-bit dict-insertion keys and appended behind the list IN
+// LDS: the lanes write their loaded chunks and the ranked arrivals into the row's table and read the merged chunks back, so no
+// per-slot select is needed.  After the loop the survivors are packed into the same table (order preserved, :963) and written
+// back with 16-byte stores from the first changed chunk on.
+// Order days: DM = 0 one shared day (bucket descriptors from Static.tdesc: one scalar load), 1 one day per workgroup, 2 one day per
+// ROW (every replica its own order stream).
+// Rows the tables cannot hold (> 128 / 256 entries, > 64 arrivals), rows with far arrivals and buckets with > 64 orders are
+// finished by the same wavefront with dense_bucket_slow (any size, straight from HBM).
 #include "vds_kernels_common.h"
 #include <algorithm>
 
@@ -614,6 +620,7 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
         if (w == CNT_VALUE) d = vsum;
         if (w == CNT_EVALS) d = evals;
         if (w == CNT_ARRIVALS) d = A;
+        // (fire-and-forget 64-bit atomics instead of preloading the eight words: measured, 6.83 vs 6.82 ms per day - no difference)
         if (LPR >= CNT_WORDS) { if (w < CNT_WORDS && d != 0) cnt[w] = cntv + d; }
         else if (d != 0) cnt[w] += d;
     }
@@ -894,17 +901,22 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 #ifndef DN_MIN_WAVES4
 #define DN_MIN_WAVES4 4
 #endif
+// 16 lanes per replica with 256-entry tables: 72 VGPRs / 7 wavefronts per SIMD (2 spilled registers; 22 KB of LDS per workgroup: 7 per
+// CU).  One box, 16 order days: 8.19 vs 8.82 ms per day scheduled for 6; the 8-lane form the other way round (6.92 vs 6.82 with 30 spills)
+#ifndef DN_MIN_WAVES256
+#define DN_MIN_WAVES256 7
+#endif
 
 #define DN_CAND 128          // static arrival slots (candidates) per bucket per tick the fast path takes (= DN_TAB: they are parked in the row's table)
 
 // TABMAX: entries of a row's LDS table = the longest list (after the slot's arrivals) the fast path takes: 128, or 256 (16 lanes per
-// replica and byte costs only: 16 table registers per lane like the 8-lane / 128-entry form, scheduled for 6 wavefronts per SIMD) -
+// replica and byte costs only: 16 table registers per lane like the 8-lane / 128-entry form, scheduled for 7 wavefronts per SIMD) -
 // what order days per replica run with: other days fill other clusters, and a row beyond the table holds up its wavefront
 // ROWS: replicas per workgroup - 16, or 32 with one shared day at 8 lanes per replica (256 threads: half the workgroups, the cost
 // block / order records / candidate records staged once for twice the rows, and the prologue's chain of dependent loads - the
 // largest part of the kernel, profiles/r04/r04_ablate_dense.txt - paid once per 32 rows)
 template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS>
-__global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES8 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
+__global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
     static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8), "32-row workgroups: one shared day, 8 lanes per replica");
     const DenseArgs &S = P, &D = P;
