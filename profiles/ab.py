@@ -47,7 +47,12 @@ def main():
     res = {l: [] for l in a.libs}
     for _ in range(a.rounds):
         for lib in a.libs:
-            env = dict(os.environ, VDS_LIB=lib)
+            # "path@NAME=VALUE[@NAME=VALUE..]": the same library under other environment switches
+            parts = lib.split("@")
+            env = dict(os.environ, VDS_LIB=parts[0])
+            for kv in parts[1:]:
+                k, v = kv.split("=", 1)
+                env[k] = v
             out = subprocess.run([sys.executable, "-c", WORKER, a.workload, str(a.replicas), str(a.days), str(a.distinct)], env=env,
                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             if out.returncode:

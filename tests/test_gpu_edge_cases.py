@@ -326,3 +326,37 @@ def test_dense_tick_switches_to_wide_rows_when_the_slow_path_is_crowded(monkeypa
         if adapt == "1": assert slow[-1] == 0 and slow[-2] == 0, slow
         else: assert slow[-1] == slow[0], slow
         env.close()
+
+
+@pytest.mark.parametrize("fg", [0, 5])
+@pytest.mark.parametrize("shape", [(300, 12, 150, 3), (300, 12, 1, 2), (700, 37, 5000, 5), (4139, 192, 10000, 3)])
+def test_reset_builds_the_same_lists_staged_and_unstaged(shape, fg, monkeypatch):
+    """InitVehiclesIntoCluster (:249-258): every cluster's idle list = its vehicles in vehicle order.  k_reset_staged (lists built
+    in LDS, written as runs) and k_reset_fast (VDS_RESET_UNSTAGED=1: every entry stored where it belongs) against numpy, on the
+    dense (force_generic 0) and the wide layout (5); then a day from each, identical results."""
+    from vehicles_dispatch_simulator_amd import workloads
+    N, Cn, V, R = shape
+    w = workloads.tiny(N=N, C=Cn, vehicles=V, orders=1500, seed=11 + V)
+    init = w.vehicle_nodes(R)
+    n2c = np.asarray(w.city.node2cluster)
+    outs = []
+    for unstaged in ("0", "1"):
+        monkeypatch.setenv("VDS_RESET_UNSTAGED", unstaged)
+        env = w.make_env(R, force_generic=fg)
+        env.reset(init)
+        for r in range(R):
+            ls = env.lists(r)
+            cl = n2c[init[r]]
+            for c in range(Cn):
+                exp = np.nonzero(cl == c)[0]
+                a, b = ls["idle_off"][c], ls["idle_off"][c + 1]
+                np.testing.assert_array_equal(ls["idle_veh"][a:b], exp, err_msg="replica %d cluster %d" % (r, c))
+                np.testing.assert_array_equal(ls["idle_node"][a:b], init[r][exp])
+        env.run(env.T)
+        env.reset_again()
+        env.run(env.T)
+        outs.append((env.orders(), env.counters()))
+        env.close()
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(outs[0][0][k], outs[1][0][k])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])

@@ -798,16 +798,31 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
 //      (:954-960) for every order, counters, order-preserving compaction of the lists (:963), headers.
 // Preconditions (vds_api dfs_hybrid_ok): the fast kernel's (fast_ok: costs < 2^23 and never above the pickup window, blocks fit
 // LDS), one order day per workgroup chunk, < 65535 orders per slot, V < 65536, C <= 2047 nodes per cluster, LDS footprint.
+#ifndef WK_THREADS
 #define WK_THREADS 256
+#endif
 #define WK_WAVES (WK_THREADS / WAVE)
+#ifndef WK_MIN_WAVES
+#define WK_MIN_WAVES 1                      // wavefronts per SIMD the kernel is compiled for (register cap)
+#endif
+#ifndef WK_PRIO
+#define WK_PRIO 0                           // s_setprio of wavefront 0 while it serves the chain of dry orders
+#endif
 #define WK_FREE 0xFFFFu
 #define WK_K 3                              // candidates kept per scanned dry order (2-4 measure the same; 8 costs 2 % in the extraction loop)
 #define WK_NS 32                            // pool of scan records (the second order of a paired scan may wait there for a while):
 #define WK_NS_MIN 8                         // Static.walk_pool of them, as many as keep the workgroup within a quarter of a CU's LDS
 #define WK_REC (4 * WK_K + 6)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
-                                            // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, 0},
+                                            // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, list position},
                                             // the number of candidates; and for the first candidate, if an own-cluster order a holds it: a, the
                                             // two entries {cost << 16 | position} a would pick instead, whether those are all it could pick; pad
+#ifndef WK_REDO_PRE
+#define WK_REDO_PRE 1                       // the scan also works out what the holder of its first candidate would pick instead
+#endif
+#ifndef WK_G
+#define WK_G 2                              // dry orders of one bucket that share a scan (consecutive sorted positions), at most
+#endif
+static_assert(WK_G >= 1 && WK_G <= 3, "dfs_scan is instantiated for 1, 2 and 3 orders per scan");
 #ifndef WK_PAIR_SPAN
 #define WK_PAIR_SPAN 65536                  // a paired scan takes the bucket's next order only if its rank is at most this far ahead
 #endif
@@ -1041,14 +1056,14 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                 const int u = __shfl(moj[jb], j & 63, WAVE), u2 = __shfl((int)ck[o][jb], j & 63, WAVE);
                 mo = (j >> 6) == jb ? u : mo; ckw = (j >> 6) == jb ? u2 : ckw;
             }
-            if (lane < nl) reinterpret_cast<int4 *>(rec[o])[lane] = make_int4(mykey, mo + bb * WAVE + mywl, ckw, 0);
+            if (lane < nl) reinterpret_cast<int4 *>(rec[o])[lane] = make_int4(mykey, mo + bb * WAVE + mywl, ckw, bb * WAVE + mywl);
             // the first candidate is the likely winner.  If an own-cluster order a holds it (taken later than this order), stealing
             // it makes a pick again (k_dfs_walk, redo chain): what a would pick - the two best entries of its cluster alive at ITS
             // time (stamp > a; the same shrinking-set argument makes the first of them still alive the re-pick) - is worked out
             // here, two HBM levels off the walk's critical path.  Lists of more than 64 entries: left to the walk.
             const int sidx0 = rdlane(mo + bb * WAVE + mywl, 0), wcl = rdlane(ckw, 0) & 0xFFFF;
             int a0 = -1, r1 = IMAX, r2 = IMAX, complete = 0;
-            if (nl > 0) {
+            if (WK_REDO_PRE && nl > 0) {
                 const int st0 = (int)st_l[sidx0];
                 const int m0w = m0_l[wcl];
                 if (st0 != (int)WK_FREE && st0 > rho[o] && m0w <= WAVE) {
@@ -1087,7 +1102,7 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
 
 // JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
 template <bool U8, int JB>
-__global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int t) {
+__global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
     const int C = S.C;
@@ -1116,6 +1131,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     unsigned short *st_l = reinterpret_cast<unsigned short *>(lg_l + 4 * WAVE);       // [V] stamps
     __shared__ int s_ev;                  // evaluations of the dry orders
     __shared__ int s_nlog;                // steals (entries of the replica's steal log)
+    __shared__ int s_nmid;                // lists of 65 .. 128 entries to compact
 #ifdef WKDEBUG
     __shared__ int s_dbg;                 // (make dbg) the dry orders' evaluations counted by the walk itself, against the closed form
 #endif
@@ -1155,7 +1171,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; ls_l[c] = own << 16; tk_l[c] = 0;
     }
     for (int w = threadIdx.x; w < nwords; w += WK_THREADS) { dry_bits[w] = 0u; clm_bits[w] = 0u; }
-    if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; s_nlog = 0; }
+    if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; s_nlog = 0; s_nmid = 0; }
     if (threadIdx.x < WK_NS) s_slot[threadIdx.x] = 0;
     __syncthreads();
     PROF_STAMP(24);
@@ -1201,16 +1217,21 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
     //      records are made by wavefronts 1..3, which scan the dry orders up to WK_NS ahead of the walk, in rank order, claiming
     //      them through s_cursor (dfs_scan: why a scan against a moving state is exact).  Wavefront 0 scans itself only when
     //      every kept candidate has died, or when a redo made an order dry that the cursor had already passed.
-    auto next_dry = [&](int from) -> int {
-        int best = IMAX;
-        for (int w = (from >> 5) + lane; w < nwords; w += WAVE) {
-            unsigned bits = (unsigned)lds_load(reinterpret_cast<const int *>(&dry_bits[w]));
+    auto next_dry = [&](int from) -> int {       // (the words ascend with the lanes: the first lane with a bit set holds the minimum)
+        for (int w0 = from >> 5; w0 < nwords; w0 += WAVE) {
+            const int w = w0 + lane;
+            unsigned bits = w < nwords ? (unsigned)lds_load(reinterpret_cast<const int *>(&dry_bits[w])) : 0u;
             if (w == (from >> 5)) bits &= 0xFFFFFFFFu << (from & 31);
-            if (bits != 0u) { best = w * 32 + __ffs((int)bits) - 1; break; }
+            const unsigned long long nz = ballot(bits != 0u);
+            if (nz != 0ull) {
+                const int l = __ffsll((long long)nz) - 1;
+                return (w0 + l) * 32 + __ffs(rdlane((int)bits, l)) - 1;
+            }
         }
-        return wave_min_i32(best);
+        return IMAX;
     };
     if (wave == 0) {
+        if (WK_PRIO) __builtin_amdgcn_s_setprio(WK_PRIO);
         int nlog = 0;
         int4 *slog = D.slog + (size_t)r * mto;
         int rho = next_dry(0);
@@ -1221,7 +1242,8 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         unsigned long long p_wait = 0, p_chain = 0, p_seg[4] = {0, 0, 0, 0}, p_cnt[4] = {0, 0, 0, 0};
 #endif
         while (rho != IMAX) {
-            const int q = tq0 + (int)qr_l[rho];
+            // (the order's sorted position - an LDS round trip - only where a scan by this wavefront needs it)
+            auto q_of = [&]() -> int { return tq0 + (int)qr_l[rho]; };
             // the order's record: in the pool (ready, or being filled), still to be claimed (wait), or passed over (scan here)
             const unsigned *rec = slot_l;
             int slot = -1;
@@ -1252,6 +1274,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (slot >= 0) {
                 rec = pool_l + slot * WK_REC;
             } else {
+                const int q = q_of();
                 dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
                 wg_order();
 #ifdef VDS_PROF
@@ -1269,6 +1292,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             }
             unsigned long long okb = ballot(stv > rho);
             if (nl > 0 && okb == 0ull) {           // every kept candidate has been taken since: scan again, on the state as it is
+                const int q = q_of();
                 dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
                 wg_order();
                 e = make_int4(IMAX, 0, 0, 0);
@@ -1284,6 +1308,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             PSEG(0);
 #ifdef WKDEBUG
             {   // reference: the alive counts of the visited clusters as they stand now
+                const int q = q_of();
                 int alive = 0;
                 for (int jb = 0; jb < JB; ++jb) {
                     const unsigned v = S.so_vis[(size_t)q * S.seq_pad + jb * WAVE + lane];
@@ -1296,13 +1321,12 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (okb != 0ull) {                     // (no candidate at all: nothing was alive when the order was scanned - rejected, :973;
                                                    //  the fast kernel has written that result already)
                 const int first = __ffsll((long long)okb) - 1;
-                const int key = rdlane(e.x, first), idx = rdlane(e.y, first), ckw = rdlane(e.z, first);
+                const int key = rdlane(e.x, first), idx = rdlane(e.y, first), ckw = rdlane(e.z, first), wpos = rdlane(e.w, first);
                 int a = rdlane(stv, first);                 // the winner's stamp: free, or the own-cluster order that took it later
                 const int wc = key >> 16;
                 if ((long long)wc <= S.reject_threshold) {
                     const int wcl = ckw & 0xFFFF;
-                    const int mo = moff_l[wcl];
-                    const int wpos = idx - mo;
+                    const int mo = idx - wpos;              // (= moff_l[wcl]: the record carries the position, no LDS round trip)
                     WKCHK(wcl < C && wpos >= 0 && wpos < m0_l[wcl < C ? wcl : 0], 4, wcl, wpos);
                     // the steal: stamp, and a log entry {rank, cluster | k, result} - staged in LDS and written out 64 at a time (an
                     // HBM store per served order would cost this wavefront a round trip at its next register reuse); the
@@ -1422,6 +1446,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
         if (lane < (nlog & (WAVE - 1)))
             slog[(nlog & ~(WAVE - 1)) + lane] = make_int4(lg_l[4 * lane], lg_l[4 * lane + 1], lg_l[4 * lane + 2], lg_l[4 * lane + 3]);
         if (lane == 0) { s_nlog = nlog; lds_release(&s_done, 1); }
+        if (WK_PRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef WKDEBUG
         if (lane == 0) s_dbg = dbg_ev;
 #endif
@@ -1465,51 +1490,70 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             won = __builtin_amdgcn_readfirstlane(won);
             if (!won) continue;
             const int q = tq0 + (int)qr_l[b];
-            // the next order of the same bucket (dry as well: the dry orders of a bucket are its last ones) shares the scan,
-            // pool permitting
-            int b2nd = -1, slot2 = -1;
-            int pn[2] = {0, 0};
-            if (q + 1 < tq1 && popc64(freem) >= 2) {
-                const int4 ra = S.so_rec[q], rb = S.so_rec[q + 1];
-                pn[0] = S.so_pnode[q]; pn[1] = S.so_pnode[q + 1];
-                if (((unsigned)ra.z >> 16) == ((unsigned)rb.z >> 16)) {
-                    const int r2 = (int)rq_l[q + 1 - tq0];
-                    const int s2 = __ffsll((long long)freem) - 1;
-                    int won2 = 0;
-                    if (lane == 0 && r2 - b <= WK_PAIR_SPAN && lds_cas(&s_slot[s2], 0, (r2 << 2) | 1)) {
-                        won2 = (atomicOr(&clm_bits[r2 >> 5], 1u << (r2 & 31)) & (1u << (r2 & 31))) ? 0 : 1;
-                        if (!won2) lds_release(&s_slot[s2], 0);
-                    }
-                    if (__builtin_amdgcn_readfirstlane(won2)) { b2nd = r2; slot2 = s2; }
+            // the next orders of the same bucket (dry as well: the dry orders of a bucket are its last ones; consecutive sorted
+            // positions, ascending ranks) share the scan, up to WK_G of them, pool permitting (one free record is left to the others)
+            int rk[WK_G], sl[WK_G], pn[WK_G];
+            int g = 1;
+            rk[0] = b; sl[0] = slot; pn[0] = S.so_pnode[q];
+#pragma unroll
+            for (int o = 1; o < WK_G; ++o) { rk[o] = -1; sl[o] = -1; pn[o] = 0; }
+            if (WK_G > 1 && q + 1 < tq1 && popc64(freem) >= 2) {
+                const int4 ra = S.so_rec[q];
+                int bk[WK_G];
+#pragma unroll
+                for (int o = 1; o < WK_G; ++o) {
+                    const int qo = min(q + o, tq1 - 1);
+                    bk[o] = (int)((unsigned)S.so_rec[qo].z >> 16);
+                    pn[o] = S.so_pnode[qo];
                 }
-            } else {
-                pn[0] = S.so_pnode[q];
+                bool go = true;
+#pragma unroll
+                for (int o = 1; o < WK_G; ++o) {
+                    go = go && q + o < tq1 && bk[o] == (int)((unsigned)ra.z >> 16) && popc64(freem) >= 2;
+                    if (go) {
+                        const int r2 = (int)rq_l[q + o - tq0];
+                        const int s2 = __ffsll((long long)freem) - 1;
+                        int won2 = 0;
+                        if (lane == 0 && r2 - b <= WK_PAIR_SPAN && lds_cas(&s_slot[s2], 0, (r2 << 2) | 1)) {
+                            won2 = (atomicOr(&clm_bits[r2 >> 5], 1u << (r2 & 31)) & (1u << (r2 & 31))) ? 0 : 1;
+                            if (!won2) lds_release(&s_slot[s2], 0);
+                        }
+                        if (__builtin_amdgcn_readfirstlane(won2)) { rk[o] = r2; sl[o] = s2; freem &= freem - 1ull; g = o + 1; }
+                        else go = false;
+                    }
+                }
             }
 #ifdef VDS_PROF
             const unsigned long long p_s0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#define WK_PACC , prof ? p_acc : nullptr
+#else
+#define WK_PACC
 #endif
-            if (b2nd >= 0) {
-                const int rho2[2] = {b, b2nd};
-                unsigned *const rec2[2] = {pool_l + slot * WK_REC, pool_l + slot2 * WK_REC};
-                dfs_scan<U8, JB, 2>(S, D, r, q, rho2, pn, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2
-#ifdef VDS_PROF
-                                    , prof ? p_acc : nullptr
+#if WK_G >= 3
+            if (g == 3) {
+                const int rho3[3] = {rk[0], rk[1], rk[2]}, pn3[3] = {pn[0], pn[1], pn[2]};
+                unsigned *const rec3[3] = {pool_l + sl[0] * WK_REC, pool_l + sl[1] * WK_REC, pool_l + sl[2] * WK_REC};
+                dfs_scan<U8, JB, 3>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 WK_PACC);
+            } else
 #endif
-                                    );
-                wg_order();
-                if (lane == 0) { lds_release(&s_slot[slot], (b << 2) | 2); lds_release(&s_slot[slot2], (b2nd << 2) | 2); }
-#ifdef VDS_PROF
-                if (prof) p_acc[6] += 1;
+#if WK_G >= 2
+            if (g == 2) {
+                const int rho2[2] = {rk[0], rk[1]}, pn2[2] = {pn[0], pn[1]};
+                unsigned *const rec2[2] = {pool_l + sl[0] * WK_REC, pool_l + sl[1] * WK_REC};
+                dfs_scan<U8, JB, 2>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 WK_PACC);
+            } else
 #endif
-            } else {
-                dfs_scan<U8, JB>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, pool_l + slot * WK_REC
-#ifdef VDS_PROF
-                                 , prof ? p_acc : nullptr
-#endif
-                                 );
-                wg_order();
-                if (lane == 0) lds_release(&s_slot[slot], (b << 2) | 2);
+            {
+                dfs_scan<U8, JB>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, pool_l + slot * WK_REC WK_PACC);
             }
+            wg_order();
+            if (lane == 0) {
+#pragma unroll
+                for (int o = 0; o < WK_G; ++o) if (o < g) lds_release(&s_slot[sl[o]], (rk[o] << 2) | 2);
+            }
+#ifdef VDS_PROF
+            if (prof && g > 1) p_acc[6] += 1;
+#endif
 #ifdef VDS_PROF
             if (prof) { p_scan += __builtin_amdgcn_s_memtime() - p_s0; p_n += 1; }
 #endif
@@ -1597,7 +1641,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                     qd4[u] = 0; qe4[u] = 0; n4[u] = 0;
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) cjs[u][jb] = 0;
-                    while (dm != 0ull && (taken & (WK_WAVES - 1)) != wave) { dm &= dm - 1ull; ++taken; }
+                    while (dm != 0ull && (taken % WK_WAVES) != wave) { dm &= dm - 1ull; ++taken; }
                     if (dm != 0ull) {
                         const int l = __ffsll((long long)dm) - 1;
                         dm &= dm - 1ull; ++taken;
@@ -1666,15 +1710,25 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             rec[u] = make_int4(0, 0, 0, 0); pr[u] = make_int2(-1, -1);
             if (q < tq1) { rec[u] = S.so_rec[q]; pr[u] = out_r[q]; }
         }
+        // ring positions of the arrivals: the counter atomics travel together with the vehicle-id gathers (they need the order's
+        // record and its wait, not the vehicle), so the entries' stores are the third - not the fourth ... (2 + orders)-th - HBM
+        // level of this pass.  rp: -1 no near arrival (unmatched, or the far inbox: post_arrival), else position | slots ahead << 16
+        int rp[WK_RES];
 #pragma unroll
         for (int u = 0; u < WK_RES; ++u) {
-            veh[u] = -1;
+            veh[u] = -1; rp[u] = -1;
             if (pr[u].x != -1) {
                 const int vc = (int)((unsigned)pr[u].x >> 16), vpos = pr[u].x & 0xFFFF;
 #ifdef WKDEBUG
                 if (vc >= C || vpos >= m0_l[vc < C ? vc : 0]) { printf("walk resolve: r %d t %d q %d (rank %d) pr %x %d vc %d vpos %d\n", r, t, qq + u * WK_THREADS - tq0, (int)S.so_rank[qq + u * WK_THREADS], pr[u].x, pr[u].y, vc, vpos); pr[u].x = -1; continue; }
 #endif
                 veh[u] = (int)D.idle[((size_t)vc * S.R + r) * S.idle_cap + vpos].x;
+                const int rel = pr[u].y + rec[u].w;
+                const int d = rel <= 0 ? 1 : ticks_until<false>(S, rel);
+                if (d < S.H) {
+                    const size_t i = ((size_t)((t + d) & (S.H - 1)) * S.C + (rec[u].z & 0xFFFF)) * S.R + r;
+                    rp[u] = (atomicAdd(&D.ring_cnt[i], 0x10001) & 0xFFFF) | (d << 16);
+                }
             }
         }
 #pragma unroll
@@ -1687,12 +1741,21 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
                 atomicAdd(&cl[CNT_REJECTS], 1);
             } else {
                 out_r[q] = make_int2(veh[u], pr[u].y);
-                post_arrival(S, D, rec[u].z & 0xFFFF, r, t, now, veh[u], rec[u].x, now + pr[u].y + rec[u].w, 0, (int)((unsigned)rec[u].y >> 16));
+                const int dl = (int)((unsigned)rec[u].y >> 16);
+                if (rp[u] >= 0) {
+                    const int pos = rp[u] & 0xFFFF;
+                    const size_t i = ((size_t)((t + (rp[u] >> 16)) & (S.H - 1)) * S.C + (rec[u].z & 0xFFFF)) * S.R + r;
+                    if (pos >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
+                    else D.ring[i * S.ring_cap + pos] = make_int4(veh[u], rec[u].x, now + pr[u].y + rec[u].w, meta_pack(t, 0, dl));
+                } else post_arrival(S, D, rec[u].z & 0xFFFF, r, t, now, veh[u], rec[u].x, now + pr[u].y + rec[u].w, 0, dl);
                 atomicAdd(&cl[CNT_WAIT], pr[u].y);
                 atomicAdd(&cl[CNT_VALUE], rec[u].w);
             }
         }
     }
+    // lists of 65 .. 128 entries that lost something: their clusters, for the batched compaction below (tk_l is dead)
+    for (int c = threadIdx.x; c < C; c += WK_THREADS)
+        if (m0_l[c] > WAVE && m0_l[c] <= 2 * WAVE && sc_l[c] != m0_l[c]) tk_l[atomicAdd(&s_nmid, 1)] = c;
     __syncthreads();
     PROF_STAMP(27);
     // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = free entries, node words clean)
@@ -1714,14 +1777,42 @@ __global__ __launch_bounds__(WK_THREADS) void k_dfs_walk(Static S, State D, int 
             if (keep4[u]) D.idle[((size_t)(c + u * WK_WAVES) * S.R + r) * S.idle_cap + popc64(kb & lanemask_lt())] = e4[u];
         }
     }
+    {   // lists of 65 .. 128 entries: six in flight per wavefront, both chunks of a list read before either is written
+        const int nmid = s_nmid;
+        for (int i0 = wave * 6; i0 < nmid; i0 += 6 * WK_WAVES) {
+            uint2 e6[6][2];
+            bool k6[6][2];
+            int c6[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                c6[u] = i0 + u < nmid ? tk_l[i0 + u] : -1;
+                const int cu = max(c6[u], 0);
+                const int mo = moff_l[cu], m0 = m0_l[cu];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = h * WAVE + lane;
+                    k6[u][h] = c6[u] >= 0 && i < m0 && (unsigned)st_l[mo + min(i, m0 - 1)] == WK_FREE;
+                    e6[u][h] = make_uint2(0u, 0u);
+                    if (k6[u][h]) e6[u][h] = D.idle[((size_t)cu * S.R + r) * S.idle_cap + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const unsigned long long kb0 = ballot(k6[u][0]), kb1 = ballot(k6[u][1]);
+                uint2 *idle = D.idle + ((size_t)max(c6[u], 0) * S.R + r) * S.idle_cap;
+                if (k6[u][0]) idle[popc64(kb0 & lanemask_lt())] = e6[u][0];
+                if (k6[u][1]) idle[popc64(kb0) + popc64(kb1 & lanemask_lt())] = e6[u][1];
+            }
+        }
+    }
     PROF_STAMP(28);
-    {   // the lists of more than 64 entries that lost something (rare): found by a vote, dealt round-robin to the wavefronts
+    {   // the lists of more than 128 entries that lost something (rare): found by a vote, dealt round-robin to the wavefronts
         int met = 0;
         for (int cb = 0; cb < C; cb += WAVE) {
             const int cme = cb + lane;
-            unsigned long long lm = ballot(cme < C && m0_l[min(cme, C - 1)] > WAVE && sc_l[min(cme, C - 1)] != m0_l[min(cme, C - 1)]);
+            unsigned long long lm = ballot(cme < C && m0_l[min(cme, C - 1)] > 2 * WAVE && sc_l[min(cme, C - 1)] != m0_l[min(cme, C - 1)]);
             for (; lm != 0ull; lm &= lm - 1ull, ++met) {
-                if ((met & (WK_WAVES - 1)) != wave) continue;
+                if ((met % WK_WAVES) != wave) continue;
                 const int c = cb + __ffsll((long long)lm) - 1;
                 const int mo = moff_l[c], m0 = m0_l[c];
                 uint2 *idle = D.idle + ((size_t)c * S.R + r) * S.idle_cap;

@@ -152,6 +152,106 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
         wave_fence();
     }
 }
+// k_reset_staged: k_reset_fast with the lists BUILT IN LDS and written out as runs.  k_reset_fast stores every entry where it
+// belongs as soon as its position is known: 4-byte stores, each into a list of its own, that leave the L2 as one 32-byte write
+// request per vehicle (PMC, configs[4]: 12.6 M write requests, 523 MB, for 76 MB of lists and headers).  Here pass B places the
+// entries into an LDS image of the replica's lists laid back to back (base of cluster c = vehicles of the clusters before it), and
+// the lists then leave as contiguous runs, one wavefront per list.  Needs (RESET_WAVES + 1) C + 1 + V (dense layout: one packed
+// word per vehicle) or + 2 V (wide layout) ints of LDS; cities beyond that keep k_reset_fast.
+template <bool DENSE>
+__global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_staged(Static S, State D, const int *veh_node) {
+    extern __shared__ int lds_dyn[];
+    const int r = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const int C = S.C;
+    const int seg = (((S.V + RESET_WAVES - 1) / RESET_WAVES) + WAVE - 1) / WAVE * WAVE;
+    const int ext = S.int2ext ? S.int2ext[r] : r;
+    const int nveh = ext < 0 ? 0 : S.V;
+    const int v0 = min(nveh, wave * seg), v1 = min(nveh, v0 + seg);
+    const int *vn = veh_node + (size_t)(ext < 0 ? 0 : ext) * S.V;
+    int *mine = lds_dyn + wave * C;
+    int *base_l = lds_dyn + RESET_WAVES * C;            // [C + 1] first staged entry of the cluster
+    unsigned *stage = reinterpret_cast<unsigned *>(base_l + C + 1);       // [V] packed entries, or [V] vehicles + [V] node indices
+    for (int i = threadIdx.x; i < RESET_WAVES * C; i += blockDim.x) lds_dyn[i] = 0;
+    __syncthreads();
+    for (int base = v0; base < v1; base += 4 * WAVE) {
+        int nd[4], cl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int v = base + u * WAVE + lane; nd[u] = v < v1 ? vn[v] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cl[u] = nd[u] >= 0 ? S.node2cluster[nd[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (cl[u] >= 0) atomicAdd(&mine[cl[u]], 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        int run = 0;
+        for (int w = 0; w < RESET_WAVES; ++w) { const int tw = lds_dyn[w * C + c]; lds_dyn[w * C + c] = run; run += tw; }
+        base_l[c] = run;                                 // (the cluster's total; turned into its base below)
+        int total = run;
+        if (total > S.idle_cap) { atomicOr(&D.err[0], ERR_IDLE_CAP); total = S.idle_cap; }
+        const size_t b = (size_t)c * S.R + r;
+        int4 *h4 = reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS);
+        h4[0] = make_int4(total, 0, 0, 0);
+        h4[1] = make_int4(0, 0, 0, 0);
+        int4 *c4 = reinterpret_cast<int4 *>(D.cnt + b * CNT_WORDS);
+        c4[0] = make_int4(0, 0, 0, 0); c4[1] = make_int4(0, 0, 0, 0); c4[2] = make_int4(0, 0, 0, 0); c4[3] = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (wave == 0) {            // exclusive prefix of the totals
+        int run = 0;
+        for (int cb = 0; cb < C; cb += WAVE) {
+            const int c = cb + lane;
+            const int v = c < C ? base_l[c] : 0;
+            int inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            if (c < C) base_l[c] = run + inc - v;
+            run += rdlane(inc, WAVE - 1);
+        }
+        if (lane == 0) base_l[C] = run;
+    }
+    __syncthreads();
+    int node_n = (v0 + lane < v1) ? vn[v0 + lane] : 0;
+    int node_nn = (v0 + WAVE + lane < v1) ? vn[v0 + WAVE + lane] : 0;
+    int cl_n = (v0 + lane < v1) ? S.node2cluster[node_n] : -1;
+    unsigned nl_n = (v0 + lane < v1) ? (unsigned)S.node_local[node_n] : 0u;
+    for (int base = v0; base < v1; base += WAVE) {
+        const int v = base + lane;
+        const bool valid = v < v1;
+        const int cl = cl_n;
+        const unsigned nl = nl_n;
+        {
+            const bool v1x = v + WAVE < v1, v2x = v + 2 * WAVE < v1;
+            cl_n = v1x ? S.node2cluster[node_nn] : -1;
+            nl_n = v1x ? (unsigned)S.node_local[node_nn] : 0u;
+            node_nn = v2x ? vn[v + 2 * WAVE] : 0;
+        }
+        unsigned long long same = ballot(valid);
+        for (int bit = 0; (1 << bit) < C; ++bit) {
+            const unsigned long long bb = ballot((cl >> bit) & 1);
+            same &= ((cl >> bit) & 1) ? bb : ~bb;
+        }
+        if (valid) {
+            const int bs = mine[cl];
+            const int at = base_l[cl] + bs + popc64(same & lanemask_lt());       // vehicle order is kept inside a cluster
+            if (DENSE) stage[at] = dense_pack((unsigned)v, nl);
+            else { stage[at] = (unsigned)v; stage[S.V + at] = nl; }
+            wave_fence();
+            if ((same & lanemask_lt()) == 0) mine[cl] = bs + popc64(same);
+        }
+        wave_fence();
+    }
+    __syncthreads();
+    // the lists leave as runs: one wavefront per list, four lists' stores behind each other
+    for (int c = wave; c < C; c += RESET_WAVES) {
+        const int b0 = base_l[c], n = min(base_l[c + 1] - b0, S.idle_cap);
+        const size_t off = ((size_t)c * S.R + r) * S.idle_cap;
+        for (int i = lane; i < n; i += WAVE) {
+            if (DENSE) reinterpret_cast<unsigned *>(D.idle)[off + i] = stage[b0 + i];
+            else D.idle[off + i] = make_uint2(stage[b0 + i], stage[S.V + b0 + i]);
+        }
+    }
+}
 // ---------------------------------------------------------------------------------------
 // Generic match phase of one bucket (own-cluster scan, :924-965).  Lane l holds idle positions
 // l*J .. l*J+J-1, so "lowest position" == "lowest lane, then lowest slot".
@@ -1231,8 +1331,20 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
 // ---------------------------------------------------------------------------------------
 // launchers (called from vds_api.hip)
 // ---------------------------------------------------------------------------------------
+#ifndef RESET_STAGED_MAX_LDS
+#define RESET_STAGED_MAX_LDS (96 * 1024)
+#endif
+static bool reset_unstaged() {           // VDS_RESET_UNSTAGED=1: k_reset_fast everywhere (A/B, tests of both forms; read per call)
+    const char *e = getenv("VDS_RESET_UNSTAGED");
+    return e && e[0] == '1';
+}
 void launch_reset(const Static &S, const State &D, const int *veh_node, hipStream_t st) {
-    if (S.C <= 2048) {
+    // the staged form while its LDS image of the lists fits (together with the counters) in 96 KB - configs[0] - [3]
+    const size_t staged = ((size_t)(RESET_WAVES + 1) * S.C + 1 + (size_t)(S.dense ? 1 : 2) * S.V) * sizeof(int);
+    if (S.C <= 2048 && staged <= (size_t)RESET_STAGED_MAX_LDS && !reset_unstaged()) {
+        if (S.dense) hipLaunchKernelGGL(k_reset_staged<true>, dim3(S.R), dim3(RESET_WAVES * WAVE), staged, st, S, D, veh_node);
+        else hipLaunchKernelGGL(k_reset_staged<false>, dim3(S.R), dim3(RESET_WAVES * WAVE), staged, st, S, D, veh_node);
+    } else if (S.C <= 2048) {
         hipLaunchKernelGGL(k_reset_fast, dim3(S.R), dim3(RESET_WAVES * WAVE), (size_t)RESET_WAVES * S.C * sizeof(int), st, S, D, veh_node);
     } else {
         dim3 grid(S.C * ((S.R + 3) / 4));
