@@ -736,6 +736,13 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     h->dfs_off_host = dfs_off; h->dfs_seq_host = dfs_seq;
     if ((rc = upload(h, &d, dfs_off))) return rc; S.dfs_off = d;
     if ((rc = upload(h, &d, dfs_seq))) return rc; S.dfs_seq = d;
+    {   // the visit sets as a bit matrix (k_dfs_walk: which dry orders see a steal from cluster c')
+        const int bmw = (C + 31) / 32;
+        std::vector<unsigned> vb((size_t)C * bmw, 0u);
+        for (int c = 0; c < C; ++c)
+            for (int j = dfs_off[c]; j < dfs_off[c + 1]; ++j) vb[(size_t)c * bmw + (dfs_seq[j] >> 5)] |= 1u << (dfs_seq[j] & 31);
+        unsigned *dv; if ((rc = upload(h, &dv, vb))) return rc; S.vis_bits = dv;
+    }
     // fast-kernel preconditions: packed (cost << 7 | position) keys, no window rejects
     {
         int cmin = 0x7FFFFFFF, cmax = -0x7FFFFFFF - 1;

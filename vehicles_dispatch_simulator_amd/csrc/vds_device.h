@@ -110,6 +110,7 @@ struct Static {
                                      // (neighbour-search mode with byte costs; nullptr otherwise)
     const int *dfs_off;              // [C+1]
     const int *dfs_seq;              // visit sequence excluding the start cluster
+    const unsigned *vis_bits;        // [C][(C + 31) / 32] bit c' of row c: cluster c' is in the visit sequence of c (k_dfs_walk's evaluation pass)
     const int4 *so_rec;              // [Oq]
     const int *bkt_off;              // [T*C + 1]
     const int *tick_off;             // [T+1] into ord_q
@@ -132,7 +133,9 @@ struct Static {
     const struct State *state_dev;   // what the rarely taken slow path of k_tick_dense reads instead of by-value kernel arguments
     // static arrival slots ("pull", see below): 1 = order-carrying arrivals go through D.arr instead of the ring
     int pull, pull_W, pull_hmax;     // W: most slots an arrival can lie behind its earliest slot a0; hmax: longest trip in slots (dmin)
-    int arr_slots;                   // slots of the longest day: D.arr is [arr_slots][R] (arr_index)
+    int arr_slots;                   // slots of the longest day: D.arr is [arr_slots][R] (arr_index).  (A replica-major table for day
+                                     // mode 2 - a row's candidate slots as one run - was built and measured in round 4: 19.92 vs 19.88 ms
+                                     // per day with 128 days, 22.53 vs 22.54 with 1024: no difference, not kept)
     const int *so_slot;              // [Oq] per sorted order: slot index in its day's D.arr rows (-1: ring / far path)
     const int2 *d_rec;               // per slot, sorted by (destination cluster, a0, id): {dense_key(insert tick, 0, id), a0 | dest_local << 16 | dmin << 24}
     const int *d_first;              // per day [(TA + 1) x C]: first slot (absolute d_rec position) of cluster c with a0 >= a

@@ -816,6 +816,9 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
                                             // list, index of the entry's stamp, its cluster | orders of that cluster before the dry order << 16, list position},
                                             // the number of candidates; and for the first candidate, if an own-cluster order a holds it: a, the
                                             // two entries {cost << 16 | position} a would pick instead, whether those are all it could pick; pad
+#ifndef WK_EVA
+#define WK_EVA 8                            // visit rows in flight per wavefront in the evaluation pass (a)
+#endif
 #ifndef WK_REDO_PRE
 #define WK_REDO_PRE 1                       // the scan also works out what the holder of its first candidate would pick instead
 #endif
@@ -839,8 +842,7 @@ static_assert(WK_G >= 1 && WK_G <= 3, "dfs_scan is instantiated for 1, 2 and 3 o
 __host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int ns = WK_NS) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
-    const size_t bmw = (size_t)(C + 31) / 32;
-    return ((size_t)8 * C + 1 + ids + 2 * words + (1 + ns) * WK_REC + WK_WAVES * bmw + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)8 * C + 1 + ids + 2 * words + (1 + ns) * WK_REC + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
 }
 
 template <bool U8>
@@ -1126,8 +1128,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     unsigned *pool_l = slot_l + WK_REC;                                               // WK_NS records, filled by wavefronts 1..3
     const int bmw = (C + 31) / 32;
     const int ns = S.walk_pool;
-    unsigned *bm_l = pool_l + ns * WK_REC;                                         // [WK_WAVES][bmw] cluster bitmaps of the evaluation pass
-    int *lg_l = reinterpret_cast<int *>(bm_l + WK_WAVES * bmw);                       // [64][4] the steal log's current chunk
+    int *lg_l = reinterpret_cast<int *>(pool_l + ns * WK_REC);                        // [64][4] the steal log's current chunk
     unsigned short *st_l = reinterpret_cast<unsigned short *>(lg_l + 4 * WAVE);       // [V] stamps
     __shared__ int s_ev;                  // evaluations of the dry orders
     __shared__ int s_nlog;                // steals (entries of the replica's steal log)
@@ -1588,17 +1589,17 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     {
         int acc = 0;        // per lane; reduced at the end
         // (a) per dry order: sum of m0 - min(k, lm) over its visit sequence; the dry orders are dealt round-robin to the wavefronts
-        //     (lane l holds word l of the dry bits of a 64-word block), four orders' rows in flight
+        //     (lane l holds word l of the dry bits of a 64-word block), WK_EVA orders' rows in flight
         for (int wb = 0; wb < nwords; wb += WAVE) {
             const unsigned myw = wb + lane < nwords ? dry_bits[wb + lane] : 0u;
             int inc = __popc(myw);
             const int own = inc;
             for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
             const int excl = inc - own, total = rdlane(inc, WAVE - 1);
-            for (int k0 = wave; k0 < total; k0 += 4 * WK_WAVES) {
-                unsigned vv[4][JB];
+            for (int k0 = wave; k0 < total; k0 += WK_EVA * WK_WAVES) {
+                unsigned vv[WK_EVA][JB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < WK_EVA; ++u) {
                     const int kx = k0 + u * WK_WAVES;
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) vv[u][jb] = 0xFFFFFFFFu;
@@ -1613,70 +1614,48 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < WK_EVA; ++u)
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb)
                         if (vv[u][jb] != 0xFFFFFFFFu) { const int c = (int)(vv[u][jb] & 0xFFFFu); acc += m0_l[c] - min((int)(vv[u][jb] >> 16), lm_l[c]); }
             }
         }
         PROF_STAMP(30);
-        // (b) per searching cluster with dry orders: the steals from the clusters of its visit sequence, counted once per dry order
-        //     of a later rank (the dry orders of a bucket are its last ones, in rank order); four clusters' sequences in flight
-        unsigned *bm = bm_l + wave * bmw;
-        int2 sl0 = make_int2(IMAX, 0);
-        if (lane < nlog) { const int4 s4 = slog[lane]; sl0 = make_int2(s4.x, s4.y); }
-        int taken = 0;          // searching clusters with dry orders met so far: dealt round-robin to the wavefronts
-        for (int cb = 0; cb < C && nlog > 0; cb += WAVE) {
-            const int cme = cb + lane;
-            int qdm = 0, qem = 0;
-            if (cme < C && (cdA_l[cme] & CAPABLE)) { qdm = (cme == 0 ? tq0 : qend_l[cme - 1]) + lm_l[cme]; qem = qend_l[cme]; }
-            unsigned long long dm = ballot(qdm < qem);
+        // (b) the steals each dry order saw: a steal (thief of rank p', victim cluster c') is counted by every dry order of a LATER
+        //     rank whose bucket's visit sequence holds c' (Static.vis_bits: the visit sets as a bit matrix).  Lane = log entry;
+        //     the searching clusters with dry orders are dealt round-robin to the wavefronts, four membership words in flight;
+        //     the dry orders of a bucket are its last ones, their ranks come from LDS (one address for the wavefront)
+        for (int i0 = 0; i0 < nlog; i0 += WAVE) {
+            int prk = IMAX, pcl = 0;
+            if (i0 + lane < nlog) { const int4 s4 = slog[i0 + lane]; prk = s4.x; pcl = s4.y & 0xFFFF; }
+            int taken = 0;          // searching clusters with dry orders met so far
+            for (int cb = 0; cb < C; cb += WAVE) {
+                const int cme = cb + lane;
+                int qdm = 0, qem = 0;
+                if (cme < C && (cdA_l[cme] & CAPABLE)) { qdm = (cme == 0 ? tq0 : qend_l[cme - 1]) + lm_l[cme]; qem = qend_l[cme]; }
+                unsigned long long dm = ballot(qdm < qem);
 #ifdef VDS_PROF
-            if (prof && wave == 0 && lane == 0) g_prof[(size_t)pwave * PROF_SLOTS + 23] += popc64(dm);
+                if (prof && wave == 0 && lane == 0 && i0 == 0) g_prof[(size_t)pwave * PROF_SLOTS + 23] += popc64(dm);
 #endif
-            while (dm != 0ull) {
-                int cjs[4][JB], qd4[4], qe4[4], n4[4];
+                while (dm != 0ull) {
+                    unsigned wd[4];
+                    int qd4[4], qe4[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    qd4[u] = 0; qe4[u] = 0; n4[u] = 0;
-#pragma unroll
-                    for (int jb = 0; jb < JB; ++jb) cjs[u][jb] = 0;
-                    while (dm != 0ull && (taken % WK_WAVES) != wave) { dm &= dm - 1ull; ++taken; }
-                    if (dm != 0ull) {
-                        const int l = __ffsll((long long)dm) - 1;
-                        dm &= dm - 1ull; ++taken;
-                        const int pc = cb + l;
-                        qd4[u] = rdlane(qdm, l); qe4[u] = rdlane(qem, l);
-                        const int s0 = S.dfs_off[pc];
-                        n4[u] = S.dfs_off[pc + 1] - s0;
-#pragma unroll
-                        for (int jb = 0; jb < JB; ++jb) if (jb * WAVE + lane < n4[u]) cjs[u][jb] = S.dfs_seq[s0 + jb * WAVE + lane];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (qd4[u] >= qe4[u]) continue;
-                    for (int w = lane; w < bmw; w += WAVE) bm[w] = 0u;
-                    wg_order();
-#pragma unroll
-                    for (int jb = 0; jb < JB; ++jb) if (jb * WAVE + lane < n4[u]) atomicOr(&bm[cjs[u][jb] >> 5], 1u << (cjs[u][jb] & 31));
-                    wg_order();
-                    for (int i0 = 0; i0 < nlog; i0 += WAVE) {
-                        int2 sl = sl0;
-                        if (i0 > 0) { sl = make_int2(IMAX, 0); if (i0 + lane < nlog) { const int4 s4 = slog[i0 + lane]; sl = make_int2(s4.x, s4.y); } }
-                        const int c = sl.y & 0xFFFF;
-                        const bool member = i0 + lane < nlog && ((bm[c >> 5] >> (c & 31)) & 1u);
-                        // the dry orders of the bucket, one per lane: the steals each of them counts
-                        for (int qb = qd4[u]; qb < qe4[u]; qb += WAVE) {
-                            const int rkm = qb + lane < qe4[u] ? (int)rq_l[qb + lane - tq0] : -1;
-                            const int nq = min(WAVE, qe4[u] - qb);
-                            for (int x = 0; x < nq; ++x) {
-                                const int cn = popc64(ballot(member && sl.x < rdlane(rkm, x)));        // (the vote outside the lane-0 branch)
-                                if (lane == 0) acc -= cn;
-                            }
+                    for (int u = 0; u < 4; ++u) {
+                        qd4[u] = 0; qe4[u] = 0; wd[u] = 0u;
+                        while (dm != 0ull && (taken % WK_WAVES) != wave) { dm &= dm - 1ull; ++taken; }
+                        if (dm != 0ull) {
+                            const int l = __ffsll((long long)dm) - 1;
+                            dm &= dm - 1ull; ++taken;
+                            qd4[u] = rdlane(qdm, l); qe4[u] = rdlane(qem, l);
+                            wd[u] = S.vis_bits[(size_t)(cb + l) * bmw + (pcl >> 5)];
                         }
                     }
-                    wg_order();
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool member = ((wd[u] >> (pcl & 31)) & 1u) != 0u;
+                        for (int qb = qd4[u]; qb < qe4[u]; ++qb) acc -= (member && prk < (int)rq_l[qb - tq0]) ? 1 : 0;
+                    }
                 }
             }
         }
@@ -1759,6 +1738,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     __syncthreads();
     PROF_STAMP(27);
     // ---- IdleVehicles.remove (:963), once per bucket: order-preserving compaction (survivors = free entries, node words clean)
+    // (software-pipelined - the next batch's loads issued before this batch's stores, two batches of 8 - measured: 37.25 vs 36.88 ms
+    // per day, the pass is bound by the memory system's throughput, not by its round trips: not kept)
     for (int c = wave; c < C; c += 12 * WK_WAVES) {        // (twelve lists in flight per wavefront)
         uint2 e4[12];
         bool keep4[12], small4[12];
