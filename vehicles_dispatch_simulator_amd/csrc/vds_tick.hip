@@ -1149,18 +1149,18 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                 const int TA = S.n_days <= 1 ? S.T + S.H : d2.z;
                 // (arrival slot a0 + delta, delta in [0, W]: due by the next slot means a0 in [tr + 1 - W, tr + 1]; on its way: a0 up to tr + hmax)
                 const int lo = df[(size_t)max(tr - S.pull_W + 1, 0) * S.C + c], hi = df[(size_t)min(tr + (want_infl ? S.pull_hmax + 1 : 2), TA) * S.C + c];
-                // (eight entries in flight per thread: the loop is a chain of dependent-free loads, 60 - 100 per bucket at configs[1])
-                for (int i0 = lo; i0 < hi; i0 += 8) {
-                    int ry[8];
-                    unsigned e[8];
+                // (sixteen entries in flight per thread (eight: +1 round trip per bucket): the loop is a chain of dependent-free loads, 60 - 100 per bucket at configs[1])
+                for (int i0 = lo; i0 < hi; i0 += 16) {
+                    int ry[16];
+                    unsigned e[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 16; ++u) {
                         const int i = min(i0 + u, hi - 1);
                         ry[u] = S.d_rec[i].y;
                         e[u] = D.arr[arr_index(S.R, i - d2.y, r)];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 16; ++u) {
                         const int tins = (ry[u] & 0xFFFF) - (int)((unsigned)ry[u] >> 24);
                         // (tins > tr: not processed yet - the entry is not of this episode)
                         const bool live = i0 + u < hi && tins <= tr && !pull_is_reject(e[u]);
