@@ -363,7 +363,7 @@ def main():
         nbr = {"workload": "configs[3]: %d replicas/GPU x 192 clusters with neighbour DFS depth 2, 10k vehicles, 200k orders/day" % R,
                "value": T4 * R * nd4 / dt4, "unit": "env-steps*replicas/s", "ms_per_step": dt4 / nd4 * 1e3, "steps": nd4,
                "kernel": env4.main_kernel(), "run_groups": env4.run_groups(),
-               "evidence": "profiles/r03_cfg4_hybrid (bench.py --workload cfg4 --check: roofline, parity)"}
+               "evidence": "profiles/r04_cfg4_hybrid (bench.py --workload cfg4 --check: roofline, parity)"}
         env4.close()
 
     # ---- the hooked slot (rank 0, N = 1): what an RL loop over R cities costs per slot - the reference's hook order
