@@ -203,8 +203,8 @@ int vds_run(vds_handle *h, int32_t n_ticks);
 /* Scheduling of vds_run (no reference counterpart, results do not depend on it): the replicas run as `groups` independent
  * groups (replicas never interact inside :1048-1091 without hooks) - in neighbour-search mode (hybrid tick) the stamp-mode
  * k_tick_rows of one group under the k_dfs_walk of the others, without neighbour search two chains of half-size k_tick_dense
- * (k_tick_rows) launches whose kernel boundaries overlap.  Defaults: plain tick 2 groups from 256 replicas on, hybrid tick 2 from 512 and
- * 3 from 1024 replicas on.  stagger 2: the groups' k_tick_rows launches are
+ * (k_tick_rows) launches whose kernel boundaries overlap.  Defaults: plain tick 2 groups from 256 replicas on (large cities: from clusters x replicas >= 192 x 256
+ * and 32 replicas on), hybrid tick 2 from 512 and 3 from 1024 replicas on.  stagger 2: the groups' k_tick_rows launches are
  * serialised round-robin by extra graph edges (keeps the groups out of phase), 1: first tick only, 0: free-running.
  * groups <= 0 / stagger < 0: library default (environment VDS_RUN_GROUPS / VDS_RUN_STAGGER).  1 <= groups <= 16.
  * The groups are parallel branches of the hipGraph vds_run replays (runs of >= 8 slots); eager runs (VDS_RUN_GRAPH=0, short

@@ -294,3 +294,27 @@ def test_bad_arguments_are_refused():
         env.set_run_groups(2, 3)
     env.set_run_groups(0, -1)
     env.close()
+
+
+def test_large_city_runs_as_two_groups_from_32_replicas_on():
+    """The plain tick takes two chains below 256 replicas when the city is large (clusters x replicas >= 192 x 256: configs[4] at
+    128 replicas): 1536 clusters x 32 replicas picks 2 groups by itself, 31 replicas of the same city 1; identical results."""
+    from vehicles_dispatch_simulator_amd import workloads
+    w = workloads.tiny(N=3200, C=1536, vehicles=2500, orders=6000, seed=23)
+    outs = []
+    for R, groups, want in ((32, 0, 2), (32, 1, 1), (31, 0, 1)):
+        env = w.make_env(R)
+        assert env.run_groups() == want if groups == 0 else True
+        if groups:
+            env.set_run_groups(groups, 0)
+        assert env.run_groups() == want
+        env.reset(w.vehicle_nodes(R))
+        env.run(env.T)
+        env.sync()
+        outs.append((env.counters().copy(), {k: np.array(v) for k, v in env.orders().items()}))
+        env.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        np.testing.assert_array_equal(outs[0][1][k], outs[1][1][k], err_msg=k)
+        np.testing.assert_array_equal(outs[0][1][k][:31], outs[2][1][k], err_msg=k)
+    np.testing.assert_array_equal(outs[0][0][:31], outs[2][0])

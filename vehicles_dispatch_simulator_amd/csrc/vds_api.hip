@@ -243,6 +243,12 @@ static int guarded(vds_handle *h, const char *name, F &&body) {
 #ifndef RUN_GROUPS_PLAIN_MIN_R
 #define RUN_GROUPS_PLAIN_MIN_R 256
 #endif
+// ... and with fewer replicas when the city is large: what the chains overlap is launch tails and kernel boundaries, and those scale
+// with the workgroups of a launch, clusters x replicas / 16 (configs[4], 2048 clusters, 128 replicas, one box: one chain 11.05, two
+// 10.58, four 12.60 ms per day - profiles/r04/run_groups_final_build.txt).  Threshold: the workgroup count of configs[1] at 256 replicas
+#ifndef RUN_GROUPS_PLAIN_MIN_CR
+#define RUN_GROUPS_PLAIN_MIN_CR (192 * 256)
+#endif
 #define RUN_GROUPS_MAX 16
 
 // Executable day graphs WITH PARALLEL BRANCHES (the replica groups of vds_run) are never destroyed while the process lives.
@@ -1480,9 +1486,10 @@ static int run_group_count(vds_handle *h) {
         h->run_stagger = (v && *v) ? atoi(v) : 1;
     }
     if (!h->use_graph) return 1;             // (groups only as branches of the day's graph: see vds_run)
-    // default: hybrid tick 3 groups from 1024 replicas on, 2 from 512 on; plain tick 2 groups from 256 replicas on
+    // default: hybrid tick 3 groups from 1024 replicas on, 2 from 512 on; plain tick 2 groups from 256 replicas on (large cities: from
+    // clusters x replicas >= 192 x 256 on)
     const int dflt = run_groups_hybrid(h) ? (h->S.R < RUN_GROUPS_MIN_R ? 1 : (h->S.R >= RUN_GROUPS_BIG_R ? 3 : 2))
-                                          : (h->S.R < RUN_GROUPS_PLAIN_MIN_R ? 1 : 2);
+                                          : ((h->S.R >= RUN_GROUPS_PLAIN_MIN_R || (h->S.R >= 32 && (long long)h->S.C * h->S.R >= RUN_GROUPS_PLAIN_MIN_CR)) ? 2 : 1);
     int G = h->run_groups > 0 ? h->run_groups : dflt;
     const int chunks = (h->S.R + 15) / 16;
     if (G > chunks) G = chunks;
