@@ -463,6 +463,29 @@ def main():
         if graph_error:
             hooked["policy_graph_error"] = graph_error
 
+    # ---- the episode reset three ways (rank 0, N = 1): start nodes resident (vds_reset_again: what the timed steps use), drawn on
+    #      the device per episode (vds_reset_random: one random.Random(seed) stream per replica, the reference's InitVehiclesIntoCluster
+    #      draws bit for bit), generated on the host and uploaded (vds_reset: what an RL loop with fresh start nodes paid before)
+    episode_reset = None
+    if rank == 0 and world == 1 and a.hooked and a.workload == "cfg2":
+        try:
+            def tm(f, n):
+                f(); env.sync()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    f()
+                env.sync()
+                return (time.perf_counter() - t1) / n * 1e3
+            seeds = (np.arange(R) + w.veh_seed + first).astype(np.uint64)
+            t1 = time.perf_counter(); init2 = w.vehicle_nodes(R, first_replica=first); gen_ms = (time.perf_counter() - t1) * 1e3
+            episode_reset = {"unit": "ms per episode reset of %d replicas" % R, "reset_again": tm(env.reset_again, 50), "reset_random_on_device": tm(lambda: env.reset_random(seeds), 10),
+                             "reset_uploaded": tm(lambda: env.reset(init2), 3), "host_generation_native_mt19937": gen_ms}
+            env.reset_random(seeds)
+            episode_reset["same_nodes_as_host_generation"] = bool(all(np.array_equal(env.vehicles(r)["node"], init2[r]) for r in (0, R // 2, R - 1)))
+            env.reset(init)
+        except Exception as e:       # (a reported extra)
+            episode_reset = {"error": repr(e)}
+
     check = None
     if a.check and rank == 0:
         from oracle.oracle import Oracle
@@ -510,6 +533,8 @@ def main():
             out["neighbour_search"] = nbr
         if hooked is not None:
             out["hooked_slot"] = hooked
+        if episode_reset is not None:
+            out["episode_reset"] = episode_reset
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))

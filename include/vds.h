@@ -159,6 +159,15 @@ int vds_idle_cap(const vds_handle *h);
  * resident in HBM): the episode restart an RL loop performs thousands of times. */
 int vds_reset_again(vds_handle *h);
 
+/* As vds_reset, with the start nodes DRAWN ON THE DEVICE: replica r (the caller's index) starts its vehicles where
+ * InitVehiclesIntoCluster (:249-258) puts them when the reference's `random` is `random.Random(seeds[r])` - vehicle after vehicle
+ * `choice(range(N))`, retried until the node lies in a cluster (:254); bit for bit the nodes vds_py_random_nodes(seeds[r], ...)
+ * returns (MT19937 seeded by init_by_array, `_randbelow` by rejection on getrandbits(N.bit_length())).  An RL loop that draws
+ * fresh start nodes every episode does not generate 10^7 draws on the host and upload them (~50 ms + 41 MB at configs[1]: seven
+ * simulated days).  seeds: R host values, not retained.  The nodes stay resident like vds_reset's (vds_reset_again re-uses them);
+ * the idle tables are sized from the fullest start list exactly as vds_reset sizes them.  Synchronises like vds_reset. */
+int vds_reset_random(vds_handle *h, const uint64_t *seeds);
+
 /* One SimCity iteration up to the Dispatch hook for every replica: UpdateFunction (:1006-1024),
  * MatchFunction (:900-975) incl. FindServerVehicleFunction (:978-996), SupplyExpectFunction
  * (:880-891) and the idle snapshots (:909-910, :1080-1081).  Asynchronous. */

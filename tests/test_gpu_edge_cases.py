@@ -360,3 +360,48 @@ def test_reset_builds_the_same_lists_staged_and_unstaged(shape, fg, monkeypatch)
     for k in ("status", "vehicle", "wait"):
         np.testing.assert_array_equal(outs[0][0][k], outs[1][0][k])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("shape", [(300, 12, 150, 5), (4139, 192, 3000, 4), (4096, 40, 700, 3), (1, 1, 40, 2), (257, 9, 1, 3)])
+def test_reset_random_draws_the_reference_start_nodes_on_the_device(shape):
+    """vds_reset_random: InitVehiclesIntoCluster (:249-258) with `random.Random(seed_r)` per replica, drawn by a device MT19937 -
+    vehicle for vehicle the nodes CPython draws (random.Random(seed).choice(range(N)), retried while the node is in no cluster),
+    for seeds of one and two 32-bit words, N at and next to a power of two, a city with nodes outside every cluster; then the
+    day from those nodes equals the day from the same nodes uploaded by vds_reset."""
+    import random as pyrandom
+    from vehicles_dispatch_simulator_amd import workloads
+    N, Cn, V, R = shape
+    w = workloads.tiny(N=N, C=Cn, vehicles=V, orders=800, seed=3 + N)
+    n2c = np.asarray(w.city.node2cluster).copy()
+    if N > 64:
+        n2c[5:N:7] = -1                                   # nodes in no cluster: those draws are retried (:254)
+    seeds = np.array([0, 1, 2**32 - 1, 2**32, 2**63 + 12345][:R], dtype=np.uint64)
+    env = BatchedDispatchEnv(w.city.cost, n2c, w.nbr_off, w.nbr_idx, replicas=R, vehicles=V, depth_limit=0, neighbor_can_server=False)
+    keep = (n2c[np.asarray(w.pickup)] >= 0) & (n2c[np.asarray(w.delivery)] >= 0)
+    env.load_orders(np.asarray(w.release_min)[keep], np.asarray(w.pickup)[keep], np.asarray(w.delivery)[keep])
+    env.reset_random(seeds)
+    exp = np.zeros((R, V), dtype=np.int32)
+    for r in range(R):
+        rng = pyrandom.Random(int(seeds[r]))
+        for v in range(V):
+            while True:
+                node = rng.choice(range(N))
+                if n2c[node] >= 0:
+                    break
+            exp[r, v] = node
+        got = env.vehicles(r)
+        assert (got["state"] == 0).all()
+        np.testing.assert_array_equal(got["node"], exp[r], err_msg="replica %d" % r)
+    env.run(env.T)
+    a = (env.orders(), env.counters().copy())
+    env.reset_again()                                     # the drawn nodes stay resident
+    env.run(env.T)
+    b = (env.orders(), env.counters().copy())
+    env.reset(exp)
+    env.run(env.T)
+    c = (env.orders(), env.counters().copy())
+    env.close()
+    for other in (b, c):
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(a[0][k], other[0][k])
+        np.testing.assert_array_equal(a[1], other[1])

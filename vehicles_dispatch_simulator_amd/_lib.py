@@ -58,6 +58,7 @@ SYMBOLS = {
     "vds_num_ticks": (C.c_int, [_VP, C.POINTER(_I32)]),
     "vds_reset": (C.c_int, [_VP, _VP]),
     "vds_reset_again": (C.c_int, [_VP]),
+    "vds_reset_random": (C.c_int, [_VP, _VP]),
     "vds_step": (C.c_int, [_VP]),
     "vds_apply_dispatch": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "vds_apply_dispatch_ex": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -17,6 +17,7 @@
 
 namespace vds {
 void launch_reset(const Static &, const State &, const int *, hipStream_t);
+void launch_py_random_nodes(const unsigned long long *, int, int, int, int, const int *, int *, int *, hipStream_t);      // vds_random.hip
 void launch_tick_main(const Static &, const State &, int, int, hipStream_t);
 void launch_tick_work(const Static &, const State &, int, hipStream_t);
 void launch_update_only(const Static &, const State &, int, hipStream_t);
@@ -117,6 +118,8 @@ struct vds_handle {
     std::vector<void *> *alloc_sink = nullptr;
     // device scratch
     int *d_veh_node = nullptr;
+    unsigned long long *d_seeds = nullptr;   // vds_reset_random: the replicas' seeds, the fullest start list per replica
+    int *d_fullest = nullptr;
     int *d_obs = nullptr;
     long long *d_cnt_per = nullptr, *d_cnt_tot = nullptr;
     int *d_actions = nullptr;
@@ -1355,6 +1358,40 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
     return vds_sync(h);   // veh_init_node is caller-owned: do not retain it; also reports idle_cap overflow
 }
 
+// vds_reset with the start nodes drawn on the device (vds_random.hip): replica r gets the sequence random.Random(seeds[r]) yields
+static int reset_random_impl(vds_handle *h, const uint64_t *seeds) {
+    if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_reset_random: load static tables and orders first");
+    if (!seeds) return fail(h, VDS_EINVAL, "vds_reset_random: null seeds");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const Static &S = h->S;
+    bool any = false;
+    for (int i = 0; i < S.N && !any; ++i) any = h->node2cluster[i] >= 0;
+    if (!any && S.V > 0) return fail(h, VDS_ESTATE, "vds_reset_random: no node lies in a cluster (:254)");
+    if ((size_t)(624 + S.C) * sizeof(int) > 64 * 1024) return fail(h, VDS_EINVAL, "vds_reset_random: %d clusters exceed the generator's LDS histogram", S.C);
+    int rc;
+    if (!h->d_seeds) {
+        if ((rc = dev_alloc(h, &h->d_seeds, (size_t)h->R_ext))) return rc;
+        if ((rc = dev_alloc(h, &h->d_fullest, (size_t)h->R_ext))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)h->R_ext * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    launch_py_random_nodes(h->d_seeds, h->R_ext, S.N, S.V, S.C, S.node2cluster, h->d_veh_node, h->d_fullest, h->stream);
+    HIPCHK(h, hipGetLastError());
+    std::vector<int> full((size_t)std::max(h->R_ext, 1));
+    HIPCHK(h, hipMemcpyAsync(full.data(), h->d_fullest, (size_t)h->R_ext * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // (the seeds are caller-owned; the capacity below needs the histogram)
+    int fullest = 0;
+    for (int r = 0; r < h->R_ext; ++r) {
+        if (full[r] < 0) return fail(h, VDS_ESTATE, "vds_reset_random: replica %d found no start nodes", r);
+        fullest = std::max(fullest, full[r]);
+    }
+    if (h->cfg.idle_cap <= 0 && S.V > 0) {               // automatic capacity, as vds_reset sizes it
+        const int want = std::min(round_up(std::max(S.V, 1), 64), round_up(2 * fullest + 64, 64));
+        if (want > S.idle_cap && (rc = set_idle_cap_impl(h, want))) return rc;
+    }
+    if ((rc = reset_device(h))) return rc;
+    return vds_sync(h);
+}
+
 int vds_reset_again(vds_handle *h) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_reset_again: needs a previous vds_reset");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -2214,6 +2251,10 @@ int vds_replica_ticks(const vds_handle *h, int32_t replica, int32_t *T, int32_t 
 
 int vds_reset(vds_handle *h, const int32_t *veh_init_node) {
     return guarded(h, "vds_reset", [&] { return reset_impl(h, veh_init_node); });
+}
+
+int vds_reset_random(vds_handle *h, const uint64_t *seeds) {
+    return guarded(h, "vds_reset_random", [&] { return reset_random_impl(h, seeds); });
 }
 
 int vds_step(vds_handle *h) {

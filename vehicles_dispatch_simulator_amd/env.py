@@ -169,6 +169,15 @@ class BatchedDispatchEnv:
             raise Exception("reset: expected %d start nodes, got %d" % (self.R * self.V, v.size))
         self._chk(self._lib.vds_reset(self._h, _p(v)))
 
+    def reset_random(self, seeds):
+        """``reset`` with the start nodes drawn ON THE DEVICE: replica r starts where ``random.Random(seeds[r])`` puts its vehicles
+        (``choice(range(N))`` per vehicle, retried until the node lies in a cluster, simulator.py:249-258) - the same nodes
+        ``workloads.native_vehicle_nodes`` / the reference would draw, without the host generation and the upload."""
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(-1))
+        if s.size != self.R:
+            raise Exception("reset_random: expected %d seeds, got %d" % (self.R, s.size))
+        self._chk(self._lib.vds_reset_random(self._h, _p(s)))
+
     def reset_again(self):
         """Restart the episode from the start nodes already resident on the device (asynchronous)."""
         self._chk(self._lib.vds_reset_again(self._h))
