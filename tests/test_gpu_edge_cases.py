@@ -405,3 +405,41 @@ def test_reset_random_draws_the_reference_start_nodes_on_the_device(shape):
         for k in ("status", "vehicle", "wait"):
             np.testing.assert_array_equal(a[0][k], other[0][k])
         np.testing.assert_array_equal(a[1], other[1])
+
+
+@pytest.mark.parametrize("host_checks", ["0", "1"])
+def test_reset_checks_start_nodes_on_the_device_and_keeps_the_old_ones_on_failure(host_checks, monkeypatch):
+    """vds_reset validates the uploaded start nodes with one kernel (VDS_RESET_HOST_CHECKS=1: the host loops of rounds 1-3): the FIRST
+    vehicle on a node outside every cluster is named (:254), a failed reset leaves the previous episode's start nodes in place
+    (vds_reset_again replays them), the idle capacity follows the fullest start list as before."""
+    from vehicles_dispatch_simulator_amd import workloads
+    monkeypatch.setenv("VDS_RESET_HOST_CHECKS", host_checks)
+    w = workloads.tiny(N=300, C=12, vehicles=200, orders=1200, seed=41)
+    n2c = np.asarray(w.city.node2cluster).copy()
+    n2c[7] = -1
+    keep = (n2c[np.asarray(w.pickup)] >= 0) & (n2c[np.asarray(w.delivery)] >= 0)
+    R, V = 3, 200
+    env = BatchedDispatchEnv(w.city.cost, n2c, w.nbr_off, w.nbr_idx, replicas=R, vehicles=V, depth_limit=0, neighbor_can_server=False)
+    env.load_orders(np.asarray(w.release_min)[keep], np.asarray(w.pickup)[keep], np.asarray(w.delivery)[keep])
+    rng = np.random.default_rng(5)
+    valid = np.flatnonzero(n2c >= 0)
+    good = valid[rng.integers(0, valid.size, size=(R, V))].astype(np.int32)
+    env.reset(good)
+    env.run(env.T)
+    ref = (env.orders(), env.counters().copy())
+    for bad_value in (7, -3, 300, 10**6):
+        bad = good.copy()
+        bad[1, 57] = bad_value
+        bad[2, 3] = 7                                        # a later offender: the first one is reported
+        with pytest.raises(Exception, match=r"vehicle 257 starts on node %d which is in no cluster" % bad_value):
+            env.reset(bad)
+    env.reset_again()                                        # the nodes of the last successful reset
+    env.run(env.T)
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(env.orders()[k], ref[0][k])
+    np.testing.assert_array_equal(env.counters(), ref[1])
+    crowded = np.full((R, V), valid[0], np.int32)            # every vehicle in one cluster: the capacity grows to hold them
+    env.reset(crowded)
+    assert env.idle_cap >= V
+    assert env.lists(2)["idle_off"][int(n2c[valid[0]]) + 1] - env.lists(2)["idle_off"][int(n2c[valid[0]])] == V
+    env.close()

@@ -18,6 +18,7 @@
 namespace vds {
 void launch_reset(const Static &, const State &, const int *, hipStream_t);
 void launch_py_random_nodes(const unsigned long long *, int, int, int, int, const int *, int *, int *, hipStream_t);      // vds_random.hip
+void launch_start_nodes_check(const int *, int, int, int, int, const int *, int *, unsigned long long *, hipStream_t);
 void launch_tick_main(const Static &, const State &, int, int, hipStream_t);
 void launch_tick_work(const Static &, const State &, int, hipStream_t);
 void launch_update_only(const Static &, const State &, int, hipStream_t);
@@ -120,6 +121,8 @@ struct vds_handle {
     int *d_veh_node = nullptr;
     unsigned long long *d_seeds = nullptr;   // vds_reset_random: the replicas' seeds, the fullest start list per replica
     int *d_fullest = nullptr;
+    int *d_veh_stage = nullptr;              // vds_reset: the caller's start nodes land here and are checked on the device before they
+    unsigned long long *d_bad = nullptr;     // replace d_veh_node (index of the first node outside every cluster, ~0 if none)
     int *d_obs = nullptr;
     long long *d_cnt_per = nullptr, *d_cnt_tot = nullptr;
     int *d_actions = nullptr;
@@ -1331,6 +1334,37 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const Static &S = h->S;
     const size_t n = (size_t)h->R_ext * S.V;
+    const bool on_device = S.V > 0 && (size_t)S.C * sizeof(int) <= 60 * 1024 && !(getenv("VDS_RESET_HOST_CHECKS") && getenv("VDS_RESET_HOST_CHECKS")[0] == '1');
+    if (on_device) {
+        // upload first, then the checks as one kernel over the uploaded array (k_start_nodes_check, vds_random.hip); the nodes of the
+        // previous vds_reset stay in place until the new ones have passed
+        int rc0;
+        if (!h->d_veh_stage) {
+            if ((rc0 = dev_alloc(h, &h->d_veh_stage, n))) return rc0;
+            if (!h->d_fullest && (rc0 = dev_alloc(h, &h->d_fullest, (size_t)h->R_ext))) return rc0;
+            if ((rc0 = dev_alloc(h, &h->d_bad, (size_t)1))) return rc0;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->d_veh_stage, veh_init_node, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_bad, 0xFF, sizeof(unsigned long long), h->stream));
+        launch_start_nodes_check(h->d_veh_stage, h->R_ext, S.N, S.V, S.C, S.node2cluster, h->d_fullest, h->d_bad, h->stream);
+        HIPCHK(h, hipGetLastError());
+        std::vector<int> full((size_t)h->R_ext);
+        unsigned long long bad = 0;
+        HIPCHK(h, hipMemcpyAsync(full.data(), h->d_fullest, (size_t)h->R_ext * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&bad, h->d_bad, sizeof(bad), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (bad != ~0ull)
+            return fail(h, VDS_ESTATE, "vds_reset: vehicle %zu starts on node %d which is in no cluster (:254)", (size_t)bad, veh_init_node[bad]);
+        if (h->cfg.idle_cap <= 0) {
+            int fullest = 0;
+            for (int r = 0; r < h->R_ext; ++r) fullest = std::max(fullest, full[r]);
+            const int want = std::min(round_up(std::max(S.V, 1), 64), round_up(2 * fullest + 64, 64));
+            if (want > S.idle_cap && (rc0 = set_idle_cap_impl(h, want))) return rc0;
+        }
+        std::swap(h->d_veh_node, h->d_veh_stage);
+        if ((rc0 = reset_device(h))) return rc0;
+        return vds_sync(h);
+    }
     for (size_t i = 0; i < n; ++i) {
         int node = veh_init_node[i];
         if (node < 0 || node >= S.N || h->node2cluster[node] < 0)

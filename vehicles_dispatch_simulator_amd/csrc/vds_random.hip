@@ -96,6 +96,39 @@ __global__ __launch_bounds__(RN_WAVE) void k_py_random_nodes(const unsigned long
     if (lane == 0) fullest[r] = done >= V ? mx : -1;
 }
 
+// vds_reset's checks of the caller's start nodes on the device, after the upload: every node must lie in a cluster (:254) - the
+// first offender's index is reported - and the fullest start list sizes the idle tables (10^7 nodes: ~8 ms of host loops before)
+#define SC_THREADS 256
+__global__ __launch_bounds__(SC_THREADS) void k_start_nodes_check(const int *__restrict__ veh_node, int N, int V, int C, const int *__restrict__ node2cluster,
+                                                                  int *__restrict__ fullest, unsigned long long *__restrict__ bad) {
+    extern __shared__ int rn_lds[];
+    __shared__ int s_max;
+    int *hist = rn_lds;
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += SC_THREADS) hist[c] = 0;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const int *vn = veh_node + (size_t)r * V;
+    for (int v = threadIdx.x; v < V; v += SC_THREADS) {
+        const int node = vn[v];
+        const int cl = (node >= 0 && node < N) ? node2cluster[node] : -1;
+        if (cl < 0) atomicMin(bad, (unsigned long long)r * (unsigned long long)V + (unsigned long long)v);
+        else atomicAdd(&hist[cl], 1);
+    }
+    __syncthreads();
+    int mx = 0;
+    for (int c = threadIdx.x; c < C; c += SC_THREADS) mx = max(mx, hist[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, RN_WAVE));
+    if ((threadIdx.x & (RN_WAVE - 1)) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) fullest[r] = s_max;
+}
+
+void launch_start_nodes_check(const int *veh_node, int R, int N, int V, int C, const int *node2cluster, int *fullest, unsigned long long *bad, hipStream_t st) {
+    if (R <= 0) return;
+    hipLaunchKernelGGL(k_start_nodes_check, dim3(R), dim3(SC_THREADS), (size_t)C * sizeof(int), st, veh_node, N, V, C, node2cluster, fullest, bad);
+}
+
 void launch_py_random_nodes(const unsigned long long *seeds, int R, int N, int V, int C, const int *node2cluster, int *veh_node, int *fullest,
                             hipStream_t st) {
     if (R <= 0) return;
