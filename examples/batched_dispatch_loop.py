@@ -17,7 +17,8 @@ from vehicles_dispatch_simulator_amd import workloads
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 w = workloads.didi_day("cfg2") if (len(sys.argv) > 2 and sys.argv[2] == "cfg2") else workloads.tiny(N=600, C=24, vehicles=400, orders=12000)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
-env.reset(w.vehicle_nodes(R))
+# start nodes drawn on the GPU: replica r as random.Random(w.veh_seed + r) would draw them (= env.reset(w.vehicle_nodes(R)), bit for bit)
+env.reset_random(np.arange(R, dtype=np.uint64) + np.uint64(w.veh_seed))
 some_node_of = torch.tensor([int(np.flatnonzero(w.city.node2cluster == c)[0]) for c in range(w.city.C)], dtype=torch.int32, device="cuda")
 t0 = time.time()
 for t in range(env.T):
