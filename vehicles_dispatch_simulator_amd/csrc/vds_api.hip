@@ -1361,7 +1361,8 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
             const int want = std::min(round_up(std::max(S.V, 1), 64), round_up(2 * fullest + 64, 64));
             if (want > S.idle_cap && (rc0 = set_idle_cap_impl(h, want))) return rc0;
         }
-        std::swap(h->d_veh_node, h->d_veh_stage);
+        // (a copy, not a pointer swap: d_veh_node belongs to the state tables, which a later vds_load_orders* re-allocates)
+        HIPCHK(h, hipMemcpyAsync(h->d_veh_node, h->d_veh_stage, n * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
         if ((rc0 = reset_device(h))) return rc0;
         return vds_sync(h);
     }
