@@ -67,7 +67,9 @@ def write_reference_data_dir(root: str, city, start_unix, pickup, delivery, n_dr
     node.to_csv(os.path.join(d, "Node.csv"), index=False, float_format="%.7f")
     with open(os.path.join(d, "NodeIDList.txt"), "w") as f:
         f.write("\n".join(str(int(x)) for x in city.node_id) + "\n")
-    pd.DataFrame(city.cost).to_csv(os.path.join(d, "AccurateMap.csv"), header=False, index=False)
+    # (fractional minutes when the city carries them: the reference then truncates at every RoadCost call, simulator.py:264)
+    cost_table = city.cost if getattr(city, "cost_float", None) is None else city.cost_float
+    pd.DataFrame(cost_table).to_csv(os.path.join(d, "AccurateMap.csv"), header=False, index=False)
     O = len(start_unix)
     orders = pd.DataFrame({
         "ID": np.arange(O), "Start_time": np.asarray(start_unix, dtype=np.int64),
@@ -317,6 +319,8 @@ def run_reference(city, start_unix, pickup, delivery, *, V: int, seed: int, clus
             dispatch_log=np.array(dispatch_log, dtype=np.int64).reshape(-1, 6),
             ref_init_s=np.float64(t_init), ref_sim_s=np.float64(t_sim),
         )
+        if not (cost == cost_int).all():
+            out["cost_float"] = np.asarray(cost, dtype=np.float64)      # the matrix as the reference read it
         out.update(dfs)
         out.update(nbr_table)
         if dispatch_extra_minutes:

@@ -75,6 +75,12 @@ TINY = {
     # the neighbour-distance table the reference computes and caches (:594-621), with two empty clusters (99999 rows)
     "tiny_nbr_empty": dict(city=dict(seed=117, N=260, C=12), O=600, oseed=17, empty=[2, 9], nbr_table=True,
                            run=dict(V=40, seed=27, cluster_mode="TransportationClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
+    # FRACTIONAL road costs (one decimal): the only floating point on the path is int(float) in RoadCost
+    # (simulator.py:263-264).  AccurateMap.csv holds values like 9.9 / 10.0 / 0.4 and asymmetric pairs; the reference truncates
+    "tiny_fraccost": dict(city=dict(seed=118, N=300, C=12, frac=True), O=2500, oseed=18, nbr_table=True,
+                          run=dict(V=140, seed=28, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
+    "tiny_fraccost_dfs2": dict(city=dict(seed=119, N=300, C=12, frac=True), O=3000, oseed=19,
+                               run=dict(V=50, seed=29, cluster_mode="SpectralClustering", side_m=3200, service_m=8000, neighbor_can_server=True)),
     "tiny_two_orders": dict(city=dict(seed=110, N=120, C=12), O=2, oseed=10,
                             run=dict(V=30, seed=20, cluster_mode="KmeansClustering", side_m=3200, service_m=3200)),
 }
@@ -176,7 +182,15 @@ def generate(name, spec, real=False, shipped=False):
         run["capture_neighbor_table"] = True
     out = rh.run_reference(city, start, pick, dele, dispatch_policy=pol, capture_lists=not real, focus_bound=focus, **run)
     # the generator's tables must be exactly what the reference loaded / derived
-    assert out["cost_is_integral"]
+    if city.cost_float is None:
+        assert out["cost_is_integral"]
+    else:
+        # the reference read the float table back from the CSV unchanged, and its RoadCost is the truncation
+        F = city.cost_float
+        assert not out["cost_is_integral"] and (out["cost_float"] == F).all()
+        assert (np.trunc(F) != np.rint(F)).any() and (F == 9.9).any() and (F == 10.0).any() and (F == 0.4).any()
+        assert (np.trunc(F) != np.trunc(F.T)).any(), "no asymmetric pair"
+        assert (out["o_value"] == np.trunc(F[out["o_delivery"], out["o_pickup"]])).all()
     assert (out["cost"] == city.cost).all()
     import random
     if focus is None:
@@ -191,7 +205,7 @@ def generate(name, spec, real=False, shipped=False):
         assert (synth.init_vehicle_nodes(random.Random(run["seed"]), city.N, run["V"], valid) == out["veh_node"]).all()
         assert (out["veh_cluster"] == out["node2cluster"][out["veh_node"]]).all()
     meta = dict(city_seed=np.int64(spec["city"]["seed"]), city_mode=np.str_(spec["city"].get("mode", "cluster")),
-                city_side_m=np.float64(spec["city"].get("side_m", 800.0)),
+                city_side_m=np.float64(spec["city"].get("side_m", 800.0)), city_frac=np.bool_(spec["city"].get("frac", False)),
                 empty=np.array(spec.get("empty", []), dtype=np.int32),
                 order_seed=np.int64(spec["oseed"]), n_orders_raw=np.int64(spec["O"]),
                 focus_bound=np.array(spec.get("focus", ()), dtype=np.float64), cluster_mode=np.str_(run["cluster_mode"]),

@@ -10,6 +10,7 @@ import pytest
 from helpers import dispatch_by_tick, engine_settings, golden_names, load_golden, make_oracle
 from oracle.oracle import Oracle
 from vehicles_dispatch_simulator_amd import BatchedDispatchEnv, synth
+from vehicles_dispatch_simulator_amd.env import neighbors_to_csr
 
 pytestmark = pytest.mark.gpu
 
@@ -166,8 +167,16 @@ MODES = {
     "dense_ring_far": {"dense_debug": (8, 0, 0, 2), "ring_ticks": 2},
     "rows": {"force_generic": 5},            # wide layout + the row-mapped kernel where the dense tick is the default
     "rows_far": {"force_generic": 5, "ring_ticks": 2},
+    # a ring horizon beyond the dense keys' 32 slots (any power of two is valid): the library keeps the wide layout and must not
+    # leave the dense tick's static-arrival-slot flag behind - observations and arrival lists read D.arr only when the dense tick
+    # wrote it
+    "ring64": {"ring_ticks": 64},
 }
 DENSE = [m for m in MODES if m.startswith("dense")]
+# every mode on a representative handful of fixtures; the default kernels, the generic kernels and the far path on all of them
+# (the full product was 17 modes x 19 fixtures: most of the GPU suite's run time for pairs that add no new path)
+ALL_MODES_ON = ("tiny_kmeans", "tiny_grid", "tiny_dispatch", "tiny_sort_ties", "tiny_fraccost", "tiny_kmeans_dfs2", "tiny_dispatch_dfs2", "tiny_window4_dfs2")
+BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dense16", "ring64")
 
 
 def _applies(name, mode):
@@ -176,6 +185,8 @@ def _applies(name, mode):
     the fallback neighbour-search kernel on fixtures without neighbour search."""
     g = load_golden(name)
     searching = bool(g["neighbor_can_server"]) and int(g["depth_limit"]) > 0
+    if name not in ALL_MODES_ON and mode not in BASE_MODES:
+        return False
     if mode.startswith("dense") or mode.startswith("rows"):
         return not searching and "window" not in name
     if mode.startswith("dfs_"):
@@ -324,3 +335,50 @@ def test_zero_copy_torch_observations_match_host_read():
     np.testing.assert_array_equal(ct[:, 0] - ct[:, 1], cn[:, 2])
     np.testing.assert_array_equal(ct[:, 6], cn[:, 4]); np.testing.assert_array_equal(ct[:, 7], cn[:, 5])
     env.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_fraccost", "tiny_fraccost_dfs2"])
+def test_fractional_road_costs_float_array_and_data_dir(name, tmp_path):
+    """The float boundary (north_star: "within 1e-6 on float distances"): the only floating point on the path is ``int(float)``
+    in ``RoadCost`` (simulator.py:263-264).  The fixtures were captured from the unmodified reference fed an ``AccurateMap.csv``
+    in FRACTIONAL minutes (9.9 / 10.0 / 0.4, asymmetric pairs).  (a) the float matrix handed to ``BatchedDispatchEnv`` as is,
+    (b) the same table read from a reference-style data directory by ``world.load_world`` (neighbour table computed by the HIP
+    reduction - no cache file).  Once truncated the path is integer: results are bit-exact, tolerance 0."""
+    import os
+    import time
+    from oracle.ref_harness import write_reference_data_dir
+    from vehicles_dispatch_simulator_amd import world
+    g = load_golden(name)
+    F = g["cost_float"]
+    assert F.dtype == np.float64 and (np.trunc(F) != np.rint(F)).any() and (np.trunc(F) == g["cost"]).all()
+
+    def day(cost, node2cluster, nbr_off, nbr_idx, depth, rel, pk, dl):
+        env = BatchedDispatchEnv(cost, node2cluster, nbr_off, nbr_idx, replicas=2, vehicles=int(g["V"]), depth_limit=depth,
+                                 neighbor_can_server=bool(g["neighbor_can_server"]), **engine_settings(g))
+        env.load_orders(rel, pk, dl)
+        env.reset(np.tile(g["veh_node"], (2, 1)))
+        for t in range(env.T):
+            env.step()
+            cn = env.counters()
+            assert cn[1, 0] == g["t_order_num"][t] and cn[1, 1] == g["t_reject_num"][t] and cn[1, 3] == g["t_wait_sum"][t], t
+            np.testing.assert_array_equal(env.obs()["supply"][1], g["t_supply"][t])
+            env.advance()
+        od, cn = env.orders(), env.counters()
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(od[k][1], g["o_" + k], err_msg=k)
+        assert cn[1, 6] == int(g["sum_order_value"]) and cn[1, 3] == int(g["wait_sum"])
+        env.close()
+
+    day(F, g["node2cluster"], g["nbr_off"], g["nbr_idx"], int(g["depth_limit"]), g["o_release_min"], g["o_pickup"], g["o_delivery"])
+
+    city = synth.make_city(int(g["city_seed"]), N=int(g["N"]), C=int(g["C"]), frac=True)
+    start, pick, dele = synth.make_orders(int(g["order_seed"]), city.N, int(g["n_orders_raw"]))
+    os.environ["TZ"] = "UTC"
+    time.tzset()
+    write_reference_data_dir(str(tmp_path), city, start, pick, dele, n_drivers=int(g["V"]), cluster_mode=str(g["cluster_mode"]))
+    W = world.load_world(os.path.join(str(tmp_path), "data"), cluster_mode=str(g["cluster_mode"]), local_region_bound=synth.DEFAULT_BOUND,
+                         side_length_meter=float(g["side_m"]), vehicles_service_meter=float(g["service_m"]))
+    np.testing.assert_array_equal(W.cost, g["cost"])
+    off, idx = neighbors_to_csr(W.neighbors)
+    np.testing.assert_array_equal(idx, g["nbr_idx"])
+    day(W.cost, W.node2cluster, off, idx, W.depth_limit, W.o_release_min, W.o_pickup, W.o_delivery)

@@ -90,6 +90,7 @@ def test_bench_under_torch_distributed_run_one_rank():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 0
     assert out["collective"]["backend"] == "nccl" and out["collective"]["allreduce_calls"] >= 2
+    assert out["collective"]["allreduce_us"] > 0 and out["per_rank"]["first_replica"] == [0]       # (event-timed RCCL all-reduce)
     assert out["parity_check_vs_oracle"] is True
     assert out["aggregate_counters_last_day"]["order_num"] == 128 * 199999
     assert 0 < out["roofline"]["frac"] <= 1.0

@@ -72,6 +72,14 @@ def test_bench_py_itself_with_two_ranks():
     assert out["value"] > 0 and abs(out["value"] - 148 * 2 * Rr * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     w = workloads.didi_day("cfg2")
     init = w.vehicle_nodes(2 * Rr)               # global replica seeds: rank 1 owns replicas Rr .. 2 Rr - 1
+    # rank r's first replica is GLOBAL replica r R: its start nodes are the draws of random.Random(veh_seed + r R)
+    import zlib
+    pr = out["per_rank"]
+    assert pr["first_replica"] == [0, Rr] and pr["first_replica_seed"] == [w.veh_seed, w.veh_seed + Rr]
+    assert pr["first_replica_nodes_crc32"] == [zlib.crc32(np.ascontiguousarray(init[0]).tobytes()), zlib.crc32(np.ascontiguousarray(init[Rr]).tobytes())]
+    assert pr["first_replica_nodes_crc32"][0] != pr["first_replica_nodes_crc32"][1]
+    assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_max"] == max(pr["ms_per_step"]) and abs(pr["ms_per_step_max"] - out["ms_per_step"]) < 1e-6 * out["ms_per_step"]
+    assert out["collective"]["allreduce_us"] > 0
     exp = dict(order_num=0, reject_num=0, wait_sum=0, evals=0)
     for r in range(2 * Rr):
         o = Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server,

@@ -17,6 +17,8 @@ def rebuild_inputs(g):
         kw["side_m"] = float(g["city_side_m"])
     else:
         kw["C"] = int(g["C"])
+    if "city_frac" in g and bool(g["city_frac"]):
+        kw["frac"] = True          # AccurateMap.csv in fractional minutes (tiny_fraccost*)
     city = synth.make_city(**kw)
     if len(g["empty"]):
         lab = city.node2cluster.copy()
@@ -29,7 +31,7 @@ def rebuild_inputs(g):
 
 
 @pytest.mark.parametrize("name", ["tiny_grid", "tiny_kmeans_dfs2", "tiny_empty_clusters_dfs2", "tiny_grid_nbr_scarce", "tiny_focus_grid",
-                                  "tiny_sort_ties", "tiny_dispatch_delay", "tiny_nbr_empty"])
+                                  "tiny_sort_ties", "tiny_dispatch_delay", "tiny_nbr_empty", "tiny_fraccost", "tiny_fraccost_dfs2"])
 def test_loader_matches_reference_tables(name, tmp_path):
     g = load_golden(name)
     city, start, pick, dele = rebuild_inputs(g)
@@ -50,6 +52,13 @@ def test_loader_matches_reference_tables(name, tmp_path):
     W = world.load_world(os.path.join(str(tmp_path), "data"), cluster_mode=str(g["cluster_mode"]), local_region_bound=bound,
                          side_length_meter=float(g["side_m"]), vehicles_service_meter=float(g["service_m"]), focus_on_local_region=focus)
     np.testing.assert_array_equal(W.cost, g["cost"])
+    if "cost_float" in g:
+        # fractional minutes in AccurateMap.csv: the loader truncates toward zero like int() in RoadCost (simulator.py:263-264);
+        # g["cost"] is what the reference's own RoadCost returned, g["cost_float"] the table it read
+        import pandas as pd
+        table = pd.read_csv(os.path.join(str(tmp_path), "data", "AccurateMap.csv"), header=None).values
+        np.testing.assert_array_equal(table, g["cost_float"])
+        assert (np.rint(table) != W.cost).any() and (table == 9.9).any() and W.cost[table == 9.9].max() == 9
     np.testing.assert_array_equal(W.node2cluster, g["node2cluster"])
     assert W.n_clusters == int(g["C"]) and W.depth_limit == int(g["depth_limit"])
     nbr = [g["nbr_idx"][g["nbr_off"][c]:g["nbr_off"][c + 1]].tolist() for c in range(int(g["C"]))]

@@ -97,6 +97,7 @@ def build(force: bool = False) -> str:
     """Compile ``csrc/*.hip`` for gfx950 into ``libvds.so`` (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vds.h"))
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vds_debug.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", CSRC])

@@ -58,7 +58,10 @@ class BatchedDispatchEnv:
             msg = self._lib.vds_last_error(None).decode()
             self._h = C.c_void_p()
             raise Exception("vds_create failed (%d): %s" % (rc, msg))
-        cost = _i32(cost)
+        # a float matrix (fractional minutes, as AccurateMap.csv may hold them) is truncated toward zero like int() in
+        # RoadCost (simulator.py:263-264): pinned by the reference-captured fixtures tiny_fraccost*
+        from .synth import road_cost_table
+        cost = road_cost_table(cost)
         self.N = cost.shape[0]
         assert cost.shape == (self.N, self.N)
         node2cluster, nbr_off, nbr_idx = _i32(node2cluster), _i32(nbr_off), _i32(nbr_idx)

@@ -77,6 +77,7 @@ class City:
     mode: str = "cluster"     # "cluster" (label file) or "grid"
     grid_w: int = 0
     grid_h: int = 0
+    cost_float: Optional[np.ndarray] = None   # [N, N] float64 when AccurateMap.csv holds fractional minutes (cost == trunc)
 
     @property
     def lon(self) -> np.ndarray:
@@ -286,9 +287,36 @@ def lattice_cost(seed: int, ix: np.ndarray, iy: np.ndarray, minutes_per_m_inv: i
     return cost
 
 
+def fractional_lattice_cost(seed: int, ix: np.ndarray, iy: np.ndarray, minutes_per_m_inv: int = 280) -> np.ndarray:
+    """The same asymmetric lattice as ``lattice_cost`` in FRACTIONAL minutes, one decimal (costs
+    "rounded to 0.1"): what a real ``AccurateMap.csv`` may hold.  ``RoadCost`` (``simulator.py:263-264``) applies
+    ``int()`` - truncation toward zero - so 9.9 is 9 and 10.0 is 10; rounding would give 10 for both."""
+    ix = np.asarray(ix, dtype=np.int64)
+    iy = np.asarray(iy, dtype=np.int64)
+    N = ix.size
+    idx = np.arange(N, dtype=np.int64)
+    dm = (np.abs(ix[:, None] - ix[None, :]) * 957 + np.abs(iy[:, None] - iy[None, :]) * 1110) // 10000
+    pair = (idx[:, None] * np.int64(N) + idx[None, :]).astype(_U64)
+    noise = (hash_u64(seed, 41, pair.ravel()) % _U64(300)).astype(np.int64).reshape(N, N)
+    tenths = (dm * (1000 + noise)) // (minutes_per_m_inv * 100)          # integer tenths of a minute
+    cost = tenths.astype(np.float64) / 10.0
+    np.fill_diagonal(cost, 0.0)
+    return np.round(cost, 1)
+
+
+def road_cost_table(cost) -> np.ndarray:
+    """``RoadCost`` for every pair at once: ``int(Map[a][b])`` (``simulator.py:263-264``) truncates toward zero.  The
+    tick path holds these integers only; a float matrix (fractional minutes in ``AccurateMap.csv``) is truncated HERE,
+    once, exactly as the reference truncates at every call."""
+    a = np.asarray(cost)
+    if a.dtype.kind == "f":
+        a = np.trunc(a)
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
 def make_city(seed: int, N: int = 4139, C: int = 192, mode: str = "cluster",
               bound=DEFAULT_BOUND, side_m: float = 800.0, minutes_per_m_inv: int = 280,
-              with_neighbors: bool = True) -> City:
+              with_neighbors: bool = True, frac: bool = False) -> City:
     """Build a synthetic city.
 
     ``mode="cluster"``: ``C`` k-means-shaped clusters (label file semantics).
@@ -300,7 +328,12 @@ def make_city(seed: int, N: int = 4139, C: int = 192, mode: str = "cluster",
     ix, iy = _node_lattice(seed, N, span_x, span_y)
     node_id = (np.int64(1_000_000_007) + np.argsort(np.argsort(hash_u64(seed, 31, np.arange(N)), kind="stable"), kind="stable") * 7919).astype(np.int64)
 
-    cost = lattice_cost(seed, ix, iy, minutes_per_m_inv)
+    cost_float = None
+    if frac:
+        cost_float = fractional_lattice_cost(seed, ix, iy, minutes_per_m_inv)
+        cost = road_cost_table(cost_float)
+    else:
+        cost = lattice_cost(seed, ix, iy, minutes_per_m_inv)
 
     gw = gh = 0
     if mode == "grid":
@@ -327,7 +360,7 @@ def make_city(seed: int, N: int = 4139, C: int = 192, mode: str = "cluster",
         node2cluster = _lloyd_labels(seed, ix, iy, C)
         neighbors = cluster_neighbors_from_cost(cost, node2cluster, C) if with_neighbors else [[] for _ in range(C)]
     return City(N=N, C=C, bound=tuple(bound), ix=ix, iy=iy, node_id=node_id, node2cluster=node2cluster,
-                cost=cost, neighbors=neighbors, mode=mode, grid_w=gw, grid_h=gh)
+                cost=cost, neighbors=neighbors, mode=mode, grid_w=gw, grid_h=gh, cost_float=cost_float)
 
 
 # hour-of-day weights: peaks at 09h, 13h and 18h, quiet night (SURVEY 8d "Cfg 2")

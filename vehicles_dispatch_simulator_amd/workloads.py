@@ -117,6 +117,17 @@ def tiny(name: str = "tiny", *, N: int = 300, C: int = 12, vehicles: int = 150, 
                     veh_seed=seed + 2)
 
 
+# Calibration of the CPU baseline's kind "port" (bench.py `cpu_baseline`): the C oracle against the REFERENCE ITSELF on identical inputs,
+# measured in the build container (the reference cannot travel to the GPU box).  Recipe: tests/golden/<fixture>.npz holds `ref_sim_s`, the
+# wall time of the unmodified reference's SimCity() on that day (tests/golden/make_golden.py, one core); the oracle replays the same day
+# (`helpers.make_oracle(g); o.reset(g["veh_node"]); o.run_day()`, median of 5).  reference_s / oracle_s:
+REFERENCE_CALIBRATION = {
+    "cfg2": {"fixture": "real_kmeans192", "reference_sim_s": 41.67, "oracle_s": 0.0407, "reference_ratio": 1024.0},
+    "cfg4": {"fixture": "real_spectral192_dfs2", "reference_sim_s": 82.59, "oracle_s": 0.1168, "reference_ratio": 707.0},
+    "where": "build container (one core of its host CPU), round 5; the ratio, not the absolute times, is what carries to another host",
+}
+
+
 def algorithmic_bytes(work: dict, vehicles: int) -> int:
     """SURVEY.md 8(d) byte model of the tick path: 16 B per (order, candidate) evaluation
     (idle entry 8 + vehicle location 4 + cost 4), 24 B per processed order, 24 B per match,

@@ -159,7 +159,7 @@ def load_world(data_dir: str, *, cluster_mode: str, local_region_bound, side_len
     node_id = read_node_id_list(os.path.join(data_dir, "NodeIDList.txt"))
     index = {int(v): i for i, v in enumerate(node_id)}
     cost = pd.read_csv(os.path.join(data_dir, "AccurateMap.csv"), header=None).values
-    cost = np.trunc(cost).astype(np.int32)                               # RoadCost = int(...) (simulator.py:264)
+    cost = synth.road_cost_table(cost)                                   # RoadCost = int(...) (simulator.py:264): truncation
     N = node_id.size
     # Node.csv rows are in their own order; internal id = position in NodeIDList (simulator.py:406,590)
     row_internal = np.array([index[int(v)] for v in node["NodeID"].values], dtype=np.int64)
