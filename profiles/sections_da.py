@@ -1,0 +1,35 @@
+"""Per-section cycle attribution of the hybrid tick's second kernel in its deferred-acceptance form (k_dfs_walk<.., DA = true>,
+instrumented build):  make -C vehicles_dispatch_simulator_amd/csrc prof;  VDS_LIB=libvds_prof.so python profiles/sections_da.py [replicas]"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np, torch
+from vehicles_dispatch_simulator_amd import workloads
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
+env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
+env.reset(w.vehicle_nodes(R))
+T = env.T
+assert env.main_kernel() == "k_dfs_hybrid"
+buf = np.zeros(32, dtype=np.uint64)
+env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
+env._lib.vds_debug_ablate(env._h, 128)
+env.profile(True); env.run(T); ms = env.profile_read(T + 8); env.profile(False)
+env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
+env._lib.vds_debug_ablate(env._h, 0)
+b = buf.astype(np.float64)
+RT = R * T
+print("instrumented: %.3f ms per tick (both kernels)" % ms.mean())
+print("per replica-tick: %.1f dry orders scanned in %.1f scans (%.0f cycles each), %.2f scans asked for again (every candidate taken), %.2f dry holders displaced, %.1f re-pick chains" % (
+    b[2] / RT, b[11] / RT, b[10] / max(1, b[11]), b[4] / RT, b[6] / RT, b[3] / RT))
+print("per wavefront and tick (cycles): scanning %.0f, chains %.0f, claim %.0f, proposals %.0f, waiting for work / the others %.0f" % (
+    b[10] / RT / 4, b[9] / RT / 4, b[12] / RT / 4, b[13] / RT / 4, b[8] / RT / 4))
+sc = [b[16 + i] / max(1, b[11]) for i in range(5)]
+print("one scan: visit row + bounds %.0f, alive counts %.0f, first pass %.0f, second pass %.0f, the K best %.0f cycles; %.2f eight-slot groups" % (
+    sc[0], sc[1], sc[2], sc[3], sc[4], b[21] / max(1, b[11])))
+sec = [("tables (ranks, lengths) + barrier", 24), ("prefix of the list lengths + barrier", 25), ("stamps from the preliminary results", 26), ("dry bits + barrier", 0),
+       ("deferred acceptance (all wavefronts)", 1), ("results + steal log off the final stamps", 14), ("steal log -> results, tk", 29),
+       ("evaluations (a): dry orders' visit rows", 30), ("evaluations (b): steals per searching cluster", 31), ("reduce + closed form + barrier", 5),
+       ("resolve: vehicle ids, arrivals, counters", 27), ("compaction, lists up to 64", 28), ("compaction, longer lists", 7)]
+tot = sum(b[i] for _, i in sec)
+for n, i in sec:
+    print("%-50s %9.0f cycles/wave/tick  %5.1f%%" % (n, b[i] / (R * 4) / T, 100.0 * b[i] / tot))

@@ -18,6 +18,19 @@ TINY = golden_names("tiny_")
 
 
 def make_env(g, R, **kw):
+    environ = kw.pop("environ", None)
+    if environ:       # library switches read when the order tables are loaded (e.g. VDS_WALK_DA=0: the serial walk of rounds 2-4)
+        import os
+        saved = {k: os.environ.get(k) for k in environ}
+        os.environ.update(environ)
+        try:
+            return make_env(g, R, **kw)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     env = BatchedDispatchEnv(g["cost"], g["node2cluster"], g["nbr_off"], g["nbr_idx"], replicas=R, vehicles=int(g["V"]),
                              depth_limit=int(g["depth_limit"]), neighbor_can_server=bool(g["neighbor_can_server"]),
                              **{**engine_settings(g), **kw})
@@ -150,6 +163,7 @@ MODES = {
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
     "dfs_v2": {"force_generic": 3},          # neighbour search by lower-bound rounds (k_tick_replica2: what the hybrid tick falls back to)
+    "dfs_walk": {"environ": {"VDS_WALK_DA": "0"}},      # hybrid tick with the serial walk of rounds 2-4 instead of deferred acceptance (the default)
     # dense tick (k_tick_dense: the default without neighbour search; 8 lanes per replica by default) - 16 lanes per replica; tiny fast-path tables
     # (buckets that outgrow them take dense_bucket_slow); slow path only; far tables.  With neighbour search or a live pickup
     # window the library keeps the wide layout (these fixtures then repeat the default run).
@@ -176,7 +190,7 @@ DENSE = [m for m in MODES if m.startswith("dense")]
 # every mode on a representative handful of fixtures; the default kernels, the generic kernels and the far path on all of them
 # (the full product was 17 modes x 19 fixtures: most of the GPU suite's run time for pairs that add no new path)
 ALL_MODES_ON = ("tiny_kmeans", "tiny_grid", "tiny_dispatch", "tiny_sort_ties", "tiny_fraccost", "tiny_kmeans_dfs2", "tiny_dispatch_dfs2", "tiny_window4_dfs2")
-BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dense16", "ring64")
+BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dfs_walk", "dense16", "ring64")
 
 
 def _applies(name, mode):
