@@ -1,6 +1,7 @@
 """Per-section cycle attribution of the hybrid tick's second kernel in its deferred-acceptance form (k_dfs_walk<.., DA = true>,
 instrumented build):  make -C vehicles_dispatch_simulator_amd/csrc prof;  VDS_LIB=libvds_prof.so python profiles/sections_da.py [replicas]"""
-import sys
+import os, sys
+os.environ["VDS_WALK_DA"] = "1"
 sys.path.insert(0, ".")
 import numpy as np, torch
 from vehicles_dispatch_simulator_amd import workloads
@@ -9,7 +10,7 @@ w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
 T = env.T
-assert env.main_kernel() == "k_dfs_hybrid"
+assert env.main_kernel() == "k_dfs_hybrid_da"
 buf = np.zeros(32, dtype=np.uint64)
 env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
 env._lib.vds_debug_ablate(env._h, 128)

@@ -20,9 +20,9 @@ CSRC = os.path.join(ROOT, "vehicles_dispatch_simulator_amd", "csrc")
 
 def build(target, name):
     path = os.path.join(ROOT, "build", name)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "vds.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "vds.h"), os.path.join(ROOT, "include", "vds_debug.h")]
     if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", CSRC, target])
+        subprocess.check_call(["make", "-s", "-j8", "-C", CSRC, target])
     return path
 
 
@@ -53,8 +53,8 @@ print("WORKER DONE")
 """
 
 
-def run_worker(lib, suffix, cases):
-    env = dict(os.environ, VDS_LIB=lib)
+def run_worker(lib, suffix, cases, **environ):
+    env = dict(os.environ, VDS_LIB=lib, **environ)
     p = subprocess.run([sys.executable, "-c", WORKER % (ROOT, suffix, cases)], env=env, capture_output=True, text=True, timeout=900)
     out = p.stdout + p.stderr
     assert p.returncode == 0 and "WORKER DONE" in out, out[-3000:]
@@ -67,6 +67,9 @@ def test_self_checking_walk_build():
     out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)])
     assert "k_dfs_hybrid" in out
     assert "check" not in out.replace("vds_debug_check", ""), out[-3000:]
+    # (the deferred-acceptance form has no walk that could count the evaluations a second time: its bounds checks only)
+    out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 5, 90, None)], VDS_WALK_DA="1")
+    assert "k_dfs_hybrid_da" in out and "check" not in out.replace("vds_debug_check", ""), out[-3000:]
 
 
 def test_guarded_build_all_tick_paths():
@@ -75,6 +78,10 @@ def test_guarded_build_all_tick_paths():
              (False, 1, 5, 150, None), (False, 5, 37, 150, None), (True, 0, 9, 40, None), (True, 3, 6, 40, None), (True, 1, 3, 40, None)]
     out = run_worker(lib, "+canary", cases)
     assert out.count("ok ") == len(cases)
+    # the hybrid tick with the dry orders by deferred acceptance: scarce vehicles, most orders dry
+    da = [(True, 0, 9, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)]
+    out = run_worker(lib, "+canary", da, VDS_WALK_DA="1")
+    assert out.count("ok ") == len(da) and out.count("k_dfs_hybrid_da") == len(da)
 
 
 def test_guarded_build_replica_days_and_dispatch():

@@ -22,11 +22,18 @@ def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_df
     rel = synth.release_minutes(start)
     off, idx = neighbors_to_csr(city.neighbors)
     results = {}
-    for mode in (0, 3, 1):
+    import os
+    # mode 7: the hybrid tick with the dry orders served by deferred acceptance (VDS_WALK_DA=1, read when the orders are loaded)
+    for mode in (0, 3, 1) + ((7,) if kernel0 == "k_dfs_hybrid" else ()):
         env = BatchedDispatchEnv(city.cost, city.node2cluster, off, idx, replicas=R, vehicles=V, depth_limit=depth,
-                                 neighbor_can_server=True, force_generic=mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
-        env.load_orders(rel, pick, dele)
-        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs"}[mode]
+                                 neighbor_can_server=True, force_generic=0 if mode == 7 else mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
+        if mode == 7:
+            os.environ["VDS_WALK_DA"] = "1"
+        try:
+            env.load_orders(rel, pick, dele)
+        finally:
+            os.environ.pop("VDS_WALK_DA", None)
+        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs", 7: "k_dfs_hybrid_da"}[mode]
         env.reset(init)
         env.run(env.T)
         results[mode] = (env.orders(), env.counters(), env.obs(), [env.lists(r) for r in range(R)])

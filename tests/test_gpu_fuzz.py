@@ -84,12 +84,12 @@ def medium_case(seed):
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_MEDIUM_N", "40")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_MEDIUM_N", "30")))))
 def test_medium_city_matches_oracle(seed):
     run_case(seed, medium_case(seed), idle_cap=1024)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "400")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "160")))))
 def test_random_city_matches_oracle(seed):
     run_case(seed, random_case(seed))
 
@@ -110,7 +110,14 @@ def run_case(seed, case, idle_cap=None):
     env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
                              tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
                              force_generic=fg, idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V), **kw)
-    env.load_orders(rel, pick, dele)
+    # half of the cases with neighbour search on the default kernels: the hybrid tick's dry orders by deferred acceptance (VDS_WALK_DA=1,
+    # read when the orders are loaded) instead of the serial walk
+    if fg == 0 and cfg["neighbor"] and lr.random() < 0.5:
+        os.environ["VDS_WALK_DA"] = "1"
+    try:
+        env.load_orders(rel, pick, dele)
+    finally:
+        os.environ.pop("VDS_WALK_DA", None)
     env.reset(init)
     oracles = []
     for r in range(R):
@@ -190,7 +197,7 @@ def days_case(seed):
 
 # 1906: one cluster, 134 vehicles, per-row days - a row without an order at a match step while its 128-slot table is full (the
 # round-3 tag-register match loop retired slot 127 of such a row)
-DAYS_SEEDS = sorted(set(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "400")))) | {1906})
+DAYS_SEEDS = sorted(set(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "160")))) | {1906})
 
 
 @pytest.mark.parametrize("seed", DAYS_SEEDS)

@@ -163,7 +163,7 @@ MODES = {
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
     "dfs_v2": {"force_generic": 3},          # neighbour search by lower-bound rounds (k_tick_replica2: what the hybrid tick falls back to)
-    "dfs_walk": {"environ": {"VDS_WALK_DA": "0"}},      # hybrid tick with the serial walk of rounds 2-4 instead of deferred acceptance (the default)
+    "dfs_da": {"environ": {"VDS_WALK_DA": "1"}},        # hybrid tick with the dry orders served by deferred acceptance instead of the serial walk
     # dense tick (k_tick_dense: the default without neighbour search; 8 lanes per replica by default) - 16 lanes per replica; tiny fast-path tables
     # (buckets that outgrow them take dense_bucket_slow); slow path only; far tables.  With neighbour search or a live pickup
     # window the library keeps the wide layout (these fixtures then repeat the default run).
@@ -190,7 +190,7 @@ DENSE = [m for m in MODES if m.startswith("dense")]
 # every mode on a representative handful of fixtures; the default kernels, the generic kernels and the far path on all of them
 # (the full product was 17 modes x 19 fixtures: most of the GPU suite's run time for pairs that add no new path)
 ALL_MODES_ON = ("tiny_kmeans", "tiny_grid", "tiny_dispatch", "tiny_sort_ties", "tiny_fraccost", "tiny_kmeans_dfs2", "tiny_dispatch_dfs2", "tiny_window4_dfs2")
-BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dfs_walk", "dense16", "ring64")
+BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dfs_da", "dense16", "ring64")
 
 
 def _applies(name, mode):

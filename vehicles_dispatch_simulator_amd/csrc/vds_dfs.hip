@@ -183,7 +183,9 @@ struct RowRank<0> {
 #define DEAD 0xFFFF
 #define CAPABLE (1 << 30)
 #ifndef PRUNE_DELTA
+#ifndef PRUNE_DELTA
 #define PRUNE_DELTA 2                       // first scan pass: candidate clusters whose cost bound is within this of the smallest
+#endif
 #endif
 #ifndef SLOTS
 #define SLOTS 12                            // candidates per lane of an 8-lane group held in registers
@@ -809,7 +811,10 @@ __global__ __launch_bounds__(REPL_THREADS, REPL2_MIN_WAVES) void k_tick_replica2
 #define WK_PRIO 0                           // s_setprio of wavefront 0 while it serves the chain of dry orders
 #endif
 #define WK_FREE 0xFFFFu
-#define WK_K 3                              // candidates kept per scanned dry order (2-4 measure the same; 8 costs 2 % in the extraction loop)
+#ifndef WK_K
+#define WK_K 3
+#endif
+//                                             candidates kept per scanned dry order (2-4 measure the same; 8 costs 2 % in the extraction loop)
 #define WK_NS 32                            // pool of scan records (the second order of a paired scan may wait there for a while):
 #define WK_NS_MIN 8                         // Static.walk_pool of them, as many as keep the workgroup within a quarter of a CU's LDS
 #define WK_REC (4 * WK_K + 6)               // one scan record (ints): WK_K candidates {cost << 16 | visit index << 8 | 64-entry chunk of the
@@ -832,7 +837,9 @@ static_assert(WK_G >= 1 && WK_G <= 3, "dfs_scan is instantiated for 1, 2 and 3 o
 #ifndef WK_RES
 #define WK_RES 10                           // orders a thread resolves at a time (their loads in flight together)
 #endif
+#ifndef WK_SLACK
 #define WK_SLACK 1                          // second scan pass: clusters whose cost bound is within this of the best cost found
+#endif
 #ifdef WKDEBUG
 #define WKCHK(cond, code, a, b2) do { if (!(cond)) { printf("k_dfs_walk check %d failed: r %d t %d lane %d  %d %d\n", code, (int)blockIdx.x, t, (int)threadIdx.x, (int)(a), (int)(b2)); return; } } while (0)
 #else
@@ -1360,12 +1367,16 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             int g = 1;
             rk[0] = b;
 #pragma unroll
-            for (int o = 0; o < WK_G; ++o) pn[o] = S.so_pnode[min(q + o, tq1 - 1)];
-            const int bucket = (int)((unsigned)S.so_rec[q].z >> 16);
+            for (int o = 0; o < WK_G; ++o) pn[o] = S.so_pnode[min(q + o, tq1 - 1)];      // (first needed by the cost gathers: in flight under the visit rows)
+            int qe = tq1;                           // end of the order's bucket: the smallest qend_l above q (no HBM round trip)
+            for (int cb = 0; cb < C; cb += WAVE) {
+                const int ce = cb + lane < C ? qend_l[cb + lane] : IMAX;
+                qe = min(qe, wave_min_i32(ce > q ? ce : IMAX));
+            }
 #pragma unroll
             for (int o = 1; o < WK_G; ++o) {
                 rk[o] = -1;
-                if (g == o && q + o < qend_l[bucket]) {
+                if (g == o && q + o < qe) {
                     const int r2 = (int)rq_l[q + o - tq0];
                     int won2 = 0;
                     if (lane == 0) won2 = (int)((atomicAnd(&scn_bits[r2 >> 5], ~(1u << (r2 & 31))) >> (r2 & 31)) & 1u);
@@ -1453,34 +1464,63 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     {
         int4 *slog_w = D.slog + (size_t)r * mto;
         const int total = moff_l[C];
-        for (int i = threadIdx.x; i < total; i += WK_THREADS) {
-            const int sv = (int)st_l[i];
-            if (sv == (int)WK_FREE) continue;
-            const bool isdry = (dry_bits[sv >> 5] >> (sv & 31)) & 1u;
-            if (!isdry && !((chg_bits[sv >> 5] >> (sv & 31)) & 1u)) continue;
-            int lo = 0, hi = C;                                  // cluster of stamp index i: the last c with moff_l[c] <= i
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (moff_l[mid] <= i) lo = mid; else hi = mid; }
-            const int c = lo, pos = i - moff_l[c];
-            const int y = tq0 + (int)qr_l[sv];
-            const int lo2 = (int)(D.idle[((size_t)c * S.R + r) * S.idle_cap + pos].y & 0xFFFF);
-            const int cda = cdA_l[c];
-            if (isdry) {
-                const int pn0 = S.so_pnode[y];
-                const char *crow = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)pn0 * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)pn0 * S.N);
-                const int cst = cost_elem<U8>(crow, (unsigned)(((cda >> 11) & 0xFFFF) + lo2));
-                // orders of bucket c with a smaller rank (ranks ascend with the sorted position inside a bucket)
-                const int qa0 = (c == 0 ? tq0 : qend_l[c - 1]) - tq0;
-                int a0 = qa0, a1 = qend_l[c] - tq0;
-                while (a0 < a1) { const int mid = (a0 + a1) >> 1; if ((int)rq_l[mid] < sv) a0 = mid + 1; else a1 = mid; }
-                const int kb = a0 - qa0;
-                const int n = atomicAdd(&s_nlog, 1);
-                slog_w[n] = make_int4(sv, c | (kb << 16), (int)(((unsigned)c << 16) | (unsigned)pos), cst);
-                atomicAdd(&ls_l[c], 1);
-            } else {
-                const int4 cd = S.cdesc[c];
-                const int pick = S.so_rec[y].y & 0xFFFF;
-                const int cst = cost_elem<U8>(blk_b, (unsigned)((U8 ? cd.z : cd.y) + pick * (cda & 2047) + lo2));
-                out_r[y] = make_int2((int)(((unsigned)c << 16) | (unsigned)pos), cst);
+        // (a thread first finds up to four entries of its stride that moved, then issues their loads together: the entries are few -
+        // ~75 of ~7000 at configs[3] - and every one costs three dependent loads)
+        int i = (int)threadIdx.x;
+        while (i < total) {
+            int mi[4], msv[4];
+            int nm = 0;
+            for (; i < total && nm < 4; i += WK_THREADS) {
+                const int sv = (int)st_l[i];
+                if (sv == (int)WK_FREE) continue;
+                if (!(((dry_bits[sv >> 5] | chg_bits[sv >> 5]) >> (sv & 31)) & 1u)) continue;
+                mi[nm] = i; msv[nm] = sv; ++nm;
+            }
+            int mc[4], mpos[4], my[4], mlo[4], mx[4];
+            bool mdry[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mc[u] = 0; mpos[u] = 0; my[u] = tq0; mlo[u] = 0; mx[u] = 0; mdry[u] = false;
+                if (u < nm) {
+                    int lo = 0, hi = C;                          // cluster of stamp index i: the last c with moff_l[c] <= i
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (moff_l[mid] <= mi[u]) lo = mid; else hi = mid; }
+                    mc[u] = lo; mpos[u] = mi[u] - moff_l[lo];
+                    my[u] = tq0 + (int)qr_l[msv[u]];
+                    mdry[u] = (dry_bits[msv[u] >> 5] >> (msv[u] & 31)) & 1u;
+                    mlo[u] = (int)(D.idle[((size_t)mc[u] * S.R + r) * S.idle_cap + mpos[u]].y & 0xFFFF);
+                    mx[u] = mdry[u] ? S.so_pnode[my[u]] : (S.so_rec[my[u]].y & 0xFFFF);      // pickup node / pickup node inside its cluster
+                }
+            }
+            int mcst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mcst[u] = 0;
+                if (u < nm) {
+                    const int cda = cdA_l[mc[u]];
+                    if (mdry[u]) {
+                        const char *crow = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)mx[u] * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)mx[u] * S.N);
+                        mcst[u] = cost_elem<U8>(crow, (unsigned)(((cda >> 11) & 0xFFFF) + mlo[u]));
+                    } else {
+                        const int4 cd = S.cdesc[mc[u]];
+                        mcst[u] = cost_elem<U8>(blk_b, (unsigned)((U8 ? cd.z : cd.y) + mx[u] * (cda & 2047) + mlo[u]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nm) continue;
+                const int c = mc[u], sv = msv[u];
+                if (mdry[u]) {
+                    // orders of bucket c with a smaller rank (ranks ascend with the sorted position inside a bucket)
+                    const int qa0 = (c == 0 ? tq0 : qend_l[c - 1]) - tq0;
+                    int a0 = qa0, a1 = qend_l[c] - tq0;
+                    while (a0 < a1) { const int mid = (a0 + a1) >> 1; if ((int)rq_l[mid] < sv) a0 = mid + 1; else a1 = mid; }
+                    const int n = atomicAdd(&s_nlog, 1);
+                    slog_w[n] = make_int4(sv, c | ((a0 - qa0) << 16), (int)(((unsigned)c << 16) | (unsigned)mpos[u]), mcst[u]);
+                    atomicAdd(&ls_l[c], 1);
+                } else {
+                    out_r[my[u]] = make_int2((int)(((unsigned)c << 16) | (unsigned)mpos[u]), mcst[u]);
+                }
             }
         }
     }
@@ -2137,7 +2177,7 @@ void emit_hybrid_walk(const Emit &e, const Static &S0, const State &D, int t, in
     Static S = S0;
     S.r_lo = r_lo;
     const dim3 grid(r_n > 0 ? r_n : S.R);
-    // Static.walk_da: the dry orders by deferred acceptance (the default; its wavefronts' records and the bitmap of the
+    // Static.walk_da: the dry orders by deferred acceptance (VDS_WALK_DA=1; its wavefronts' records and the bitmap of the
     // own-cluster orders that moved live where the walk keeps its record pool)
     const bool da = S.walk_da != 0 && (size_t)(1 + S.walk_pool) * WK_REC >= (size_t)WK_WAVES * WK_G * WK_REC + (size_t)(S.max_tick_orders + 31) / 32 + 1;
     if (da) {
