@@ -1166,7 +1166,10 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     S.tdesc = nullptr;
     if (S.dense && n_days == 1 && (int)h->corder_host.size() == C) {
         const DayDesc &de = ddesc[0];
-        std::vector<int4> td((size_t)std::max(de.T, 1) * C, make_int4(0, 0, 0, 0));
+        // 32 bytes per (slot, cluster): the bucket's descriptor, then the cluster's (Static.cdesc_dense[ci]) - one scalar load
+        std::vector<int4> td((size_t)std::max(de.T, 1) * C * 2, make_int4(0, 0, 0, 0));
+        std::vector<int4> cdd((size_t)C);
+        HIPCHK(h, hipMemcpy(cdd.data(), S.cdesc_dense, (size_t)C * sizeof(int4), hipMemcpyDeviceToHost));
         for (int t = 0; t < de.T; ++t)
             for (int ci = 0; ci < C; ++ci) {
                 const int c = h->corder_host[ci];
@@ -1176,7 +1179,8 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                     clo = d_first_keep[(size_t)std::max(t - S.pull_W, 0) * C + c];
                     n = d_first_keep[(size_t)(t + 1) * C + c] - clo;
                 }
-                td[(size_t)t * C + ci] = make_int4(q0, k, clo, n);
+                td[2 * ((size_t)t * C + ci)] = make_int4(q0, k, clo, n);
+                td[2 * ((size_t)t * C + ci) + 1] = cdd[ci];
             }
         struct Sink3 { vds_handle *h; ~Sink3() { h->alloc_sink = nullptr; } } sink3{h};
         h->alloc_sink = &h->order_allocs;

@@ -147,7 +147,7 @@ struct Static {
     const unsigned char *blk8s;      // (dense, byte costs <= 254) the same as bytes, column n_c = 0xFF: the loc byte of a taken / absent
                                      // entry names that column, so the entry loses every comparison without a test in the match loop
     const int4 *cdesc_dense;         // [C] {n_c, offset into blk8s / blk32s, cluster, 0}, heaviest cluster first
-    const int4 *tdesc;               // (dense, one shared order day) [T][C] in cdesc_dense's cluster order: {first sorted order, orders, first
+    const int4 *tdesc;               // (dense, one shared order day) [T][C][2] in cdesc_dense's cluster order: {first sorted order, orders, first
                                      // candidate slot, candidate slots} of the (slot, cluster) bucket - one scalar load next to cdesc_dense's
                                      // instead of four that depend on it (the workgroup's prologue is a chain of dependent loads)
 };

@@ -939,7 +939,14 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     CT *lds_blk = reinterpret_cast<CT *>(tab_all + ROWS * (TABMAX + DN_TPAD));
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
     const int nchunks = gridDim.x / S.C;
-    const int4 cd = S.cdesc_dense[blockIdx.x / nchunks];        // {n_c, byte offset of the block, cluster, 0}
+    // {n_c, byte offset of the block, cluster, 0}.  One shared day: the cluster's descriptor sits BEHIND the bucket's in Static.tdesc
+    // (32 bytes per (slot, cluster)): ONE scalar load - two loads from two tables were issued one after the other (the second
+    // waited for a register of the first: ISA of round 4), a dependent round trip at the head of every workgroup
+    int4 cd, td0 = make_int4(0, 0, 0, 0);
+    if (DM == 0) {
+        const int4 *tp = S.tdesc + 2 * ((size_t)t * S.C + blockIdx.x / nchunks);
+        td0 = tp[0]; cd = tp[1];
+    } else cd = S.cdesc_dense[blockIdx.x / nchunks];
     const int c = cd.z, nc = cd.x;
     const int row0 = S.r_lo + (int)(blockIdx.x % nchunks) * ROWS;      // (vds_run launches the tick per replica group: rows [r_lo, r_hi))
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1003,8 +1010,8 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
         now = dd.y + t * S.tick_minutes;
         qb = dd.w;
     } else {
-        // one shared day: the bucket's descriptor sits next to the cluster's (same index, independent scalar loads)
-        const int4 td = S.tdesc[(size_t)t * S.C + blockIdx.x / nchunks];
+        // one shared day: the bucket's descriptor {first sorted order, orders, first candidate slot, candidate slots} (loaded above)
+        const int4 td = td0;
         q0 = td.x; k = td.y;
         now = S.now0 + t * S.tick_minutes;
         if (PULL) { clo = td.z; n = td.w; }
@@ -1013,25 +1020,45 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
     const bool wg_ok = k <= DN_ORDERS && n <= DN_CAND;          // (DM == 2: per row)
     unsigned *tab = tab_all + (wave * RPW + g) * (TABMAX + DN_TPAD);
-    // 1. bucket header words; PULL: the raw entries of the bucket's candidates, parked in the row's table
+    // 1. everything that depends on the two scalar descriptors only goes out TOGETHER (round 5; before: the staging loads of step 2
+    //    were issued behind the wait for the header words and the candidates - one more dependent round trip of the prologue's
+    //    chain, profiles/r04/r04_ablate_dense.txt): bucket header words, counters, the first piece of the cluster's cost block, the
+    //    bucket's order records / arrival-slot indices / candidate records (one element per thread), and - PULL - the raw entries of
+    //    the bucket's candidates, which are then parked in the row's table
     int m = 0, far = 0, A = 0;
     long long cntv = 0;
+    int4 h0 = make_int4(0, 0, 0, 0);
+    int hin = 0, rcw = 0;
     if (rowvalid) {
-        const int4 h0 = *reinterpret_cast<const int4 *>(D.hdr + b * HDR_WORDS);
-        const int hin = D.hdr[b * HDR_WORDS + HDR_INBOX0 + p];
-        m = h0.x;
-        far = h0.w | hin;
-        A = D.ring_cnt[si] & 0xFFFF;
+        h0 = *reinterpret_cast<const int4 *>(D.hdr + b * HDR_WORDS);
+        hin = D.hdr[b * HDR_WORDS + HDR_INBOX0 + p];
+        rcw = D.ring_cnt[si];            // (the raw word: masking it HERE made the compiler wait for it before the loads below went out)
         if (LPR >= CNT_WORDS && lg < CNT_WORDS && !(DN_ABL & 131072)) cntv = D.cnt[b * CNT_WORDS + lg];
     }
-    int Aring = A;
+    const char *blk_g = S.blk + cd.y;
+    const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
+    const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
+    const bool stage = DM != 2 && k > 0;
+    const bool mine = stage && (int)threadIdx.x < min(k, DN_ORDERS);
+    const bool dmine = PULL && DM != 2 && wg_ok && (int)threadIdx.x < n;
+    int4 sblk = make_int4(0, 0, 0, 0), srec = make_int4(0, 0, 0, 0);
+    int sslot = -1;
+    int2 sdrec = make_int2(0, 0);
+    if (stage && (int)threadIdx.x < n4 && !(DN_ABL & 1024)) sblk = blk4[threadIdx.x];
+    if (mine) { srec = S.so_rec[q0 + threadIdx.x]; if (PULL) sslot = S.so_slot[q0 + threadIdx.x]; }
+    if (dmine) sdrec = S.d_rec[clo + threadIdx.x];
+#ifdef DN_PREFETCH
+    // the head of the idle list (read after the barrier, once its length is known) touched now: lane lg one word of every 64 bytes
+    unsigned pfw = 0u;
+    if (rowvalid && k > 0 && lg * 16 < S.idle_cap) pfw = D.idle[b * S.idle_cap + lg * 16];
+#endif
+    int Ac = 0;
     if (PULL && wg_ok) {
         // the candidates' raw entries; those that say "slot t" are parked in the row's table, packed in candidate order (position
         // among the group's lanes from the ballot of the step): raw entry in tab[i], candidate index in tab[DN_TH + i]
         const unsigned *ar = D.arr + arr_index(S.R, clo - qdb, rowvalid ? r : 0);      // slot s of this row: ar[s * R]
         const unsigned never = pull_reject(t - 1);          // (a byte slot t does not have)
         const int gsh = lane & ~(LPR - 1);
-        int Ac = 0;
         constexpr int NIF = 4;              // loads in flight per lane (8 at 8 lanes per replica - one round for up to 64 candidates - measured: 6.99 vs 6.92 ms per day, not kept)
         for (int i0 = 0; i0 < n; i0 += NIF * LPR) {
             unsigned v[NIF];
@@ -1051,32 +1078,33 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
                 Ac += __popc(gm);
             }
         }
-        A = Aring + Ac;       // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
     }
+#ifdef DN_PREFETCH
+    asm volatile("" :: "v"(pfw));
+#endif
+    asm volatile("" : "+v"(rcw));       // (keeps the mask below out of the branch that issued the load: there it would wait for the word)
+    int Aring = rcw & 0xFFFF;
+    A = Aring + Ac;           // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
+    m = h0.x;
+    far = h0.w | hin;
     if (DN_ABL & 256) { if (m + far + A + (int)cntv == 0x7FFFFFF1) D.err[1] = 1; return; }
-    // 2. stage the cluster's cost block, the bucket's order records and - PULL - the candidates' static records in LDS
-    const char *blk_g = S.blk + cd.y;
+    // 2. the staged pieces into LDS: the cluster's cost block (what is left of it: blocks beyond one 16-byte piece per thread), the
+    //    bucket's order records and - PULL - the candidates' static records
     if (DM == 2) {
         // the cost block (some row of the workgroup almost always has an order); every row's pickup rows as offsets into it
-        const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
-        const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
         for (int i = threadIdx.x; i < n4; i += NTHR) lds4[i] = blk4[i];
         if (wg_ok)
             for (int j = lg; j < k; j += LPR) pick[j] = (unsigned short)((S.so_rec[q0 + j].y & 0xFFFF) * (nc + 1));
     } else if (k > 0) {
-        const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
         int4 *lds4 = reinterpret_cast<int4 *>(lds_blk);
-        const int n4 = (nc * (nc + 1) * (int)sizeof(CT) + 15) >> 4;
-        int4 rec = make_int4(0, 0, 0, 0);
-        int slot = -1;
-        const bool mine = (int)threadIdx.x < min(k, DN_ORDERS);
-        if (mine) { rec = S.so_rec[q0 + threadIdx.x]; if (PULL) slot = S.so_slot[q0 + threadIdx.x]; }
-        if (!(DN_ABL & 1024)) for (int i = threadIdx.x; i < n4; i += NTHR) lds4[i] = blk4[i];
-        if (mine) { lds_rec[threadIdx.x] = rec; if (PULL) lds_slot[threadIdx.x] = slot; }
+        if (!(DN_ABL & 1024)) {
+            if ((int)threadIdx.x < n4) lds4[threadIdx.x] = sblk;
+            for (int i = threadIdx.x + NTHR; i < n4; i += NTHR) lds4[i] = blk4[i];
+        }
+        if (mine) { lds_rec[threadIdx.x] = srec; if (PULL) lds_slot[threadIdx.x] = sslot; }
     }
-    if (PULL && DM != 2 && wg_ok)
-        for (int i = threadIdx.x; i < n; i += NTHR) lds_drec[i] = S.d_rec[clo + i];
+    if (dmine) lds_drec[threadIdx.x] = sdrec;
     PROF_STAMP(0);          // scalar loads, header words, candidate entries, staging loads: all arrived
     __syncthreads();
     PROF_STAMP_NW(1);       // barrier
