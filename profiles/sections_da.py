@@ -24,6 +24,10 @@ print("per replica-tick: %.1f dry orders scanned in %.1f scans (%.0f cycles each
     b[2] / RT, b[11] / RT, b[10] / max(1, b[11]), b[4] / RT, b[6] / RT, b[3] / RT))
 print("per wavefront and tick (cycles): scanning %.0f, chains %.0f, claim %.0f, proposals %.0f, waiting for work / the others %.0f" % (
     b[10] / RT / 4, b[9] / RT / 4, b[12] / RT / 4, b[13] / RT / 4, b[8] / RT / 4))
+if b[22]:      # row-mapped bucket scans (da_scan_rows)
+    sr = [b[16 + i] / max(1, b[11]) for i in range(5)]
+    print("one row-mapped scan (4 buckets per wavefront): visit rows + bounds %.0f, candidate masks %.0f, item tables %.0f, entry batches %.0f, the K best %.0f cycles; %.1f table rounds, %.1f batches of 64 entries per row" % (
+        sr[0], sr[1], sr[2], sr[3], sr[4], b[21] / max(1, b[11]), b[22] / max(1, b[11])))
 sc = [b[16 + i] / max(1, b[11]) for i in range(5)]
 print("one scan: visit row + bounds %.0f, alive counts %.0f, first pass %.0f, second pass %.0f, the K best %.0f cycles; %.2f eight-slot groups" % (
     sc[0], sc[1], sc[2], sc[3], sc[4], b[21] / max(1, b[11])))
