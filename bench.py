@@ -441,7 +441,10 @@ def main():
         fixed_back[:, 0, 0] = (ar + 97) % env.C
         fixed_back[:, 0, 2] = some_node_of[(ar % env.C).long()]
         actions_static = torch.zeros((R, K, 3), dtype=torch.int32, device="cuda")
-        pol_graph, graph_error = None, None
+        # the day-graph form (vds_run_hooked) applies ONE tensor every slot: both moves of the pair in it (steady state)
+        fixed_both = fixed_actions.clone()
+        fixed_both[:, 1, :] = fixed_back[:, 0, :]
+        pol_graph, pol_graph_keep, graph_error = None, None, None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(stream)
@@ -453,17 +456,29 @@ def main():
             pol_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(pol_graph):
                 actions_static.copy_(policy(obs_static))
+            # the same capture with the graph kept (raw handle): embedded into the hooked day graph as a child graph
+            pol_graph_keep = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(pol_graph_keep):
+                actions_static.copy_(policy(obs_static))
         except Exception as e:       # (a reported extra)
-            pol_graph = None
             graph_error = repr(e)
 
         def hooked_day(kind):
             env.reset_again()
+            if kind == "fixed_day_graph":         # one graph launch: T x (tick -> k_pack_obs -> k_dispatch_dense), replica groups as branches
+                env.run_hooked(T, actions=fixed_both, inflight=False)
+                return
+            if kind == "policy_day_graph":        # ... with the torch policy as a child graph between observations and dispatch
+                env.run_hooked(T, actions=actions_static, policy_graph=pol_graph_keep, inflight=False)
+                return
             for ts in range(T):
                 env.step()
                 if kind == "fixed":
                     env.obs_torch(inflight=False)
                     env.apply_dispatch_torch(fixed_actions if ts % 2 == 0 else fixed_back)
+                elif kind == "fixed_both":
+                    env.obs_torch(inflight=False)
+                    env.apply_dispatch_torch(fixed_both)
                 elif kind == "graph":
                     env.obs_torch(inflight=False)           # k_pack_obs into the static block (the policy reads idle, supply, demand)
                     pol_graph.replay()
@@ -484,7 +499,9 @@ def main():
                     hook_errors.append(str(e))
 
         res = {}
-        kinds = [("step_advance_only", "none"), ("engine_hook_fixed_actions", "fixed")] + ([("torch_policy_graph", "graph")] if pol_graph is not None else []) + [("torch_policy_eager", "eager")]
+        kinds = ([("step_advance_only", "none"), ("engine_hook_fixed_actions", "fixed"), ("engine_hook_fixed_actions_both_moves", "fixed_both"), ("engine_hook_day_graph", "fixed_day_graph")]
+                 + ([("torch_policy_graph", "graph")] if pol_graph is not None else []) + ([("torch_policy_day_graph", "policy_day_graph")] if pol_graph_keep is not None else [])
+                 + [("torch_policy_eager", "eager")])
         for label, kind in kinds:
             hooked_day(kind); torch.cuda.synchronize()            # warm
             sync_skipping_refused_moves()
@@ -499,14 +516,19 @@ def main():
             res[label] = {"slot_us": dt / (nd * T) * 1e6, "host_issue_us_per_slot": t_issue / (nd * T) * 1e6, "value": T * R * nd / dt,
                           "dispatches_last_day": int(env.work().get("dispatches", 0))}
         hookless_us = elapsed / a.steps / T * 1e6
-        best = "torch_policy_graph" if "torch_policy_graph" in res else "torch_policy_eager"
+        best = "torch_policy_day_graph" if "torch_policy_day_graph" in res else ("torch_policy_graph" if "torch_policy_graph" in res else "torch_policy_eager")
         hooked = {"unit": "env-steps*replicas/s", "value": res[best]["value"], "K": K, "days": 2, "policy": best,
                   "slot_us": res[best]["slot_us"], "hookless_run_tick_us": hookless_us,
-                  "engine_hook_vs_hookless_tick": res["engine_hook_fixed_actions"]["slot_us"] / hookless_us,
+                  # the boundary without a policy: the hooked day as ONE graph (vds_run_hooked: tick -> observations -> dispatch per slot,
+                  # replica groups as parallel branches) against the hook-less day graph of the headline
+                  "engine_hook_vs_hookless_tick": res["engine_hook_day_graph"]["slot_us"] / hookless_us,
+                  "engine_hook_call_by_call_vs_hookless_tick": res["engine_hook_fixed_actions"]["slot_us"] / hookless_us,
                   "policy_slot_vs_hookless_tick": res[best]["slot_us"] / hookless_us,
+                  "host_issue_us_per_slot": res[best]["host_issue_us_per_slot"],
                   "variants": res,
-                  "note": "per slot: vds_step (one tick launch over all replicas) -> k_pack_obs -> policy -> k_dispatch_dense -> vds_advance; wall "
-                          "time of 2 days incl. the per-day reset; engine_hook_fixed_actions = the boundary without a policy"}
+                  "note": "per slot: tick -> k_pack_obs -> policy -> k_dispatch_dense -> advance; wall time of 2 days incl. the per-day reset.  *_day_graph: "
+                          "vds_run_hooked, one graph launch per day (the torch policy embedded as a child graph); the others: one call per step "
+                          "(vds_step / vds_obs_device_planes / policy / vds_apply_dispatch_device / vds_advance); engine_hook_* = the boundary without a policy"}
         if graph_error:
             hooked["policy_graph_error"] = graph_error
         if hook_errors:

@@ -209,6 +209,18 @@ int vds_advance(vds_handle *h);
  * are empty).  Asynchronous. */
 int vds_run(vds_handle *h, int32_t n_ticks);
 
+/* SimCity's loop WITH the dispatch hook on the device for n_ticks slots (:1048-1091): per slot vds_step (Update -> Match ->
+ * SupplyExpect, :1053-1076) -> the observation planes named by `planes` into the block of vds_obs_device (0: none) -> the caller's
+ * POLICY, a captured graph (hipGraph_t) that reads that block / the counters and writes the action tensor (NULL: the tensor is
+ * applied as it stands) -> vds_apply_dispatch_device(K, dev_actions), the DispatchFunction body (:1083; K = 0: none) ->
+ * vds_advance (:1090-1091).  The whole run is ONE executable graph (built on first use, replayed while nothing it was built for
+ * has changed; the policy is embedded as a child graph - it is copied: re-capture it and pass the new handle to change it): one
+ * submission per call instead of three or four launches per slot.  The replicas run as the groups of vds_run in parallel branches
+ * (the observation and dispatch kernels of one group under the tick of another); the policy node joins them once per slot.
+ * Results are those of the stepwise loop.  Asynchronous on the handle's stream, which must be the stream the policy was
+ * captured on, or ordered with it.  Errors of skipped actions surface at the next vds_sync as for vds_apply_dispatch_device. */
+int vds_run_hooked(vds_handle *h, int32_t n_ticks, int32_t planes, int32_t K, const void *dev_actions, void *policy_graph);
+
 /* Scheduling of vds_run (no reference counterpart, results do not depend on it): the replicas run as `groups` independent
  * groups (replicas never interact inside :1048-1091 without hooks) - in neighbour-search mode (hybrid tick) the stamp-mode
  * k_tick_rows of one group under the k_dfs_walk of the others, without neighbour search two chains of half-size k_tick_dense

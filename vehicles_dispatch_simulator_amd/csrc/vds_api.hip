@@ -45,6 +45,8 @@ void set_ablate_dense(int, hipStream_t);
 void read_prof_dense(unsigned long long *, hipStream_t);
 void read_span_dense(unsigned long long *, int, hipStream_t);
 void emit_tick_dense(const Emit &, const Static &, const State &, int, int, int);
+void emit_pack_obs(const Emit &, const Static &, const State &, int, int, int, int *, int, int);
+void emit_dispatch_dense(const Emit &, const Static &, const State &, int, int, const int *, int, int, int);
 }  // namespace vds
 
 using namespace vds;
@@ -140,6 +142,7 @@ struct vds_handle {
     hipEvent_t pin_ev = nullptr;             // recorded behind the copy into pin_slow
     long long pin_bucket_ticks = 0;          // bucket-ticks of that episode (0: nothing copied yet)
     int dense_adapt = 0;                     // 0 undecided (8 lanes), 1 switched to 16 lanes / 256-entry tables; -1 fixed by the caller / environment
+    unsigned tables_gen = 0;                 // bumped with run_stale: what a graph was built for (the hooked day graph keeps its own copy)
     bool run_stale = false;                  // tables / capacities changed since the graph was built: same shape -> hipGraphExecUpdate
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
@@ -148,6 +151,15 @@ struct vds_handle {
     // vds_run of the hybrid neighbour-search tick: replica GROUPS on streams (run_grouped)
     int run_groups = -1;                     // -1: ask VDS_RUN_GROUPS (default: by replica count, run_group_count)
     int run_stagger = -1;                    // -1: ask VDS_RUN_STAGGER (default 1)
+    // vds_run_hooked: the hooked day (tick -> observations -> policy -> dispatch per slot) as one executable graph, and what it was built for
+    hipGraphExec_t hook_exec = nullptr;
+    hipGraphExec_t hook_policy_exec = nullptr;   // (eager fallback: the caller's policy graph instantiated by itself)
+    void *hook_policy_inst = nullptr;
+    int hook_t0 = -1, hook_n = 0, hook_G = 1, hook_planes = 0, hook_K = 0;
+    unsigned hook_gen = 0;
+    const void *hook_actions = nullptr;
+    void *hook_policy = nullptr;
+    hipStream_t hook_stream = nullptr;
 };
 
 static int fail(vds_handle *h, int code, const char *fmt, ...) {
@@ -312,7 +324,19 @@ extern "C" int vds_debug_graph_pool_size() {      // executable graphs parked ri
     return (int)g_graph_pool.size();
 }
 
+static void drop_hook_graph(vds_handle *h) {
+    if (h->hook_exec) {
+        (void)hipStreamSynchronize(h->hook_stream);
+        if (h->hook_G > 1) graph_pool_put(h->cfg.device, 0ull, h->hook_exec);     // (parallel branches: parked, never destroyed - see above)
+        else (void)hipGraphExecDestroy(h->hook_exec);
+        h->hook_exec = nullptr;
+    }
+    if (h->hook_policy_exec) { (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->hook_policy_exec); h->hook_policy_exec = nullptr; h->hook_policy_inst = nullptr; }
+    h->hook_t0 = -1; h->hook_n = 0;
+}
+
 static void drop_run_graph(vds_handle *h) {
+    drop_hook_graph(h);
     if (h->run_exec) {
         (void)hipStreamSynchronize(h->run_stream);      // (it may still be running; nullptr = the legacy default stream: valid)
         if (h->run_G > 1) graph_pool_put(h->cfg.device, h->run_shape, h->run_exec);
@@ -850,7 +874,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (void *p : h->order_allocs) dev_free(p);
         h->order_allocs.clear();
-        h->run_stale = true;
+        { h->run_stale = true; h->tables_gen++; }
         h->have_orders = false; h->have_reset = false;
         h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
         h->err.clear();
@@ -1286,7 +1310,7 @@ static void adapt_dense(vds_handle *h) {
             const char *t256 = getenv("VDS_DENSE_TAB256");
             S.dense_lpr = 16; S.dense_tab = (t256 && *t256 == '0') ? 128 : 256;
             h->dense_adapt = 1;
-            h->run_stale = true;               // the day graph holds the other kernel
+            { h->run_stale = true; h->tables_gen++; }               // the day graph holds the other kernel
             return;
         }
     }
@@ -1321,7 +1345,7 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     if (cap < 1) return fail(h, VDS_EINVAL, "vds_set_idle_cap: bad capacity %d", cap);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->run_stale = true;
+    { h->run_stale = true; h->tables_gen++; }
     cap = std::min(round_up(cap, 64), round_up(std::max(h->S.V, 1), 64));
     if (cap > (1 << 24)) return fail(h, VDS_EINVAL, "vds_set_idle_cap: %d > 2^24 unsupported", cap);
     if (cap == h->S.idle_cap) return VDS_OK;
@@ -1716,10 +1740,157 @@ int vds_get_run_groups(vds_handle *h) {
 int vds_set_run_groups(vds_handle *h, int32_t groups, int32_t stagger) {
     if (!h) return VDS_EINVAL;
     if (groups > RUN_GROUPS_MAX || stagger > 2) return fail(h, VDS_EINVAL, "vds_set_run_groups: groups <= %d, stagger 0 / 1 / 2 (or negative: default)", RUN_GROUPS_MAX);
-    h->run_stale = true;
+    { h->run_stale = true; h->tables_gen++; }
     h->run_groups = groups > 0 ? groups : -1;
     h->run_stagger = stagger >= 0 ? stagger : -1;
     return VDS_OK;
+}
+
+// ---- vds_run_hooked: SimCity's loop WITH the dispatch hook on the device (:1048-1091).  Per slot: the tick (Update -> Match ->
+// SupplyExpect, :1053-1076), the observation planes into the library's block (vds_obs_device_planes), the caller's policy - a captured
+// graph that reads the block and writes the action tensor, embedded as a child graph; or none -, the actions applied
+// (vds_apply_dispatch_device: the DispatchFunction body, :1083), the next slot (:1090-1091).  The whole run is ONE executable graph:
+// one submission per call instead of three or four launches per slot, and - like vds_run - the replicas as groups in parallel
+// branches, so that the small latency-bound kernels of one group (observations, dispatch) run under the tick of the other.  The
+// policy node, which sees all replicas, joins the branches once per slot.
+static int run_hooked_eager(vds_handle *h, int32_t n_ticks, int32_t planes, int32_t K, const void *dev_actions, void *policy_graph) {
+    if (policy_graph && h->hook_policy_inst != policy_graph) {
+        if (h->hook_policy_exec) { (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->hook_policy_exec); h->hook_policy_exec = nullptr; }
+        HIPCHK(h, hipGraphInstantiate(&h->hook_policy_exec, (hipGraph_t)policy_graph, nullptr, nullptr, 0));
+        h->hook_policy_inst = policy_graph;
+    }
+    for (int i = 0; i < n_ticks; ++i) {
+        int rc = vds_step(h);
+        if (rc) return rc;
+        if (planes && (rc = vds_obs_device_planes(h, planes, nullptr))) return rc;
+        if (policy_graph) HIPCHK(h, hipGraphLaunch(h->hook_policy_exec, h->stream));
+        if (K > 0 && dev_actions && (rc = vds_apply_dispatch_device(h, K, dev_actions))) return rc;
+        if ((rc = vds_advance(h))) return rc;
+    }
+    return VDS_OK;
+}
+
+static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32_t K, const void *dev_actions, void *policy_graph) {
+    if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_run_hooked: call vds_reset first");
+    if (n_ticks < 0 || planes < 0 || planes > 31 || K < 0 || K > 64 || (K > 0 && !dev_actions))
+        return fail(h, VDS_EINVAL, "vds_run_hooked: planes is a mask of the five planes (0 .. 31), K in [0, 64] with a non-null action tensor");
+    if (h->last_stepped == h->t) return fail(h, VDS_EINVAL, "vds_run_hooked: tick %d already stepped; call vds_advance", h->t);
+    if (h->t + n_ticks > h->S.T) return fail(h, VDS_EINVAL, "vds_run_hooked: %d slots from slot %d on run past the end of the day (%d slots, :1048)", n_ticks, h->t, h->S.T);
+    if (n_ticks == 0) return VDS_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->use_graph < 0) { const char *v = getenv("VDS_RUN_GRAPH"); h->use_graph = (v && *v == '0') ? 0 : 1; }
+    const bool groupable = run_groups_hybrid(h) || run_groups_plain(h);
+    if (!h->use_graph || h->profiling || !groupable) return run_hooked_eager(h, n_ticks, planes, K, dev_actions, policy_graph);
+    { const int rcs = dev_copy_sync(h); if (rcs) return rcs; }
+    // replica groups as parallel branches only when the caller asked for them (vds_set_run_groups): measured at configs[1], the
+    // hooked day is FASTER as one chain (69.8 / 72.6 / 76.1 us per slot with 1 / 2 / 3 groups, profiles/r05/hooked_groups.txt - the
+    // observation and dispatch kernels are chains of dependent loads that gain nothing from running beside a tick, and every group
+    // adds two kernel boundaries per slot)
+    (void)run_group_count(h);
+    const int G = h->run_groups > 0 ? std::min(run_group_count(h), RUN_GROUPS_MAX) : 1;
+    const bool same = h->hook_exec && h->hook_gen == h->tables_gen && h->hook_t0 == h->t && h->hook_n == n_ticks && h->hook_G == G && h->hook_planes == planes && h->hook_K == K &&
+                      h->hook_actions == dev_actions && h->hook_policy == policy_graph && h->hook_stream == h->stream;
+    if (!same) {
+        hipGraph_t g = nullptr;
+        HIPCHK(h, hipGraphCreate(&g, 0));
+        const int chunks = (h->S.R + 15) / 16;
+        std::vector<hipGraphNode_t> last(G, nullptr), tail(G, nullptr);
+        hipError_t err = hipSuccess;
+        for (int i = 0; i < n_ticks && err == hipSuccess; ++i) {
+            const int t = h->t + i;
+            for (int gi = 0; gi < G && err == hipSuccess; ++gi) {
+                const int c0 = (int)((long long)chunks * gi / G), c1 = (int)((long long)chunks * (gi + 1) / G);
+                const int r_lo = c0 * 16, r_n = (c1 * 16 < h->S.R ? c1 * 16 : h->S.R) - r_lo;
+                tail[gi] = last[gi];
+                if (r_n <= 0) continue;
+                hipGraphNode_t n1 = nullptr, n2 = nullptr, n3 = nullptr;
+                Emit e;
+                e.graph = g; e.deps = last[gi] ? &last[gi] : nullptr; e.ndeps = last[gi] ? 1 : 0; e.node = &n1; e.err = &err;
+                if (!h->dfs_mode) {
+                    if (h->S.dense) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
+                    else emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+                } else {
+                    emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+                    if (err != hipSuccess) break;
+                    e.deps = &n1; e.ndeps = 1; e.node = &n2;
+                    emit_hybrid_walk(e, h->S, h->D, t, r_lo, r_n);
+                    n1 = n2;
+                }
+                if (err != hipSuccess) break;
+                tail[gi] = n1;
+                if (planes) {
+                    e.deps = &n1; e.ndeps = 1; e.node = &n3;
+                    emit_pack_obs(e, h->S, h->D, t, 1, planes, h->d_obs, r_lo, r_n);
+                    if (err != hipSuccess) break;
+                    tail[gi] = n3;
+                }
+            }
+            if (err != hipSuccess) break;
+            hipGraphNode_t pol = nullptr;
+            if (policy_graph) {
+                std::vector<hipGraphNode_t> deps;
+                for (int gi = 0; gi < G; ++gi) if (tail[gi]) deps.push_back(tail[gi]);
+                // (the child graph between two EMPTY nodes: with several parents / several children attached to the child-graph node
+                // itself the runtime of this image started it after the first parent - actions computed from observations of the slot before)
+                hipGraphNode_t join = nullptr, fork = nullptr;
+                err = hipGraphAddEmptyNode(&join, g, deps.data(), deps.size());
+                if (err != hipSuccess) break;
+                err = hipGraphAddChildGraphNode(&pol, g, &join, 1, (hipGraph_t)policy_graph);
+                if (err != hipSuccess) break;
+                err = hipGraphAddEmptyNode(&fork, g, &pol, 1);
+                if (err != hipSuccess) break;
+                pol = fork;
+            }
+            for (int gi = 0; gi < G && err == hipSuccess; ++gi) {
+                const int c0 = (int)((long long)chunks * gi / G), c1 = (int)((long long)chunks * (gi + 1) / G);
+                const int r_lo = c0 * 16, r_n = (c1 * 16 < h->S.R ? c1 * 16 : h->S.R) - r_lo;
+                if (r_n <= 0) continue;
+                hipGraphNode_t dep = pol ? pol : tail[gi];
+                if (K > 0) {
+                    hipGraphNode_t nd = nullptr;
+                    Emit e;
+                    e.graph = g; e.deps = dep ? &dep : nullptr; e.ndeps = dep ? 1 : 0; e.node = &nd; e.err = &err;
+                    emit_dispatch_dense(e, h->S, h->D, t, K, (const int *)dev_actions, 0, r_lo, r_n);
+                    if (err != hipSuccess) break;
+                    dep = nd;
+                }
+                last[gi] = dep;
+            }
+        }
+        if (err != hipSuccess) {
+            (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            return fail(h, VDS_EHIP, "vds_run_hooked: building the day graph failed: %s", hipGetErrorString(err));
+        }
+        bool updated = false;
+        if (h->hook_exec && h->hook_n == n_ticks && h->hook_G == G && (h->hook_planes != 0) == (planes != 0) && (h->hook_K > 0) == (K > 0) && (h->hook_policy != nullptr) == (policy_graph != nullptr)) {
+            (void)hipStreamSynchronize(h->hook_stream);
+            hipGraphNode_t bad = nullptr;
+            hipGraphExecUpdateResult res;
+            updated = hipGraphExecUpdate(h->hook_exec, g, &bad, &res) == hipSuccess;
+            if (!updated) (void)hipGetLastError();
+        }
+        if (!updated) {
+            drop_hook_graph(h);
+            const hipError_t ei = hipGraphInstantiate(&h->hook_exec, g, nullptr, nullptr, 0);
+            if (ei != hipSuccess) {
+                (void)hipGraphDestroy(g); h->hook_exec = nullptr; (void)hipGetLastError();
+                return run_hooked_eager(h, n_ticks, planes, K, dev_actions, policy_graph);
+            }
+        }
+        (void)hipGraphDestroy(g);
+        h->hook_t0 = h->t; h->hook_n = n_ticks; h->hook_G = G; h->hook_planes = planes; h->hook_K = K; h->hook_actions = dev_actions;
+        h->hook_policy = policy_graph; h->hook_stream = h->stream; h->hook_gen = h->tables_gen;
+    }
+    HIPCHK(h, hipGraphLaunch(h->hook_exec, h->stream));
+    h->t += n_ticks;
+    h->last_stepped = h->t - 1;
+    if (K > 0) { h->dispatch_seq += K * n_ticks; h->seq_tick = -1; }
+    return VDS_OK;
+}
+
+int vds_run_hooked(vds_handle *h, int32_t n_ticks, int32_t planes, int32_t K, const void *dev_actions, void *policy_graph) {
+    return guarded(h, "vds_run_hooked", [&] { return run_hooked_impl(h, n_ticks, planes, K, dev_actions, policy_graph); });
 }
 
 int vds_sync(vds_handle *h) {

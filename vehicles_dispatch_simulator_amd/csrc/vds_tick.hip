@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
     // that both the reads (16 consecutive replicas) and the writes (16 consecutive clusters) are 64-byte runs
     __shared__ int tile[5][16][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+    const int r0 = S.r_lo + blockIdx.x * 16, c0 = blockIdx.y * 16;      // (S.r_lo: the launch covers a replica group of vds_run_hooked)
     const size_t RC = (size_t)S.R * S.C;
     const size_t RCX = (size_t)S.R_ext * S.C;      // the block is laid out by the caller's replica index
     {
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                 for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
             // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
             int supply = (int)((unsigned)D.ring_cnt[(size_t)((tr + 1) & (S.H - 1)) * RC + b] >> 16);
-            if (S.pull && stepped) {
+            if (S.pull && stepped && (planes & (4 | 16))) {       // (neither supply nor inflight wanted: the arrival slots are not read)
                 // static arrival slots (vds_device.h): the orders to this cluster that are on their way sit in D.arr, not in the ring -
                 // processed (insert tick <= tr), matched, arrival slot a0 + delta behind tr; due by the next slot: a0 + delta == tr + 1
                 const int4 d2 = S.n_days <= 1 ? make_int4(0, 0, 0x7FFFFFFF, 0) : S.replica_desc2[r];
@@ -1236,7 +1236,7 @@ __global__ void k_total_counters(int R, const long long *per, long long *tot) {
 // action index) and the idle list is compacted once, order preserved.  Positions refer to the lists as they stand
 // before the call.  Same effects as k_dispatch.
 __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t, int K, const int *actions, int seq_base) {
-    const int r = blockIdx.x;
+    const int r = S.r_lo + blockIdx.x;
     const int lane = lane_id();
     const DayView dvw = day_view(S, r);
     const int now = dvw.now0 + t * S.tick_minutes;
@@ -1429,12 +1429,39 @@ void launch_dispatch(const Static &S, const State &D, int t, int ngroups, const 
     hipLaunchKernelGGL(k_dispatch, dim3(ngroups), dim3(64), 0, st, S, D, t, ngroups, grp_off, a_replica, a_cluster, a_pos, a_target, a_seq, a_arrive, a_counted);
 }
 
+// the hook-side kernels for the replicas [r_lo, r_lo + r_n) (r_lo a multiple of 16; r_n = 0: all), on a stream or as kernel nodes of
+// the hooked day graph (vds_run_hooked)
+void emit_dispatch_dense(const Emit &e, const Static &S0, const State &D, int t, int K, const int *actions, int seq_base, int r_lo, int r_n) {
+    Static S = S0;
+    S.r_lo = r_lo;
+    const dim3 grid(r_n > 0 ? r_n : S.R - r_lo), block(64);
+    if (!e.graph) { hipLaunchKernelGGL(k_dispatch_dense, grid, block, 0, e.st, S, D, t, K, actions, seq_base); return; }
+    State Dv = D;
+    void *args[6] = {&S, &Dv, &t, &K, &actions, &seq_base};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void *>(k_dispatch_dense); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = args; p.extra = nullptr;
+    *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
+}
+void emit_pack_obs(const Emit &e, const Static &S0, const State &D, int t, int stepped, int planes, int *obs, int r_lo, int r_n) {
+    Static S = S0;
+    S.r_lo = r_lo;
+    const dim3 grid(((r_n > 0 ? r_n : S.R - r_lo) + 15) / 16, (S.C + 15) / 16), block(256);
+    if (!e.graph) { hipLaunchKernelGGL(k_pack_obs, grid, block, 0, e.st, S, D, t, stepped, planes, obs); return; }
+    State Dv = D;
+    void *args[6] = {&S, &Dv, &t, &stepped, &planes, &obs};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void *>(k_pack_obs); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = args; p.extra = nullptr;
+    *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
+}
+
 void launch_dispatch_dense(const Static &S, const State &D, int t, int K, const int *actions, int seq_base, hipStream_t st) {
-    hipLaunchKernelGGL(k_dispatch_dense, dim3(S.R), dim3(64), 0, st, S, D, t, K, actions, seq_base);
+    Emit e; e.st = st;
+    emit_dispatch_dense(e, S, D, t, K, actions, seq_base, 0, 0);
 }
 
 void launch_pack_obs(const Static &S, const State &D, int t, int stepped, int planes, int *obs, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_obs, dim3((S.R + 15) / 16, (S.C + 15) / 16), dim3(256), 0, st, S, D, t, stepped, planes, obs);
+    Emit e; e.st = st;
+    emit_pack_obs(e, S, D, t, stepped, planes, obs, 0, 0);
 }
 
 void launch_reduce_counters(const Static &S, const State &D, long long *per, long long *tot, hipStream_t st) {

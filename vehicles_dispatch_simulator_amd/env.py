@@ -217,6 +217,25 @@ class BatchedDispatchEnv:
     def run(self, n_ticks: int):
         self._chk(self._lib.vds_run(self._h, int(n_ticks)))
 
+    def run_hooked(self, n_ticks: int, actions=None, policy_graph=None, idle_pre=True, idle_now=True, supply=True, cl_orders=True, inflight=False):
+        """``n_ticks`` slots of ``SimCity`` WITH the dispatch hook on the device as one graph launch (``vds_run_hooked``): per slot
+        step -> the named observation planes into the block ``obs_torch`` returns -> ``policy_graph`` -> ``actions`` applied ->
+        advance.  ``actions``: the contiguous int32 CUDA tensor ``[R, K, 3]`` the policy writes (``None``: no dispatch).
+        ``policy_graph``: a ``torch.cuda.CUDAGraph`` captured with ``keep_graph=True`` (its ``raw_cuda_graph()`` is embedded), or a
+        raw ``hipGraph_t`` as an integer, or ``None`` (the tensor is applied as it stands)."""
+        planes = (1 if idle_pre else 0) | (2 if idle_now else 0) | (4 if supply else 0) | (8 if cl_orders else 0) | (16 if inflight else 0)
+        K, ptr = 0, None
+        if actions is not None:
+            if tuple(actions.shape[:1]) != (self.R,) or actions.dim() != 3 or actions.shape[2] != 3:
+                raise Exception("run_hooked: expected an int32 tensor [R, K, 3]")
+            if str(actions.dtype) != "torch.int32" or not actions.is_cuda or not actions.is_contiguous():
+                raise Exception("run_hooked: expected a contiguous int32 CUDA tensor")
+            K, ptr = int(actions.shape[1]), C.c_void_p(actions.data_ptr())
+        raw = None
+        if policy_graph is not None:
+            raw = policy_graph if isinstance(policy_graph, int) else int(policy_graph.raw_cuda_graph())
+        self._chk(self._lib.vds_run_hooked(self._h, int(n_ticks), planes, K, ptr, C.c_void_p(raw) if raw is not None else None))
+
     def set_run_groups(self, groups: int = 0, stagger: int = -1):
         """Scheduling of ``run`` (``vds_set_run_groups``): the replicas as ``groups`` independent chains of launches (parallel
         branches of the day graph); results do not depend on it.  ``groups <= 0`` / ``stagger < 0``: library default."""
@@ -249,7 +268,7 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_obs_device_planes(self._h, int(planes), C.byref(p)))
         return p.value
 
-    def obs_torch(self, inflight: bool = True):
+    def obs_torch(self, inflight: bool = True, idle_pre: bool = True, idle_now: bool = True, supply: bool = True, cl_orders: bool = True):
         """The packed observation block as a zero-copy ``torch`` int32 tensor ``[5, R, C]`` on the GPU
         (``idle_pre, idle_now, supply, cl_orders, inflight``): what a batched RL agent consumes without a
         host round trip.  The tensor aliases library memory and is overwritten by the next call.
@@ -261,7 +280,7 @@ class BatchedDispatchEnv:
             pass
 
         blk = _Block()
-        blk.__cuda_array_interface__ = {"shape": (5, self.R, self.C), "typestr": "<i4", "data": (self.obs_device_ptr(31 if inflight else 15), False),
+        blk.__cuda_array_interface__ = {"shape": (5, self.R, self.C), "typestr": "<i4", "data": (self.obs_device_ptr((1 if idle_pre else 0) | (2 if idle_now else 0) | (4 if supply else 0) | (8 if cl_orders else 0) | (16 if inflight else 0)), False),
                                         "version": 2, "strides": None}
         return torch.as_tensor(blk, device=torch.device("cuda", self.device))
 
