@@ -1258,69 +1258,77 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
         if (k < K) { cl = act[k * 3]; pos = act[k * 3 + 1]; tgt = act[k * 3 + 2]; }
         bool valid = cl >= 0;
         if (valid && (cl >= S.C || tgt < 0 || tgt >= S.N)) { atomicOr(&D.err[0], ERR_DISPATCH); valid = false; }
-        const int tc = valid ? S.node2cluster[tgt] : -1;
+        // ---- phase 1, every action on its own lane: the chain header -> entry -> cost -> post is walked ONCE for all of them
+        // (round 5; before: once per source cluster, one after the other - eight moves from eight clusters were eight chains)
+        int tc = -1, m = 0, coff = 0;
+        if (valid) {
+            tc = S.node2cluster[tgt];
+            m = D.hdr[((size_t)cl * S.R + r) * HDR_WORDS + HDR_IDLE];
+            coff = S.cl_off[cl];
+        }
         if (valid && tc < 0) { atomicOr(&D.err[0], ERR_DISPATCH); valid = false; }
+        // a position named twice: the first action (lowest slot) stands, the others are refused - nothing of theirs is posted, so
+        // the vehicle cannot end up in two arrival tables
+        bool dup = false;
+        {
+            const int kn = min(K - k0, WAVE);
+            const unsigned long long vmask = ballot(valid);
+            for (int l2 = 0; l2 < kn; ++l2) {
+                const int c2 = rdlane(cl, l2), p2 = rdlane(pos, l2);
+                dup = dup || (valid && l2 < lane && c2 == cl && p2 == pos && ((vmask >> l2) & 1ull));
+            }
+        }
+        if (dup) atomicOr(&D.err[0], ERR_DISPATCH);
+        bool ok = valid && !dup && pos >= 0 && pos < m;
+        if (valid && !dup && !ok) atomicOr(&D.err[0], ERR_DISPATCH);
+        int cst = 0;
+        if (ok) {
+            const uint2 e = idle_ref(S, D, cl, r).get(pos);
+            cst = S.cost[(size_t)tgt * S.N + coff + e.y];     // RoadCost(LocationNode, target)
+            post_arrival<false, true>(S, D, tc, r, t, now, (int)e.x, seq_base + k, now + cst, 1, S.node_local[tgt]);
+        }
+        // ---- phase 2, source cluster by source cluster: the list is compacted once (order preserved), header and counters
         unsigned long long todo = ballot(valid);
         unsigned long long same = todo;
         for (int bit = 0; (1 << bit) < S.C; ++bit) {
             const unsigned long long bb = ballot((cl >> bit) & 1);
             same &= ((cl >> bit) & 1) ? bb : ~bb;
         }
+        wave_fence();
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const unsigned long long grp = ((unsigned long long)__builtin_amdgcn_readlane((int)(same & 0xFFFFFFFFu), leader)) |
                                            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(same >> 32), leader) << 32);
             const int c = rdlane(cl, leader);
+            const int mc = rdlane(m, leader);
             const size_t b = (size_t)c * S.R + r;
-            int *hdr = D.hdr + b * HDR_WORDS;
             const IdleRef idle = idle_ref(S, D, c, r);
-            const int m = hdr[HDR_IDLE];
-            bool mine = (grp >> lane) & 1ull;
-            {   // a position named twice: the first action (lowest slot) stands, the others are refused - nothing of
-                // theirs is posted, so the vehicle cannot end up in two arrival tables
-                bool dup = false;
-                for (unsigned long long rest = grp; rest; rest &= rest - 1) {
-                    const int l2 = __ffsll((long long)rest) - 1;
-                    const int p2 = rdlane(pos, l2);
-                    dup = dup || (mine && l2 < lane && p2 == pos);
-                }
-                if (dup) { atomicOr(&D.err[0], ERR_DISPATCH); mine = false; }
-            }
-            bool ok = false;
-            int cst = 0;
-            if (mine) {
-                if (pos >= 0 && pos < m) {
-                    const uint2 e = idle.get(pos);
-                    cst = S.cost[(size_t)tgt * S.N + S.cl_off[c] + e.y];     // RoadCost(LocationNode, target)
-                    post_arrival<false, true>(S, D, tc, r, t, now, (int)e.x, seq_base + k, now + cst, 1, S.node_local[tgt]);
-                    ok = true;
-                } else {
-                    atomicOr(&D.err[0], ERR_DISPATCH);
-                }
-            }
-            int csum = cst;
+            const bool mine = (grp >> lane) & 1ull;
+            int csum = (mine && ok) ? cst : 0;
             for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o, WAVE);
-            const int ndone = popc64(ballot(ok));
-            wave_fence();
-            int newm = 0;
-            for (int base = 0; base < m; base += WAVE) {
-                const int i = base + lane;
-                bool keep = i < m;
-                for (unsigned long long rest = grp; rest; rest &= rest - 1)
-                    keep = keep && (rdlane(pos, __ffsll((long long)rest) - 1) != i);
-                const uint2 e = (i < m) ? idle.get(i) : make_uint2(0u, 0u);
-                const unsigned long long kb = ballot(keep);
-                wave_fence();
-                if (keep) idle.set(newm + popc64(kb & lanemask_lt()), e);
-                newm += popc64(kb);
-                wave_fence();
-            }
-            if (m - newm != ndone && lane == 0) atomicOr(&D.err[0], ERR_DISPATCH);   // duplicate positions
-            if (lane == 0) {
-                hdr[HDR_IDLE] = newm;
+            const unsigned long long okg = ballot(mine && ok);
+            const int ndone = popc64(okg);
+            if (ndone > 0) {
                 long long *cnt = D.cnt + b * CNT_WORDS;
-                cnt[CNT_DISPATCH] += ndone;
-                cnt[CNT_DISPATCH_COST] += csum;
+                long long cv = 0;
+                if (lane == CNT_DISPATCH || lane == CNT_DISPATCH_COST) cv = cnt[lane];      // (in flight with the list)
+                int newm = 0;
+                for (int base = 0; base < mc; base += WAVE) {
+                    const int i = base + lane;
+                    bool keep = i < mc;
+                    for (unsigned long long rest = okg; rest; rest &= rest - 1)
+                        keep = keep && (rdlane(pos, __ffsll((long long)rest) - 1) != i);
+                    const uint2 e = (i < mc) ? idle.get(i) : make_uint2(0u, 0u);
+                    const unsigned long long kb = ballot(keep);
+                    wave_fence();
+                    if (keep) idle.set(newm + popc64(kb & lanemask_lt()), e);
+                    newm += popc64(kb);
+                    wave_fence();
+                }
+                if (mc - newm != ndone && lane == 0) atomicOr(&D.err[0], ERR_DISPATCH);
+                if (lane == 0) D.hdr[b * HDR_WORDS + HDR_IDLE] = newm;
+                if (lane == CNT_DISPATCH) cnt[lane] = cv + ndone;
+                if (lane == CNT_DISPATCH_COST) cnt[lane] = cv + csum;
             }
             wave_fence();
             todo &= ~grp;
