@@ -558,6 +558,41 @@ def main():
         finally:
             env.reset(init)          # whatever happened above: the --check pass and the line below describe `init`
 
+    # ---- episode turnover (rank 0, N = 1): what an RL loop pays to change the order day between episodes (the reference: Reload,
+    #      simulator.py:130-212).  (a) another replica -> day map over resident days (vds_set_replica_days: nothing rebuilt),
+    #      (b) a new day on a loaded handle (vds_load_orders: host tables by counting sorts, the neighbour search's visit rows built
+    #      on the device), (c) 16 new days (vds_load_order_days: the days built by worker threads)
+    episode_turnover = None
+    if rank == 0 and world == 1 and a.hooked and a.workload in ("cfg2", "cfg4"):
+        try:
+            def wall(f, n):
+                f(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    f()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n * 1e3
+            days16 = workloads.distinct_days(w, 16)
+            env3 = w.make_env(R, device=local_rank, stream=stream.cuda_stream, load=False)
+            maps = [np.random.default_rng(s).integers(0, 16, size=R).astype(np.int32) for s in range(4)]
+            t1 = time.perf_counter(); env3.load_order_days(days16, (np.arange(R) % 16).astype(np.int32)); first16 = (time.perf_counter() - t1) * 1e3
+            env3.reset(init)
+            it = iter(range(10 ** 9))
+            episode_turnover = {"unit": "ms per call, %d replicas" % R,
+                                "load_order_days_16_first": first16,
+                                "load_order_days_16_again": wall(lambda: env3.load_order_days(days16, (np.arange(R) % 16).astype(np.int32)), 3),
+                                "set_replica_days_blocks_of_64": wall(lambda: env3.set_replica_days((np.arange(R) // 64 + next(it)) % 16), 10),
+                                "set_replica_days_random_map": wall(lambda: env3.set_replica_days(maps[next(it) % 4]), 10)}
+            env3.set_replica_days(maps[0]); env3.reset(init)
+            episode_turnover["day_after_random_map_ms"] = wall(lambda: (env3.reset_again(), env3.run(env3.T)), 3)
+            episode_turnover["kernel_after_random_map"] = env3.main_kernel()
+            env3.close()
+            episode_turnover["load_orders_on_a_loaded_handle"] = wall(lambda: env.load_orders(w.release_min, w.pickup, w.delivery), 5)
+        except Exception as e:       # (a reported extra)
+            episode_turnover = {"error": repr(e)}
+        finally:
+            env.reset(init)
+
     check = None
     if a.check and rank == 0:
         from oracle.oracle import Oracle
@@ -609,6 +644,8 @@ def main():
             out["hooked_slot"] = hooked
         if episode_reset is not None:
             out["episode_reset"] = episode_reset
+        if episode_turnover is not None:
+            out["episode_turnover"] = episode_turnover
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))

@@ -133,6 +133,14 @@ int vds_load_orders(vds_handle *h, const int32_t *release_min, const int32_t *pi
 int vds_load_order_days(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min,
                         const int32_t *pickup, const int32_t *delivery, const int32_t *replica_day);
 
+/* Another replica -> day map over the order days that are ALREADY resident on the handle (the last vds_load_order_days): what an
+ * RL loop does between episodes when every city draws its next day from a pool (the reference: one Simulation.Reload per city,
+ * simulator.py:130-212 - here no file is read and no table rebuilt: five small arrays are re-derived and uploaded, well under a
+ * millisecond at 1024 replicas; the per-replica state tables are re-allocated only if the storage order of the replicas has to change
+ * between "as given" and "regrouped by day").  replica_day[replicas] as for vds_load_order_days.  The episode state is void
+ * afterwards: vds_reset / vds_reset_again / vds_reset_random must follow.  Synchronises the handle's stream. */
+int vds_set_replica_days(vds_handle *h, const int32_t *replica_day);
+
 /* The same in SURVEY.md 8(b)'s strided form: replica r's day of O orders starts at element r * replica_stride of the three
  * arrays; replica_stride == 0: one day shared by all replicas (== vds_load_orders), otherwise replica_stride >= O. */
 int vds_load_orders_strided(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery,

@@ -400,3 +400,46 @@ def test_loader_wrappers_check_array_lengths():
     with pytest.raises(Exception, match="need .* elements"):
         env.load_orders_strided(np.tile(rel, 2), np.tile(pk, 2), np.tile(dl, 2), O, O)      # 3 replicas need 3 * O
     env.close()
+
+
+@pytest.mark.parametrize("name,R", [("tiny_kmeans", 40), ("tiny_kmeans_dfs2", 40), ("tiny_grid", 7)])
+def test_replica_day_map_changes_every_episode_over_resident_days(name, R):
+    """vds_set_replica_days: the order days stay resident, only the replica -> day map changes between episodes (the reference: one
+    Reload per city, simulator.py:130-212).  Maps of every storage form follow each other on ONE handle - days in aligned blocks of 16
+    (one day per workgroup), interleaved (stored regrouped by day, with padding replicas), random with few replicas per day (one order
+    stream per row), everything on one day - and every replica is compared with the oracle of ITS day after every episode."""
+    g = load_golden(name)
+    V, N = int(g["V"]), int(g["N"])
+    days = synth_days(g, 4, seed=4100 + R)
+    rng = np.random.default_rng(31 + R)
+    valid = g["node2cluster"] >= 0
+    init = np.stack([synth.init_vehicle_nodes(random.Random(7000 + r), N, V, valid) for r in range(R)])
+    env = mk_env(g, R)
+    maps = [np.minimum(np.arange(R) // 16, 3), np.arange(R) % 4, rng.integers(0, 4, size=R), np.arange(R) % 2, np.zeros(R, dtype=np.int64), (np.arange(R) * 7 + 1) % 4,
+            np.minimum(np.arange(R) // 16, 3)[::-1].copy()]
+    env.load_order_days(days, maps[0].astype(np.int32))
+    expected = {}
+    for ep, rd in enumerate(maps):
+        if ep:
+            env.set_replica_days(rd.astype(np.int32))
+            with pytest.raises(Exception, match="reset"):
+                env.step()                                  # the episode state is void until a reset
+        env.reset(init)
+        assert env.T == max(mk_oracle(g, days[int(d)]).num_ticks for d in set(rd.tolist()))
+        env.run(env.T)
+        got, cn = env.orders(), env.counters()
+        for r in range(R):
+            d = int(rd[r])
+            key = (r, d)
+            if key not in expected:
+                o = mk_oracle(g, days[d]); o.reset(init[r]); o.run_day()
+                expected[key] = (o.orders(), o.counters())
+            exp, oc = expected[key]
+            n = exp["status"].size
+            for k in ("status", "vehicle", "wait"):
+                np.testing.assert_array_equal(got[k][r][:n], exp[k], err_msg="episode %d replica %d day %d %s" % (ep, r, d, k))
+            assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["evals"]), (ep, r)
+            assert env.replica_ticks(r)[0] == mk_oracle(g, days[d]).num_ticks if hasattr(env, "replica_ticks") else True
+    with pytest.raises(Exception, match="mapped to day"):
+        env.set_replica_days(np.full(R, 9, dtype=np.int32))
+    env.close()

@@ -78,6 +78,7 @@ SYMBOLS = {
     "vds_reduce_counters_into": (C.c_int, [_VP, _VP]),
     "vds_profile_enable": (C.c_int, [_VP, _I32]),
     "vds_run_hooked": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
+    "vds_set_replica_days": (C.c_int, [_VP, _VP]),
     "vds_profile_read": (C.c_int, [_VP, _VP, _I32, C.POINTER(_I32)]),
     "vds_read_orders": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
     "vds_read_lists": (C.c_int, [_VP, _I32] + [_VP] * 8),

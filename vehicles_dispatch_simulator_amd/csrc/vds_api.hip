@@ -5,6 +5,9 @@
 #include "vds_device.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +32,7 @@ void launch_tick_hybrid(const Static &, const State &, int, int, hipStream_t);
 void emit_tick_rows(const Emit &, const Static &, const State &, int, int, int, int);
 void emit_hybrid_rows(const Emit &, const Static &, const State &, int, int, int, int);
 void emit_hybrid_walk(const Emit &, const Static &, const State &, int, int, int);
+void launch_build_vis(const Static &, const int *, unsigned *, unsigned char *, long long, hipStream_t);
 size_t dfs_walk_lds(const Static &);
 int dfs_walk_pool(const Static &);
 void launch_dispatch(const Static &, const State &, int, int, const int *, const int *, const int *, const int *,
@@ -116,6 +120,11 @@ struct vds_handle {
     int alloc_R = 0;                     // replica count the state tables were allocated for
     std::vector<void *> dev_allocs;          // static tables, scratch
     std::vector<void *> order_allocs;        // tables of the loaded day (replaced by the next vds_load_orders)
+    std::vector<void *> map_allocs;          // the replica -> day map's device arrays (replaced by vds_set_replica_days / the next load)
+    std::vector<void *> result_allocs;       // per-replica result tables out / arr / slog (sized by S.R)
+    std::vector<DayDesc> ddesc_host;         // the loaded days (+ the empty day of padding replicas, last)
+    int alloc_O = 0;                         // what alloc_state was sized for (orders per day)
+    int Oqmax = 0;
     std::vector<void *> state_allocs;        // per-replica state (kept across days while the capacities still fit)
     std::vector<void *> idle_allocs;         // the idle table alone (regrown by vds_reset / vds_set_idle_cap)
     int idle_cap_grown = 0;                  // capacity chosen by a reset histogram or vds_set_idle_cap (0: none)
@@ -374,6 +383,32 @@ static int dev_copy_sync(vds_handle *h) {
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// the order days of one vds_load_order_days call are independent until their tables are laid back to back: worker threads take days
+// off a counter (at most 16, VDS_LOAD_THREADS overrides; one day: the calling thread).  fn(d) must not throw.
+template <typename F>
+static void for_each_day(int n_days, F &&fn) {
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *v = getenv("VDS_LOAD_THREADS")) { if (*v) nt = atoi(v); }
+    nt = std::max(1, std::min(std::min(nt, 16), n_days));
+    if (nt <= 1) { for (int d = 0; d < n_days; ++d) fn(d); return; }
+    std::atomic<int> next{0};
+    auto work = [&] { for (int d = next.fetch_add(1); d < n_days; d = next.fetch_add(1)) fn(d); };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; ++i) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+struct LoadTimer {       // VDS_LOAD_TIMING=1: where vds_load_orders* spends its time, to stderr
+    bool on; std::chrono::steady_clock::time_point t0;
+    LoadTimer() { const char *v = getenv("VDS_LOAD_TIMING"); on = v && *v == '1'; t0 = std::chrono::steady_clock::now(); }
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "vds_load_orders: %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 extern "C" {
 
 int32_t vds_version(void) { return (1 << 16) | 0; }
@@ -498,6 +533,8 @@ int vds_destroy(vds_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->dev_allocs) dev_free(p);
     for (void *p : h->order_allocs) dev_free(p);
+    for (void *p : h->map_allocs) dev_free(p);
+    for (void *p : h->result_allocs) dev_free(p);
     for (void *p : h->state_allocs) dev_free(p);
     for (void *p : h->idle_allocs) dev_free(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -861,8 +898,122 @@ static int alloc_state(vds_handle *h, int O) {
 }
 
 // self.Orders after CreateAllInstantiate (:325-342) for n_days independent days; replica r replays day replica_day[r].
+static int alloc_state(vds_handle *h, int O);
+
+// The replica -> day map h->replica_day over the resident order days, turned into what the kernels read: the storage order of the
+// replicas (regrouped by day when the map mixes days inside aligned groups of 16 and the padding stays under a quarter - see
+// vds_handle), Static.chunk_days / rperm / replica_day / int2ext / replica_desc / replica_desc2, the length of the batch's day.  Called
+// by vds_load_order_days and by vds_set_replica_days (another map over the SAME resident days: five small uploads, no table is rebuilt).
+static int apply_replica_map(vds_handle *h) {
+    Static &S = h->S;
+    const int RX = h->R_ext, n_days = S.n_days;
+    const std::vector<DayDesc> &ddesc = h->ddesc_host;
+    int Tmax = 0;                                   // the batch steps as long as its longest day that some replica replays
+    for (int r = 0; r < RX; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
+    S.T = Tmax;
+    S.R = RX; h->int2ext.clear(); h->ext2int.clear();
+    S.chunk_days = n_days > 1 ? 1 : 0;
+    for (int r = 0; r < RX && S.chunk_days; ++r)
+        if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
+    // a map that mixes days inside aligned groups of 16 replicas: the replicas are STORED regrouped by day (see vds_handle),
+    // every day's last group padded with dummy replicas, when the padding stays under a quarter; otherwise every 16-lane row
+    // of the fast kernel gets its own order stream (day mode 2)
+    std::vector<int> rperm;          // row slot -> internal replica, -1 for a dummy (k_tick_rows skips those rows)
+    std::vector<int> day_of_internal;
+    if (n_days > 1 && !S.chunk_days && h->cfg.force_generic == 0) {
+        std::vector<std::vector<int>> by_day(n_days);
+        for (int r = 0; r < RX; ++r) by_day[h->replica_day[r]].push_back(r);
+        std::vector<int> i2e;
+        for (int dd = 0; dd < n_days; ++dd) {
+            for (int r : by_day[dd]) { i2e.push_back(r); day_of_internal.push_back(dd); }
+            while (i2e.size() % 16) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // dummy: replays the empty day
+        }
+        if (i2e.size() * 4 <= (size_t)RX * 5) {
+            // (a handle that already stores more padded replicas keeps that many: the state tables are strided by S.R, and a map
+            // whose padding differs by a group must not re-allocate them - vds_set_replica_days every episode)
+            if (h->alloc_R > (int)i2e.size() && (size_t)h->alloc_R * 4 <= (size_t)RX * 5 && !h->state_allocs.empty())
+                while ((int)i2e.size() < h->alloc_R) { i2e.push_back(-1); day_of_internal.push_back(n_days); }
+            S.chunk_days = 1;
+            S.R = (int)i2e.size();
+            h->int2ext = i2e;
+            h->ext2int.assign(RX, -1);
+            for (int i = 0; i < S.R; ++i) if (i2e[i] >= 0) h->ext2int[i2e[i]] = i;
+            rperm.resize(S.R);
+            for (int i = 0; i < S.R; ++i) rperm[i] = i2e[i] >= 0 ? i : -1;
+        } else {
+            day_of_internal.clear();
+        }
+    }
+    if (day_of_internal.empty()) day_of_internal = h->replica_day;
+    for (void *p : h->map_allocs) dev_free(p);
+    h->map_allocs.clear();
+    struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
+    h->alloc_sink = &h->map_allocs;
+    int rc;
+    int *d;
+    S.rperm = nullptr; S.rslots = 0; S.int2ext = nullptr;
+    if (!rperm.empty()) { if ((rc = upload(h, &d, rperm))) return rc; S.rperm = d; S.rslots = (int)rperm.size(); }
+    if ((rc = upload(h, &d, day_of_internal))) return rc; S.replica_day = d;
+    if (!h->int2ext.empty()) { if ((rc = upload(h, &d, h->int2ext))) return rc; S.int2ext = d; }
+    {
+        std::vector<int4> rdesc(S.R);
+        for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[day_of_internal[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
+        int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
+    }
+    S.replica_desc2 = nullptr;
+    if (S.pull) {
+        std::vector<int4> rd2(S.R);
+        for (int r = 0; r < S.R; ++r) rd2[r] = day_of_internal[r] < n_days ? h->pull_desc[day_of_internal[r]] : make_int4(0, 0, 0, 0);
+        int4 *d4r; if ((rc = upload(h, &d4r, rd2))) return rc; S.replica_desc2 = d4r;
+    }
+    return VDS_OK;
+}
+
+// per-replica result tables (strided / sized by S.R): out [R][Oq], arr [slots][R] (static arrival slots), slog (hybrid tick)
+static int alloc_results(vds_handle *h) {
+    Static &S = h->S;
+    for (void *p : h->result_allocs) dev_free(p);
+    h->result_allocs.clear();
+    struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
+    h->alloc_sink = &h->result_allocs;
+    int rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(h->Oqmax, 1));
+    h->D.arr = nullptr;
+    S.arr_slots = std::max(h->pull_Od_max, 1);
+    if (!rc && S.pull) rc = dev_alloc(h, &h->D.arr, (size_t)S.R * S.arr_slots);       // [Od][R] (arr_index)
+    h->D.slog = nullptr;
+    if (!rc && h->hybrid_ok) rc = dev_alloc(h, &h->D.slog, (size_t)S.R * std::max(S.max_tick_orders, 1));
+    return rc;
+}
+
+// Another replica -> day map over the order days that are ALREADY resident (vds_load_order_days): no table is rebuilt.
+static int set_replica_days_impl(vds_handle *h, const int32_t *replica_day) {
+    if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_set_replica_days: load order days first");
+    if (!replica_day) return fail(h, VDS_EINVAL, "vds_set_replica_days: null map");
+    const int n_days = h->S.n_days;
+    for (int r = 0; r < h->R_ext; ++r)
+        if (replica_day[r] < 0 || replica_day[r] >= n_days) return fail(h, VDS_EINVAL, "vds_set_replica_days: replica %d is mapped to day %d of %d", r, replica_day[r], n_days);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));        // (the tick kernels in flight read the map's arrays)
+    h->replica_day.assign(replica_day, replica_day + h->R_ext);
+    const int R_before = h->S.R;
+    int rc = apply_replica_map(h);
+    if (rc) return rc;
+    if (h->S.R != R_before) {
+        // the storage order changed between "as given" and "regrouped by day" (or the padding outgrew the tables): the per-replica
+        // tables are strided by S.R - the slow path, allocations
+        if ((rc = alloc_state(h, h->alloc_O))) return rc;
+        if ((rc = alloc_results(h))) return rc;
+        if (h->d_veh_stage) { /* sized by R_ext: unchanged */ }
+    }
+    { h->run_stale = true; h->tables_gen++; }
+    h->have_reset = false;                              // the episode state belongs to the previous map: vds_reset* must follow
+    h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
+    return VDS_OK;
+}
+
 static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min, const int32_t *pickup,
                           const int32_t *delivery, const int32_t *replica_day) {
+    LoadTimer lt;
     if (!h || !h->have_static) return fail(h, VDS_EINVAL, "vds_load_orders: call vds_load_static first");
     if (n_days < 1 || !day_off || !release_min || !pickup || !delivery) return fail(h, VDS_EINVAL, "vds_load_orders: bad argument");
     for (int d = 0; d < n_days; ++d)
@@ -879,6 +1030,7 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
         h->err.clear();
     }
+    lt.lap("sync + free the previous day");
     Static &S = h->S;
     const int N = S.N, C = S.C, tick = S.tick_minutes;
     const int RX = h->R_ext;
@@ -897,129 +1049,127 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     std::vector<DayDesc> ddesc(n_days);
     int Tmax = 0, Oqmax = 0, Omax = 0, mto = 0;
     long long Ototal = 0;
-    for (int d = 0; d < n_days; ++d) {
-        DayHost &H = h->days[d];
-        const int32_t *rel = release_min + day_off[d], *pk = pickup + day_off[d], *dl = delivery + day_off[d];
-        const int O = (int)(day_off[d + 1] - day_off[d]);
-        // SimCity prologue :1037-1040
-        const long long now0 = (long long)rel[0] - tick;
-        const long long end = (long long)rel[O - 1] + 3LL * tick;
-        const int T = end >= now0 ? (int)((end - now0) / tick) + 1 : 0;
-        if (T > 65535) return fail(h, VDS_EINVAL, "vds_load_orders: %d ticks > 65535 unsupported", T);
-        H.O = O; H.T = T; H.now0 = (int)now0; H.q_base = (int)so_rec.size();
-        std::vector<int> value(O);
-        {
-            const std::vector<int> &costh = h->cost_host;
-            for (int i = 0; i < O; ++i) {
-                if (pk[i] < 0 || pk[i] >= N || dl[i] < 0 || dl[i] >= N) return fail(h, VDS_EINVAL, "vds_load_orders: order %d has a node outside [0,%d)", i, N);
-                value[i] = costh[(size_t)dl[i] * N + pk[i]];           // :341-342
-            }
+    {
+        // (a) per day, in parallel: SimCity's prologue, OrderValue, the cursor of MatchFunction, bucket counts
+        struct DayLocal { int O = 0, T = 0, n_proc = 0, day_mto = 0, code = 0; long long now0 = 0; std::vector<int> value, cnt, toff; std::string msg; };
+        std::vector<DayLocal> L(n_days);
+        auto day_fail = [](DayLocal &l, int code, const char *fmt, long long a, long long b) { char buf[256]; snprintf(buf, sizeof(buf), fmt, a, b); l.code = code; l.msg = buf; };
+        for_each_day(n_days, [&](int d) {
+            DayLocal &l = L[d];
+            try {
+                DayHost &H = h->days[d];
+                const int32_t *rel = release_min + day_off[d], *pk = pickup + day_off[d], *dl = delivery + day_off[d];
+                const int O = (int)(day_off[d + 1] - day_off[d]);
+                // SimCity prologue :1037-1040
+                const long long now0 = (long long)rel[0] - tick;
+                const long long end = (long long)rel[O - 1] + 3LL * tick;
+                const int T = end >= now0 ? (int)((end - now0) / tick) + 1 : 0;
+                if (T > 65535) { day_fail(l, VDS_EINVAL, "vds_load_orders: %lld ticks > 65535 unsupported", T, 0); return; }
+                l.O = O; l.T = T; l.now0 = now0;
+                H.O = O; H.T = T; H.now0 = (int)now0;
+                l.value.resize(O);
+                const std::vector<int> &costh = h->cost_host;
+                for (int i = 0; i < O; ++i) {
+                    if (pk[i] < 0 || pk[i] >= N || dl[i] < 0 || dl[i] >= N) { day_fail(l, VDS_EINVAL, "vds_load_orders: order %lld has a node outside [0,%lld)", i, N); return; }
+                    l.value[i] = costh[(size_t)dl[i] * N + pk[i]];           // :341-342
+                }
+                // the cursor of MatchFunction (:912-973): order i is processed at the first tick whose window
+                // covers every order up to i; the last order is never processed (quirk Q1, :914-915)
+                H.o_tick.assign(O, -1);
+                l.cnt.assign((size_t)T * C + 1, 0);
+                long long run = 0;
+                int n_proc = 0;
+                H.value_all = 0;
+                for (int i = 0; i < O; ++i) {
+                    H.value_all += l.value[i];
+                    long long x = (long long)rel[i] - now0;
+                    long long ti = x < 0 ? 0 : x / tick;
+                    run = std::max(run, ti);
+                    if (i == O - 1 || run >= T) continue;
+                    int pc = h->node2cluster[pk[i]], dc = h->node2cluster[dl[i]];
+                    if (pc < 0 || dc < 0) { day_fail(l, VDS_ESTATE, "vds_load_orders: order %lld touches a node outside every cluster (KeyError in the reference, :918/:960)", i, 0); return; }
+                    H.o_tick[i] = (int)run;
+                    l.cnt[(size_t)run * C + pc + 1]++;
+                    n_proc++;
+                }
+                for (size_t i = 1; i < l.cnt.size(); ++i) l.cnt[i] += l.cnt[i - 1];
+                l.n_proc = n_proc;
+            } catch (...) { l.code = VDS_ENOMEM; l.msg = "vds_load_orders: out of host memory"; }
+        });
+        // (b) the days laid back to back
+        std::vector<size_t> rec0(n_days + 1, 0), bk0(n_days + 1, 0), tk0(n_days + 1, 0);
+        for (int d = 0; d < n_days; ++d) {
+            if (L[d].code) return fail(h, L[d].code, "%s", L[d].msg.c_str());
+            rec0[d + 1] = rec0[d] + (size_t)L[d].n_proc;
+            bk0[d + 1] = bk0[d] + L[d].cnt.size();
+            tk0[d + 1] = tk0[d] + (size_t)L[d].T + 1;
+            if (rec0[d + 1] >= (1ull << 31)) return fail(h, VDS_EINVAL, "vds_load_orders: more than 2^31 processed orders on one handle");
+            if (bk0[d + 1] >= (1ull << 31)) return fail(h, VDS_EINVAL, "vds_load_orders: bucket table exceeds 2^31 entries");
         }
-        // the cursor of MatchFunction (:912-973): order i is processed at the first tick whose window
-        // covers every order up to i; the last order is never processed (quirk Q1, :914-915)
-        H.o_tick.assign(O, -1);
-        std::vector<int> cnt((size_t)T * C + 1, 0);
-        long long run = 0;
-        int n_proc = 0;
-        H.value_all = 0;
-        for (int i = 0; i < O; ++i) {
-            H.value_all += value[i];
-            long long x = (long long)rel[i] - now0;
-            long long ti = x < 0 ? 0 : x / tick;
-            run = std::max(run, ti);
-            if (i == O - 1 || run >= T) continue;
-            int pc = h->node2cluster[pk[i]], dc = h->node2cluster[dl[i]];
-            if (pc < 0 || dc < 0) return fail(h, VDS_ESTATE, "vds_load_orders: order %d touches a node outside every cluster (KeyError in the reference, :918/:960)", i);
-            H.o_tick[i] = (int)run;
-            cnt[(size_t)run * C + pc + 1]++;
-            n_proc++;
+        so_rec.resize(rec0[n_days]); so_pnode.resize(rec0[n_days]); ord_q.resize(rec0[n_days]);
+        bkt_off.resize(bk0[n_days]); tick_off.resize(tk0[n_days]);
+        // (c) per day, in parallel: the sorted order records (tick, pickup cluster, id), results' bookkeeping
+        for_each_day(n_days, [&](int d) {
+            DayLocal &l = L[d];
+            try {
+                DayHost &H = h->days[d];
+                const int32_t *pk = pickup + day_off[d], *dl = delivery + day_off[d];
+                const int O = l.O, T = l.T, n_proc = l.n_proc;
+                const size_t r0 = rec0[d];
+                H.q_base = (int)r0; H.Oq = n_proc;
+                H.so_id.assign(n_proc, 0);
+                H.q_value.assign(n_proc, 0);
+                H.value_upto.assign(T + 1, 0);
+                l.toff.assign(T + 1, 0);
+                std::vector<int> fill(l.cnt.begin(), l.cnt.end() - 1);
+                int k = 0;
+                for (int i = 0; i < O; ++i) {
+                    int ti = H.o_tick[i];
+                    if (ti < 0) continue;
+                    int pc = h->node2cluster[pk[i]], dc = h->node2cluster[dl[i]];
+                    int q = fill[(size_t)ti * C + pc]++;
+                    so_rec[r0 + q] = make_int4(i, h->node_local[pk[i]] | (h->node_local[dl[i]] << 16), dc | (pc << 16), l.value[i]);
+                    H.so_id[q] = i;
+                    H.q_value[q] = l.value[i];
+                    so_pnode[r0 + q] = pk[i];
+                    ord_q[r0 + k++] = (int)r0 + q;                       // absolute positions
+                    l.toff[ti + 1]++;
+                    H.value_upto[ti + 1] += l.value[i];
+                }
+                for (int t = 0; t < T; ++t) { l.toff[t + 1] += l.toff[t]; H.value_upto[t + 1] += H.value_upto[t]; }
+                int day_mto = 0;
+                for (int t = 0; t < T; ++t) day_mto = std::max(day_mto, l.toff[t + 1] - l.toff[t]);
+                l.day_mto = day_mto;
+                ddesc[d].bkt_base = (int)bk0[d];
+                ddesc[d].tick_base = (int)tk0[d];
+                ddesc[d].now0 = H.now0; ddesc[d].T = T; ddesc[d].q_base = H.q_base; ddesc[d].Oq = n_proc;
+                ddesc[d].max_tick_orders = day_mto; ddesc[d].pad = 0;
+                for (size_t i = 0; i < l.cnt.size(); ++i) bkt_off[bk0[d] + i] = l.cnt[i] + (int)r0;            // absolute positions
+                for (int t = 0; t <= T; ++t) tick_off[tk0[d] + t] = l.toff[t] + (int)r0;
+                std::vector<int>().swap(l.value); std::vector<int>().swap(l.cnt);
+            } catch (...) { l.code = VDS_ENOMEM; l.msg = "vds_load_orders: out of host memory"; }
+        });
+        for (int d = 0; d < n_days; ++d) {
+            if (L[d].code) return fail(h, L[d].code, "%s", L[d].msg.c_str());
+            Tmax = std::max(Tmax, L[d].T); Oqmax = std::max(Oqmax, L[d].n_proc); Omax = std::max(Omax, L[d].O); mto = std::max(mto, L[d].day_mto);
+            Ototal += L[d].O;
         }
-        if ((long long)so_rec.size() + n_proc >= (1ll << 31)) return fail(h, VDS_EINVAL, "vds_load_orders: more than 2^31 processed orders on one handle");
-        for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
-        H.Oq = n_proc;
-        H.so_id.assign(n_proc, 0);
-        H.q_value.assign(n_proc, 0);
-        H.value_upto.assign(T + 1, 0);
-        std::vector<int> toff(T + 1, 0);
-        const size_t rec0 = so_rec.size(), oq0 = ord_q.size();
-        so_rec.resize(rec0 + n_proc);
-        so_pnode.resize(rec0 + n_proc);
-        ord_q.resize(oq0 + n_proc);
-        {
-            std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-            int k = 0;
-            for (int i = 0; i < O; ++i) {
-                int ti = H.o_tick[i];
-                if (ti < 0) continue;
-                int pc = h->node2cluster[pk[i]], dc = h->node2cluster[dl[i]];
-                int q = fill[(size_t)ti * C + pc]++;
-                so_rec[rec0 + q] = make_int4(i, h->node_local[pk[i]] | (h->node_local[dl[i]] << 16), dc | (pc << 16), value[i]);
-                H.so_id[q] = i;
-                H.q_value[q] = value[i];
-                so_pnode[rec0 + q] = pk[i];
-                ord_q[oq0 + k++] = (int)rec0 + q;                       // absolute positions
-                toff[ti + 1]++;
-                H.value_upto[ti + 1] += value[i];
-            }
-            for (int t = 0; t < T; ++t) { toff[t + 1] += toff[t]; H.value_upto[t + 1] += H.value_upto[t]; }
-        }
-        int day_mto = 0;
-        for (int t = 0; t < T; ++t) day_mto = std::max(day_mto, toff[t + 1] - toff[t]);
-        ddesc[d].bkt_base = (int)bkt_off.size();
-        ddesc[d].tick_base = (int)tick_off.size();
-        ddesc[d].now0 = H.now0; ddesc[d].T = T; ddesc[d].q_base = H.q_base; ddesc[d].Oq = n_proc;
-        ddesc[d].max_tick_orders = day_mto; ddesc[d].pad = 0;
-        if ((long long)bkt_off.size() + (long long)cnt.size() >= (1ll << 31)) return fail(h, VDS_EINVAL, "vds_load_orders: bucket table exceeds 2^31 entries");
-        for (int v : cnt) bkt_off.push_back(v + (int)rec0);            // absolute positions
-        for (int v : toff) tick_off.push_back(v + (int)oq0);
-        Tmax = std::max(Tmax, T); Oqmax = std::max(Oqmax, n_proc); Omax = std::max(Omax, O); mto = std::max(mto, day_mto);
-        Ototal += O;
     }
-    Tmax = 0;                                   // the batch steps as long as its longest day that some replica replays
-    for (int r = 0; r < RX; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
-    S.now0 = h->days[0].now0; S.T = Tmax; S.Oq = Oqmax; h->O = Omax;
+    lt.lap("cursor, buckets, sorted records");
+    S.now0 = h->days[0].now0; S.Oq = Oqmax; h->O = Omax; h->Oqmax = Oqmax;
     S.n_days = n_days;
-    S.chunk_days = n_days > 1 ? 1 : 0;
-    for (int r = 0; r < RX && S.chunk_days; ++r)
-        if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
-    // a map that mixes days inside aligned groups of 16 replicas: the replicas are STORED regrouped by day (see vds_handle),
-    // every day's last group padded with dummy replicas, when the padding stays under a quarter; otherwise every 16-lane row
-    // of the fast kernel gets its own order stream (day mode 2)
-    std::vector<int> rperm;          // row slot -> internal replica, -1 for a dummy (k_tick_rows skips those rows)
-    std::vector<int> day_of_internal;
-    if (n_days > 1 && !S.chunk_days && h->cfg.force_generic == 0) {
-        std::vector<std::vector<int>> by_day(n_days);
-        for (int r = 0; r < RX; ++r) by_day[h->replica_day[r]].push_back(r);
-        std::vector<int> i2e;
-        for (int dd = 0; dd < n_days; ++dd) {
-            for (int r : by_day[dd]) { i2e.push_back(r); day_of_internal.push_back(dd); }
-            while (i2e.size() % 16) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // dummy: replays the empty day
-        }
-        if (i2e.size() * 4 <= (size_t)RX * 5) {
-            S.chunk_days = 1;
-            S.R = (int)i2e.size();
-            h->int2ext = i2e;
-            h->ext2int.assign(RX, -1);
-            for (int i = 0; i < S.R; ++i) if (i2e[i] >= 0) h->ext2int[i2e[i]] = i;
-            rperm.resize(S.R);
-            for (int i = 0; i < S.R; ++i) rperm[i] = i2e[i] >= 0 ? i : -1;
-        } else {
-            day_of_internal.clear();
-        }
-    }
-    if (day_of_internal.empty()) day_of_internal = h->replica_day;
-    if (!h->int2ext.empty()) {       // the empty day of the dummy replicas: over before its first slot
+    (void)Tmax;
+    {   // the empty day of padding replicas (storage regrouped by day): over before its first slot.  Always there, last.
         DayDesc e{}; e.bkt_base = 0; e.tick_base = 0; e.now0 = h->days[0].now0; e.T = 0; e.q_base = 0; e.Oq = 0; e.max_tick_orders = 0; e.pad = 0;
         ddesc.push_back(e);
     }
+    h->ddesc_host = ddesc;
     S.max_tick_orders = mto;
     int rc;
     int *d;
     int4 *d4;
     struct Sink { vds_handle *h; ~Sink() { h->alloc_sink = nullptr; } } sink{h};
     h->alloc_sink = &h->order_allocs;
-    S.rperm = nullptr; S.rslots = 0;
-    if (!rperm.empty()) { if ((rc = upload(h, &d, rperm))) return rc; S.rperm = d; S.rslots = (int)rperm.size(); }
     if ((rc = upload(h, &d4, so_rec))) return rc; S.so_rec = d4;
     if ((rc = upload(h, &d, bkt_off))) return rc; S.bkt_off = d;
     if ((rc = upload(h, &d, tick_off))) return rc; S.tick_off = d;
@@ -1027,56 +1177,41 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     if ((rc = upload(h, &d, ord_q))) return rc; S.ord_q = d;
     {   // rank of every sorted position inside its slot (tick_off / ord_q hold absolute positions)
         std::vector<int> so_rank(so_rec.size(), 0);
-        size_t tbase = 0;
-        for (int dd = 0; dd < n_days; ++dd) {
+        for_each_day(n_days, [&](int dd) {
             const DayDesc &de = ddesc[dd];
             for (int t = 0; t < de.T; ++t) {
                 const int a = tick_off[de.tick_base + t], b = tick_off[de.tick_base + t + 1];
                 for (int i = a; i < b; ++i) so_rank[ord_q[i]] = i - a;
             }
-        }
-        (void)tbase;
+        });
         if ((rc = upload(h, &d, so_rank))) return rc; S.so_rank = d;
     }
+    lt.lap("upload records, ranks");
     S.so_lb = nullptr; S.so_vis = nullptr;
     if (h->dfs_mode && h->cfg.force_generic == 0 && h->max_seq <= 256 && mto < 65535 && (long long)so_rec.size() * S.seq_pad * 5 <= (6ll << 30)) {
         // per sorted order, for the hybrid neighbour-search tick: its visit sequence (j-th visited cluster | orders of that cluster
         // of the same slot with a smaller id << 16) and, with byte costs, the cost bounds of those clusters (Static.lbc gathered
-        // through the sequence once, here)
-        std::vector<unsigned> so_vis(so_rec.size() * (size_t)S.seq_pad, 0xFFFFFFFFu);
-        std::vector<unsigned char> so_lb(h->lbc_host.empty() ? 0 : so_rec.size() * (size_t)S.seq_pad, 255);
-        std::vector<int> before((size_t)S.C);
-        for (int dd = 0; dd < n_days; ++dd) {
+        // through the sequence once) - built ON THE DEVICE from the tables uploaded above (k_build_vis, vds_dfs.hip)
+        std::vector<int> so_bkt0(so_rec.size(), 0);
+        for_each_day(n_days, [&](int dd) {
             const DayDesc &de = ddesc[dd];
             for (int t = 0; t < de.T; ++t) {
-                const int a = tick_off[de.tick_base + t], b = tick_off[de.tick_base + t + 1];
-                std::fill(before.begin(), before.end(), 0);
-                for (int i = a; i < b; ++i) {               // id (rank) order inside the slot
-                    const size_t q = (size_t)ord_q[i];
-                    const int pc = (int)((unsigned)so_rec[q].z >> 16);
-                    const int s0 = h->dfs_off_host[pc], n = h->dfs_off_host[pc + 1] - s0;
-                    unsigned *dst = so_vis.data() + q * (size_t)S.seq_pad;
-                    for (int j = 0; j < n; ++j) { const int c = h->dfs_seq_host[s0 + j]; dst[j] = (unsigned)c | ((unsigned)before[c] << 16); }
-                    if (!so_lb.empty()) {
-                        const unsigned char *row = h->lbc_host.data() + (size_t)so_pnode[q] * S.C;
-                        unsigned char *dl = so_lb.data() + q * (size_t)S.seq_pad;
-                        for (int j = 0; j < n; ++j) dl[j] = row[h->dfs_seq_host[s0 + j]];
-                    }
-                    before[pc] += 1;
-                }
+                const int b0 = de.bkt_base + t * C;
+                for (int q = bkt_off[b0]; q < bkt_off[b0 + C]; ++q) so_bkt0[q] = b0;
             }
-        }
-        unsigned *dv; if ((rc = upload(h, &dv, so_vis))) return rc; S.so_vis = dv;
-        if (!so_lb.empty()) { unsigned char *dl; if ((rc = upload(h, &dl, so_lb))) return rc; S.so_lb = dl; }
+        });
+        int *d_b0;
+        if ((rc = upload(h, &d_b0, so_bkt0))) return rc;
+        unsigned *dv;
+        if ((rc = dev_alloc(h, &dv, so_rec.size() * (size_t)S.seq_pad))) return rc;
+        unsigned char *dl = nullptr;
+        if (!h->lbc_host.empty() && (rc = dev_alloc(h, &dl, so_rec.size() * (size_t)S.seq_pad))) return rc;
+        launch_build_vis(S, d_b0, dv, dl, (long long)so_rec.size(), h->stream);
+        HIPCHK(h, hipGetLastError());
+        S.so_vis = dv; S.so_lb = dl;
     }
+    lt.lap("visit rows + bounds per order");
     { DayDesc *dd; if ((rc = upload(h, &dd, ddesc))) return rc; S.day = dd; }
-    if ((rc = upload(h, &d, day_of_internal))) return rc; S.replica_day = d;
-    if (!h->int2ext.empty()) { if ((rc = upload(h, &d, h->int2ext))) return rc; S.int2ext = d; }
-    {
-        std::vector<int4> rdesc(S.R);
-        for (int r = 0; r < S.R; ++r) { const DayDesc &dd = ddesc[day_of_internal[r]]; rdesc[r] = make_int4(dd.bkt_base, dd.now0, dd.T, dd.q_base); }
-        int4 *dr; if ((rc = upload(h, &dr, rdesc))) return rc; S.replica_desc = dr;
-    }
     // ---- dense layout (k_tick_dense: 4-byte idle entries, 8-byte arrival entries): the plain tick - one shared day, one day per
     //      workgroup chunk or one day per replica (day modes 0 / 1 / 2) -, ids that fit the packed keys.  vds_config.force_generic 5
     //      keeps the wide layout and k_tick_rows.
@@ -1120,46 +1255,63 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         std::vector<int4> ddesc2(ddesc.size(), make_int4(0, 0, 0, 0));
         int W = 0, hmax = 0;
         bool ok = true;
-        for (int dd = 0; dd < n_days && ok; ++dd) {
-            const DayDesc &de = ddesc[dd];
-            const int TA = de.T + Hc;                        // a0 < T + H for every pull order
-            if (TA >= 65535) { ok = false; break; }
-            struct PO { int dc, a0, id, q, dmin, tins; };
-            std::vector<PO> po;
-            po.reserve(de.Oq);
+        // per day (in parallel, for_each_day): the day's pull orders in the order (destination cluster, earliest arrival slot a0, id) -
+        // a stable counting sort on (dc, a0) over the orders taken in id order (tick_off / ord_q); round 5: a comparison sort of
+        // 200 000 records was 14 of the 19 ms of a Reload at configs[1]
+        struct PullDay { std::vector<int> start; int npull = 0, W = 0, hmax = 0, TA = 0, code = 0; };
+        std::vector<PullDay> PD(n_days);
+        auto for_pull = [&](const DayDesc &de, auto &&fn) {
             for (int t = 0; t < de.T; ++t)
-                for (int c = 0; c < C; ++c)
-                    for (int q = bkt_off[de.bkt_base + (size_t)t * C + c]; q < bkt_off[de.bkt_base + (size_t)t * C + c + 1]; ++q) {
-                        const int4 &rr = so_rec[q];
-                        const int dmin = slots_of(rr.w), dmax = slots_of((long long)rr.w + h->cl_cmax[c]);
-                        if (dmax >= Hc) continue;            // may outlive the ring horizon: stays on the ring / far path
-                        W = std::max(W, dmax - dmin);
-                        hmax = std::max(hmax, dmin);
-                        po.push_back(PO{rr.z & 0xFFFF, t + dmin, rr.x, q, dmin, t});
-                    }
-            std::sort(po.begin(), po.end(), [](const PO &a, const PO &b) { return a.dc != b.dc ? a.dc < b.dc : (a.a0 != b.a0 ? a.a0 < b.a0 : a.id < b.id); });
-            const int base = (int)d_rec.size();
-            ddesc2[dd] = make_int4((int)d_first.size(), base, TA, (int)po.size());
-            // d_first[a][c]: first position (absolute) of the day's orders to cluster c with a0 >= a, a = 0 .. TA
-            std::vector<int> first((size_t)(TA + 1) * C, 0);
-            {
-                size_t i = 0;
-                for (int c = 0; c < C; ++c) {
-                    for (int a = 0; a <= TA; ++a) {
-                        while (i < po.size() && po[i].dc == c && po[i].a0 < a) ++i;
-                        first[(size_t)a * C + c] = base + (int)i;
-                    }
-                    while (i < po.size() && po[i].dc == c) ++i;
+                for (int ix = tick_off[de.tick_base + t]; ix < tick_off[de.tick_base + t + 1]; ++ix) {
+                    const int q = ord_q[ix];
+                    const int4 &rr = so_rec[q];
+                    const int c = (int)((unsigned)rr.z >> 16);
+                    const int dmin = slots_of(rr.w), dmax = slots_of((long long)rr.w + h->cl_cmax[c]);
+                    if (dmax >= Hc) continue;            // may outlive the ring horizon: stays on the ring / far path
+                    fn(q, rr, t, dmin, dmax);
                 }
-            }
-            for (size_t i = 0; i < po.size(); ++i) {
-                const PO &o = po[i];
-                const int4 &rr = so_rec[o.q];
-                d_rec.push_back(make_int2((int)dense_key(o.tins, 0, o.id), o.a0 | ((int)((unsigned)rr.y >> 16) << 16) | (o.dmin << 24)));
-                so_slot[o.q] = (int)i;
-            }
-            d_first.insert(d_first.end(), first.begin(), first.end());
-            Od_max = std::max(Od_max, (int)po.size());
+        };
+        for (int dd = 0; dd < n_days; ++dd) { PD[dd].TA = ddesc[dd].T + Hc; if (PD[dd].TA >= 65535) ok = false; }      // a0 < T + H for every pull order
+        if (ok) for_each_day(n_days, [&](int dd) {
+            PullDay &P = PD[dd];
+            try {
+                const int TA = P.TA;
+                P.start.assign((size_t)C * (TA + 1) + 1, 0);
+                for_pull(ddesc[dd], [&](int, const int4 &rr, int t, int dmin, int dmax) {
+                    P.W = std::max(P.W, dmax - dmin);
+                    P.hmax = std::max(P.hmax, dmin);
+                    P.start[(size_t)(rr.z & 0xFFFF) * (TA + 1) + (t + dmin) + 1]++;
+                    ++P.npull;
+                });
+                for (size_t kx = 0; kx + 1 < P.start.size(); ++kx) P.start[kx + 1] += P.start[kx];
+            } catch (...) { P.code = VDS_ENOMEM; }
+        });
+        std::vector<size_t> rbase(n_days + 1, 0), fbase(n_days + 1, 0);
+        for (int dd = 0; dd < n_days && ok; ++dd) {
+            if (PD[dd].code) return fail(h, VDS_ENOMEM, "vds_load_orders: out of host memory");
+            rbase[dd + 1] = rbase[dd] + (size_t)PD[dd].npull;
+            fbase[dd + 1] = fbase[dd] + (size_t)(PD[dd].TA + 1) * C;
+            W = std::max(W, PD[dd].W); hmax = std::max(hmax, PD[dd].hmax); Od_max = std::max(Od_max, PD[dd].npull);
+            ddesc2[dd] = make_int4((int)fbase[dd], (int)rbase[dd], PD[dd].TA, PD[dd].npull);
+        }
+        if (fbase[n_days] >= (1ull << 31) || rbase[n_days] >= (1ull << 31)) ok = false;
+        if (ok) {
+            d_rec.resize(rbase[n_days]);
+            d_first.resize(fbase[n_days]);
+            for_each_day(n_days, [&](int dd) {
+                PullDay &P = PD[dd];
+                const int TA = P.TA, base = (int)rbase[dd];
+                // d_first[a][c]: first position (absolute) of the day's orders to cluster c with a0 >= a, a = 0 .. TA
+                int *first = d_first.data() + fbase[dd];
+                for (int c = 0; c < C; ++c)
+                    for (int a = 0; a <= TA; ++a) first[(size_t)a * C + c] = base + P.start[(size_t)c * (TA + 1) + a];
+                for_pull(ddesc[dd], [&](int q, const int4 &rr, int t, int dmin, int) {
+                    const int a0 = t + dmin;
+                    const int i = P.start[(size_t)(rr.z & 0xFFFF) * (TA + 1) + a0]++;
+                    d_rec[(size_t)base + i] = make_int2((int)dense_key(t, 0, rr.x), a0 | ((int)((unsigned)rr.y >> 16) << 16) | (dmin << 24));
+                    so_slot[q] = i;
+                });
+            });
         }
         if ((long long)d_first.size() >= (1ll << 31) || W > DENSE_PULL_WMAX) ok = false;
         if (!ok) S.pull = 0;
@@ -1170,22 +1322,19 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
             if ((rc = upload(h, &d, so_slot))) return rc; S.so_slot = d;
             int2 *d2; if ((rc = upload(h, &d2, d_rec))) return rc; S.d_rec = d2;
             if ((rc = upload(h, &d, d_first))) return rc; S.d_first = d;
-            std::vector<int4> rd2(S.R);
-            for (int r = 0; r < S.R; ++r) rd2[r] = day_of_internal[r] < n_days ? ddesc2[day_of_internal[r]] : make_int4(0, 0, 0, 0);
-            int4 *d4r; if ((rc = upload(h, &d4r, rd2))) return rc; S.replica_desc2 = d4r;
             h->pull_desc = ddesc2;
             d_first_keep = d_first;
             h->pull_drec = d_rec;
             h->pull_slot_q.assign(d_rec.size(), 0);
-            for (size_t q = 0; q < so_slot.size(); ++q) {
-                if (so_slot[q] < 0) continue;
-                // which day? q -> day by q_base ranges
-                int dd = (int)(std::upper_bound(ddesc.begin(), ddesc.begin() + n_days, (int)q, [](int v, const DayDesc &e) { return v < e.q_base; }) - ddesc.begin()) - 1;
-                h->pull_slot_q[(size_t)ddesc2[dd].y + so_slot[q]] = (int)q - ddesc[dd].q_base;
-            }
+            for_each_day(n_days, [&](int dd) {
+                const int qb = ddesc[dd].q_base;
+                for (int q = qb; q < qb + ddesc[dd].Oq; ++q)
+                    if (so_slot[q] >= 0) h->pull_slot_q[(size_t)ddesc2[dd].y + so_slot[q]] = q - qb;
+            });
         }
     }
     h->pull_Od_max = Od_max;
+    lt.lap("static arrival slots");
     // per-bucket descriptors of the dense tick with one shared day (Static.tdesc)
     S.tdesc = nullptr;
     if (S.dense && n_days == 1 && (int)h->corder_host.size() == C) {
@@ -1211,14 +1360,12 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         int4 *dtd; if ((rc = upload(h, &dtd, td))) return rc; S.tdesc = dtd;
     }
     h->alloc_sink = nullptr;
-    if ((rc = alloc_state(h, (int)std::min<long long>(Ototal / n_days, 0x7fffffff)))) return rc;
-    h->alloc_sink = &h->order_allocs;            // results: [R][Oq]
-    rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(Oqmax, 1));
-    h->D.arr = nullptr;
-    S.arr_slots = std::max(h->pull_Od_max, 1);
-    if (!rc && S.pull) rc = dev_alloc(h, &h->D.arr, (size_t)S.R * S.arr_slots);       // [Od][R] (arr_index)
+    lt.lap("bucket descriptors");
+    if ((rc = apply_replica_map(h))) return rc;         // S.R (stored replicas), S.T, the map's arrays
     h->alloc_sink = nullptr;
-    if (rc) return rc;
+    h->alloc_O = (int)std::min<long long>(Ototal / n_days, 0x7fffffff);
+    if ((rc = alloc_state(h, h->alloc_O))) return rc;
+    lt.lap("state tables");
     {   // preconditions of k_tick_replica2 (packed ids, 16-bit positions / nodes / costs, LDS footprint)
         const Static &Z = h->S;
         const int ids2 = std::max(Z.max_tick_orders, 4 * Z.C);
@@ -1236,14 +1383,9 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
                        Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
                        dfs_walk_lds(Z) + 1024 <= 64 * 1024 && Z.so_vis != nullptr;
-        h->D.slog = nullptr;
-        if (h->hybrid_ok) {
-            h->alloc_sink = &h->order_allocs;
-            rc = dev_alloc(h, &h->D.slog, (size_t)Z.R * std::max(Z.max_tick_orders, 1));
-            h->alloc_sink = nullptr;
-            if (rc) return rc;
-        }
     }
+    if ((rc = alloc_results(h))) return rc;
+    lt.lap("results, arrival slots, steal log");
     h->have_orders = true;
     return VDS_OK;
 }
@@ -2463,6 +2605,10 @@ int vds_load_order_days(vds_handle *h, int32_t n_days, const int64_t *day_off, c
 int vds_load_orders_strided(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O,
                             int64_t replica_stride) {
     return guarded(h, "vds_load_orders_strided", [&] { return load_orders_strided_impl(h, release_min, pickup, delivery, O, replica_stride); });
+}
+
+int vds_set_replica_days(vds_handle *h, const int32_t *replica_day) {
+    return guarded(h, "vds_set_replica_days", [&] { return set_replica_days_impl(h, replica_day); });
 }
 
 int vds_replica_ticks(const vds_handle *h, int32_t replica, int32_t *T, int32_t *n_orders) {

@@ -2144,8 +2144,46 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
 }
 
 // ---------------------------------------------------------------------------------------
+// k_build_vis: the per-order visit rows of the hybrid tick, built on the device at vds_load_orders* (round 5; the host loop - 100 MB
+// of rows at configs[3], then their upload - was 56 of the 62 ms of a Reload, :130-212).  Thread (sorted order q, visit slot j):
+//   so_vis[q][j] = j-th cluster c' of the visit sequence of q's pickup cluster (FindServerVehicleFunction :978-996, Static.dfs_seq)
+//                  | orders of bucket (q's slot, c') with a smaller id << 16   (ranks ascend with the sorted position inside a bucket:
+//                  a binary search over Static.so_rank), 0xFFFFFFFF past the end of the sequence;
+//   so_lb[q][j]  = Static.lbc[pickup node of q][c'] (byte costs), 255 past the end.
+// so_bkt0[q]: index into bkt_off of (q's day, q's slot, cluster 0).
+__global__ __launch_bounds__(256) void k_build_vis(Static S, const int *so_bkt0, unsigned *so_vis, unsigned char *so_lb, long long n_orders) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long q = i / S.seq_pad;
+    const int j = (int)(i % S.seq_pad);
+    if (q >= n_orders) return;
+    const int pc = (int)((unsigned)S.so_rec[q].z >> 16);
+    const int s0 = S.dfs_off[pc], n = S.dfs_off[pc + 1] - s0;
+    unsigned v = 0xFFFFFFFFu;
+    unsigned char lb = 255;
+    if (j < n) {
+        const int c = S.dfs_seq[s0 + j];
+        const int b0 = so_bkt0[q];
+        int lo = S.bkt_off[b0 + c];
+        int hi = S.bkt_off[b0 + c + 1];
+        const int rk = S.so_rank[q];
+        const int first = lo;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (S.so_rank[mid] < rk) lo = mid + 1; else hi = mid; }
+        v = (unsigned)c | ((unsigned)(lo - first) << 16);
+        if (so_lb) lb = S.lbc[(size_t)S.so_pnode[q] * S.C + c];
+    }
+    so_vis[i] = v;
+    if (so_lb) so_lb[i] = lb;
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers (called from vds_api.hip)
 // ---------------------------------------------------------------------------------------
+void launch_build_vis(const Static &S, const int *so_bkt0, unsigned *so_vis, unsigned char *so_lb, long long n_orders, hipStream_t st) {
+    const long long total = n_orders * S.seq_pad;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_build_vis, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, so_bkt0, so_vis, so_lb, n_orders);
+}
+
 void launch_hybrid_rows(const Static &S, const State &D, int t, int lds_ints, hipStream_t st, int r_lo, int r_n);      // vds_tick.hip
 
 void launch_tick_replica2(const Static &S, const State &D, int t, hipStream_t st) {

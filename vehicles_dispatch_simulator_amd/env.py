@@ -136,6 +136,17 @@ class BatchedDispatchEnv:
         self._chk(self._lib.vds_load_order_days(self._h, len(days), _p(off), _p(rel), _p(pk), _p(dl), _p(rd)))
         self._after_load(int(np.diff(off).max()))
 
+    def set_replica_days(self, replica_day):
+        """Another replica -> day map over the days of the last ``load_order_days`` (``vds_set_replica_days``): nothing is
+        rebuilt or re-read - what the reference does with one ``Reload`` per city (``simulator.py:130-212``).  A reset must follow."""
+        rd = _i32(replica_day)
+        if rd.size != self.R:
+            raise Exception("set_replica_days: replica_day needs %d entries" % self.R)
+        self._chk(self._lib.vds_set_replica_days(self._h, _p(rd)))
+        t = C.c_int32()
+        self._chk(self._lib.vds_num_ticks(self._h, C.byref(t)))
+        self.T = t.value
+
     def load_orders_strided(self, release_min, pickup, delivery, O: int, replica_stride: int):
         """SURVEY 8(b) form: replica ``r``'s day starts at element ``r * replica_stride`` (0 = one shared day)."""
         r, p, d = _i32(release_min).reshape(-1), _i32(pickup).reshape(-1), _i32(delivery).reshape(-1)
