@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--no-distinct-all", dest="distinct_all", action="store_false", help="skip the leg with one order stream per replica")
     ap.add_argument("--distinct-all-days", type=int, default=128, help="distinct days of that leg (replica r replays day r %% N)")
     ap.add_argument("--no-hooked-leg", dest="hooked", action="store_false", help="skip the hooked-slot leg (step -> obs -> policy -> dispatch -> advance)")
+    ap.add_argument("--no-fallbacks-leg", dest="fallbacks", action="store_false", help="skip the leg that times the documented fallback tick paths")
     a = ap.parse_args()
 
     import torch
@@ -558,6 +559,42 @@ def main():
         finally:
             env.reset(init)          # whatever happened above: the --check pass and the line below describe `init`
 
+    # ---- the documented fallbacks (rank 0, N = 1): every tick path a configuration can end up on has a number next to the default's
+    #      (DESIGN.md 5).  A few days each; the serial reference form of the neighbour search on 128 replicas (it takes seconds per day)
+    fallbacks = None
+    if rank == 0 and world == 1 and a.fallbacks and a.workload == "cfg2":
+        fallbacks = {"unit": "env-steps*replicas/s", "note": "same workload and replica count as the headline unless said; vds_config.force_generic selects the path"}
+        def leg(wl, Rl, fg, nd, environ=None):
+            saved = {k: os.environ.get(k) for k in (environ or {})}
+            os.environ.update(environ or {})
+            try:
+                e = wl.make_env(Rl, device=local_rank, stream=stream.cuda_stream, force_generic=fg)
+            finally:
+                for k, v in saved.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            e.reset(wl.vehicle_nodes(Rl))
+            Tl = e.T
+            e.reset_again(); e.run(Tl); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nd):
+                e.reset_again(); e.run(Tl)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            e.sync()
+            out = {"value": Tl * Rl * nd / dt, "ms_per_step": dt / nd * 1e3, "steps": nd, "replicas": Rl, "kernel": e.main_kernel()}
+            e.close()
+            return out
+        try:
+            w4f = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
+            fallbacks["configs[1] wide layout, row-mapped kernel (force_generic 5: clusters above 255 nodes, V >= 2^24, costs beyond the dense keys)"] = leg(w, R, 5, 3)
+            fallbacks["configs[1] generic kernel, one wavefront per bucket (force_generic 1: costs >= 2^23 or above the pickup window)"] = leg(w, R, 1, 2)
+            fallbacks["configs[1] dense tick with the arrival ring instead of static arrival slots (VDS_DENSE_PULL=0)"] = leg(w, R, 0, 3, {"VDS_DENSE_PULL": "0"})
+            fallbacks["configs[3] hybrid tick with deferred acceptance (VDS_WALK_DA=1)"] = leg(w4f, R, 0, 2, {"VDS_WALK_DA": "1"})
+            fallbacks["configs[3] lower-bound rounds (force_generic 3: visit sequences over 256 clusters, costs >= 2^15)"] = leg(w4f, R, 3, 2)
+            fallbacks["configs[3] serial reference form (force_generic 1), 128 replicas"] = leg(w4f, 128, 1, 1)
+        except Exception as e:       # (a reported extra)
+            fallbacks["error"] = repr(e)
+
     # ---- episode turnover (rank 0, N = 1): what an RL loop pays to change the order day between episodes (the reference: Reload,
     #      simulator.py:130-212).  (a) another replica -> day map over resident days (vds_set_replica_days: nothing rebuilt),
     #      (b) a new day on a loaded handle (vds_load_orders: host tables by counting sorts, the neighbour search's visit rows built
@@ -646,6 +683,8 @@ def main():
             out["episode_reset"] = episode_reset
         if episode_turnover is not None:
             out["episode_turnover"] = episode_turnover
+        if fallbacks is not None:
+            out["fallbacks"] = fallbacks
         if check is not None:
             out["parity_check_vs_oracle"] = check
         print(json.dumps(out))
