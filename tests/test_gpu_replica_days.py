@@ -410,13 +410,17 @@ def test_replica_day_map_changes_every_episode_over_resident_days(name, R):
     stream per row), everything on one day - and every replica is compared with the oracle of ITS day after every episode."""
     g = load_golden(name)
     V, N = int(g["V"]), int(g["N"])
-    days = synth_days(g, 4, seed=4100 + R)
+    days = synth_days(g, 5 if R == 40 else 4, seed=4100 + R)
     rng = np.random.default_rng(31 + R)
     valid = g["node2cluster"] >= 0
     init = np.stack([synth.init_vehicle_nodes(random.Random(7000 + r), N, V, valid) for r in range(R)])
     env = mk_env(g, R)
     maps = [np.minimum(np.arange(R) // 16, 3), np.arange(R) % 4, rng.integers(0, 4, size=R), np.arange(R) % 2, np.zeros(R, dtype=np.int64), (np.arange(R) * 7 + 1) % 4,
             np.minimum(np.arange(R) // 16, 3)[::-1].copy()]
+    if R == 40:
+        # day groups of EIGHT replicas (the dense tick's 8-row workgroups): as given, and interleaved over five days - regrouped by
+        # day in groups of eight (groups of sixteen would double the replicas) - then back to one stream per row and to blocks of 16
+        maps += [np.arange(R) // 8, np.arange(R) % 5, rng.integers(0, 5, size=R), (np.arange(R) // 8 + 2) % 5, np.minimum(np.arange(R) // 16, 3)]
     env.load_order_days(days, maps[0].astype(np.int32))
     expected = {}
     for ep, rd in enumerate(maps):

@@ -912,9 +912,18 @@ static int apply_replica_map(vds_handle *h) {
     for (int r = 0; r < RX; ++r) Tmax = std::max(Tmax, h->days[h->replica_day[r]].T);
     S.T = Tmax;
     S.R = RX; h->int2ext.clear(); h->ext2int.clear();
+    // the day groups' granule: aligned groups of 16 replicas on one day - or, on the dense layout at 16 lanes per replica (what order
+    // days per replica run with), of 8: k_tick_dense then runs 8-row workgroups
+    const bool gran8_ok = S.dense && S.dense_lpr == 16 && h->cfg.force_generic == 0 && !(getenv("VDS_ROW_GRAN8") && getenv("VDS_ROW_GRAN8")[0] == '0');
+    S.row_gran = 16;
     S.chunk_days = n_days > 1 ? 1 : 0;
     for (int r = 0; r < RX && S.chunk_days; ++r)
         if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
+    if (n_days > 1 && !S.chunk_days && gran8_ok) {
+        bool ok8 = true;
+        for (int r = 0; r < RX && ok8; ++r) ok8 = h->replica_day[r] == h->replica_day[r & ~7];
+        if (ok8) { S.chunk_days = 1; S.row_gran = 8; }
+    }
     // a map that mixes days inside aligned groups of 16 replicas: the replicas are STORED regrouped by day (see vds_handle),
     // every day's last group padded with dummy replicas, when the padding stays under a quarter; otherwise every 16-lane row
     // of the fast kernel gets its own order stream (day mode 2)
@@ -924,11 +933,18 @@ static int apply_replica_map(vds_handle *h) {
         std::vector<std::vector<int>> by_day(n_days);
         for (int r = 0; r < RX; ++r) by_day[h->replica_day[r]].push_back(r);
         std::vector<int> i2e;
-        for (int dd = 0; dd < n_days; ++dd) {
-            for (int r : by_day[dd]) { i2e.push_back(r); day_of_internal.push_back(dd); }
-            while (i2e.size() % 16) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // dummy: replays the empty day
+        int gran = 16;
+        for (int pass = 0; pass < 2; ++pass, gran = 8) {
+            i2e.clear(); day_of_internal.clear();
+            for (int dd = 0; dd < n_days; ++dd) {
+                for (int r : by_day[dd]) { i2e.push_back(r); day_of_internal.push_back(dd); }
+                while (i2e.size() % gran) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // dummy: replays the empty day
+            }
+            if (i2e.size() * 4 <= (size_t)RX * 5 || !gran8_ok) break;      // (too much padding with groups of 16: groups of 8)
         }
+        while (i2e.size() % 16) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // (the replica count stays a multiple of 16)
         if (i2e.size() * 4 <= (size_t)RX * 5) {
+            S.row_gran = gran > 8 ? 16 : 8;
             // (a handle that already stores more padded replicas keeps that many: the state tables are strided by S.R, and a map
             // whose padding differs by a group must not re-allocate them - vds_set_replica_days every episode)
             if (h->alloc_R > (int)i2e.size() && (size_t)h->alloc_R * 4 <= (size_t)RX * 5 && !h->state_allocs.empty())

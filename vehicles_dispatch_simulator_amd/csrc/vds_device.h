@@ -80,7 +80,9 @@ struct Static {
     int n_days;                      // 1: one order stream shared by every replica (the fast path of k_tick_rows)
     const int *rperm;                // [rslots] k_tick_rows row slot -> replica, grouped by order day in groups of 16 (-1 padding); null: identity
     int rslots;
-    int chunk_days;                  // n_days > 1 and every aligned group of 16 replicas (one k_tick_rows workgroup) replays one day
+    int chunk_days;                  // n_days > 1 and every aligned group of row_gran replicas (one workgroup of the fast kernels) replays one day
+    int row_gran;                    // 16; 8 on the dense layout when the days come in aligned groups of eight replicas (k_tick_dense with 8-row
+                                     // workgroups, round 5: eight replicas per day no longer mean one order stream per row)
     const DayDesc *day;              // [n_days]
     const int *replica_day;          // [R]
     const int4 *replica_desc;        // [R] {bkt_base, now0, T, q_base} of the replica's day: one load instead of replica_day -> day[]

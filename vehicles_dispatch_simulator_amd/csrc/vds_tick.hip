@@ -860,7 +860,9 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
     } else if (DM == 1) {
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
         const int r0 = (int)(chunk * ROWS_WAVES * 4);       // (a group's first slot is never padding)
-        const int4 dd = S.replica_desc[S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1)];
+        const int rd0 = S.rperm != nullptr ? S.rperm[min(r0, S.rslots - 1)] : min(r0, S.R - 1);
+        if (rd0 < 0) return;                         // a whole group of padding replicas (the tail of the regrouped storage)
+        const int4 dd = S.replica_desc[rd0];
         rowvalid = rowvalid && t < dd.z;             // (workgroup-uniform apart from r < R)
         q0 = 0; k = 0;
         if (t < dd.z) {                              // (past the day's last slot its bucket table must not be read: the last day's ends there)

@@ -918,7 +918,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS>
 __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
-    static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8), "32-row workgroups: one shared day, 8 lanes per replica");
+    static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8) || (ROWS == 8 && DM == 1 && LPR == 16),
+                  "32-row workgroups: one shared day, 8 lanes per replica; 8-row workgroups: one day per workgroup, 16 lanes per replica");
     const DenseArgs &S = P, &D = P;
 #ifdef VDS_PROF
     const int span_i = (((P.r_lo != 0 ? 1 : 0) * SPAN_TICKS + (t & (SPAN_TICKS - 1))) * SPAN_WAYS + (int)(blockIdx.x & (SPAN_WAYS - 1))) * 2;
@@ -993,6 +994,7 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
         // the workgroup's day: one descriptor for its 16 replicas (uniform address -> scalar loads)
         const int r0 = row0;                    // (a group's first slot is never padding)
         const int rd = S.rperm != nullptr ? S.rperm[r0] : min(r0, S.R - 1);
+        if (rd < 0) return;                     // a whole group of padding replicas (the tail of the regrouped storage): nothing to do
         const int4 dd = S.replica_desc[rd];
         rowvalid = rowvalid && t < dd.z;
         q0 = 0; k = 0;
@@ -1159,6 +1161,7 @@ static bool dense_tab256(const Static &S) { return S.dense_lpr == 16 && S.blk8s 
 template <bool PULL>
 static void emit_dense_256(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
     const dim3 block(DN_ROWS * 16);
+    if (S.n_days > 1 && S.chunk_days && S.row_gran == 8) { emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256, 8>, grid, dim3(8 * 16), lds, P, t); return; }
     if (S.n_days <= 1) emit_dense(e, k_tick_dense<true, 0, 16, PULL, 256>, grid, block, lds, P, t);
     else if (S.chunk_days) emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256>, grid, block, lds, P, t);
     else emit_dense(e, k_tick_dense<true, 2, 16, PULL, 256>, grid, block, lds, P, t);
@@ -1168,6 +1171,11 @@ template <int LPR, bool PULL>
 static void emit_dense_lpr(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
     const int dm = S.n_days <= 1 ? 0 : (S.chunk_days ? 1 : 2);
     const dim3 block(DN_ROWS * LPR);
+    if (LPR == 16 && dm == 1 && S.row_gran == 8) {      // day groups of eight replicas: 8-row workgroups
+        if (S.blk8s) emit_dense(e, k_tick_dense<true, 1, 16, PULL, DN_TAB, 8>, grid, dim3(8 * 16), lds, P, t);
+        else emit_dense(e, k_tick_dense<false, 1, 16, PULL, DN_TAB, 8>, grid, dim3(8 * 16), lds, P, t);
+        return;
+    }
     if (S.blk8s) emit_dense(e, dm == 2 ? k_tick_dense<true, 2, LPR, PULL> : (dm ? k_tick_dense<true, 1, LPR, PULL> : k_tick_dense<true, 0, LPR, PULL>), grid, block, lds, P, t);
     else emit_dense(e, dm == 2 ? k_tick_dense<false, 2, LPR, PULL> : (dm ? k_tick_dense<false, 1, LPR, PULL> : k_tick_dense<false, 0, LPR, PULL>), grid, block, lds, P, t);
 }
@@ -1189,7 +1197,8 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const bool t256 = dense_tab256(S);
     // 32-row workgroups: one shared day, 8 lanes per replica, byte costs, static arrival slots, at least 64 rows in the launch
     const bool rows32 = S.n_days <= 1 && S.dense_lpr == 8 && !t256 && S.blk8s != nullptr && S.pull && slots >= 64 && DN_ROWS32;
-    const int rows = rows32 ? 32 : DN_ROWS;
+    const bool rows8 = S.n_days > 1 && S.chunk_days && S.row_gran == 8 && S.dense_lpr == 16;
+    const int rows = rows32 ? 32 : (rows8 ? 8 : DN_ROWS);
     const int rchunks = (slots + rows - 1) / rows;
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
