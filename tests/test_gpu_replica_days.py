@@ -420,7 +420,8 @@ def test_replica_day_map_changes_every_episode_over_resident_days(name, R):
     if R == 40:
         # day groups of EIGHT replicas (the dense tick's 8-row workgroups): as given, and interleaved over five days - regrouped by
         # day in groups of eight (groups of sixteen would double the replicas) - then back to one stream per row and to blocks of 16
-        maps += [np.arange(R) // 8, np.arange(R) % 5, rng.integers(0, 5, size=R), (np.arange(R) // 8 + 2) % 5, np.minimum(np.arange(R) // 16, 3)]
+        maps += [np.arange(R) // 8, np.arange(R) % 5, rng.integers(0, 5, size=R), (np.arange(R) // 8 + 2) % 5, np.minimum(np.arange(R) // 16, 3),
+                 (np.arange(R) // 4) % 5, np.arange(R) % 5]       # (... and of four: one wavefront per workgroup)
     env.load_order_days(days, maps[0].astype(np.int32))
     expected = {}
     for ep, rd in enumerate(maps):

@@ -919,10 +919,10 @@ static int apply_replica_map(vds_handle *h) {
     S.chunk_days = n_days > 1 ? 1 : 0;
     for (int r = 0; r < RX && S.chunk_days; ++r)
         if (h->replica_day[r] != h->replica_day[r & ~15]) S.chunk_days = 0;
-    if (n_days > 1 && !S.chunk_days && gran8_ok) {
-        bool ok8 = true;
-        for (int r = 0; r < RX && ok8; ++r) ok8 = h->replica_day[r] == h->replica_day[r & ~7];
-        if (ok8) { S.chunk_days = 1; S.row_gran = 8; }
+    for (int gr = 8; gr >= 4 && n_days > 1 && !S.chunk_days && gran8_ok; gr >>= 1) {
+        bool okg = true;
+        for (int r = 0; r < RX && okg; ++r) okg = h->replica_day[r] == h->replica_day[r & ~(gr - 1)];
+        if (okg) { S.chunk_days = 1; S.row_gran = gr; }
     }
     // a map that mixes days inside aligned groups of 16 replicas: the replicas are STORED regrouped by day (see vds_handle),
     // every day's last group padded with dummy replicas, when the padding stays under a quarter; otherwise every 16-lane row
@@ -934,17 +934,17 @@ static int apply_replica_map(vds_handle *h) {
         for (int r = 0; r < RX; ++r) by_day[h->replica_day[r]].push_back(r);
         std::vector<int> i2e;
         int gran = 16;
-        for (int pass = 0; pass < 2; ++pass, gran = 8) {
+        for (int pass = 0; pass < 3; ++pass, gran >>= 1) {
             i2e.clear(); day_of_internal.clear();
             for (int dd = 0; dd < n_days; ++dd) {
                 for (int r : by_day[dd]) { i2e.push_back(r); day_of_internal.push_back(dd); }
                 while (i2e.size() % gran) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // dummy: replays the empty day
             }
-            if (i2e.size() * 4 <= (size_t)RX * 5 || !gran8_ok) break;      // (too much padding with groups of 16: groups of 8)
+            if (i2e.size() * 4 <= (size_t)RX * 5 || !gran8_ok) break;      // (too much padding with groups of 16: groups of 8, then of 4)
         }
         while (i2e.size() % 16) { i2e.push_back(-1); day_of_internal.push_back(n_days); }      // (the replica count stays a multiple of 16)
         if (i2e.size() * 4 <= (size_t)RX * 5) {
-            S.row_gran = gran > 8 ? 16 : 8;
+            S.row_gran = gran >= 16 ? 16 : (gran >= 8 ? 8 : 4);
             // (a handle that already stores more padded replicas keeps that many: the state tables are strided by S.R, and a map
             // whose padding differs by a group must not re-allocate them - vds_set_replica_days every episode)
             if (h->alloc_R > (int)i2e.size() && (size_t)h->alloc_R * 4 <= (size_t)RX * 5 && !h->state_allocs.empty())

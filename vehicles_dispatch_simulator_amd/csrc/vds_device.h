@@ -81,7 +81,7 @@ struct Static {
     const int *rperm;                // [rslots] k_tick_rows row slot -> replica, grouped by order day in groups of 16 (-1 padding); null: identity
     int rslots;
     int chunk_days;                  // n_days > 1 and every aligned group of row_gran replicas (one workgroup of the fast kernels) replays one day
-    int row_gran;                    // 16; 8 on the dense layout when the days come in aligned groups of eight replicas (k_tick_dense with 8-row
+    int row_gran;                    // 16; 8 / 4 on the dense layout when the days come in aligned groups of eight / four replicas (k_tick_dense with 8- / 4-row
                                      // workgroups, round 5: eight replicas per day no longer mean one order stream per row)
     const DayDesc *day;              // [n_days]
     const int *replica_day;          // [R]

@@ -918,8 +918,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS>
 __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
-    static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8) || (ROWS == 8 && DM == 1 && LPR == 16),
-                  "32-row workgroups: one shared day, 8 lanes per replica; 8-row workgroups: one day per workgroup, 16 lanes per replica");
+    static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8) || ((ROWS == 8 || ROWS == 4) && DM == 1 && LPR == 16),
+                  "32-row workgroups: one shared day, 8 lanes per replica; 8- / 4-row workgroups: one day per workgroup, 16 lanes per replica");
     const DenseArgs &S = P, &D = P;
 #ifdef VDS_PROF
     const int span_i = (((P.r_lo != 0 ? 1 : 0) * SPAN_TICKS + (t & (SPAN_TICKS - 1))) * SPAN_WAYS + (int)(blockIdx.x & (SPAN_WAYS - 1))) * 2;
@@ -1107,6 +1107,8 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
         if (mine) { lds_rec[threadIdx.x] = srec; if (PULL) lds_slot[threadIdx.x] = sslot; }
     }
     if (dmine) lds_drec[threadIdx.x] = sdrec;
+    if (NTHR < DN_CAND && PULL && DM != 2 && wg_ok)          // (4-row workgroups: more candidates than threads)
+        for (int i = threadIdx.x + NTHR; i < n; i += NTHR) lds_drec[i] = S.d_rec[clo + i];
     PROF_STAMP(0);          // scalar loads, header words, candidate entries, staging loads: all arrived
     __syncthreads();
     PROF_STAMP_NW(1);       // barrier
@@ -1162,6 +1164,7 @@ template <bool PULL>
 static void emit_dense_256(const Emit &e, const Static &S, const DenseArgs &P, int t, dim3 grid, size_t lds) {
     const dim3 block(DN_ROWS * 16);
     if (S.n_days > 1 && S.chunk_days && S.row_gran == 8) { emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256, 8>, grid, dim3(8 * 16), lds, P, t); return; }
+    if (S.n_days > 1 && S.chunk_days && S.row_gran == 4) { emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256, 4>, grid, dim3(4 * 16), lds, P, t); return; }
     if (S.n_days <= 1) emit_dense(e, k_tick_dense<true, 0, 16, PULL, 256>, grid, block, lds, P, t);
     else if (S.chunk_days) emit_dense(e, k_tick_dense<true, 1, 16, PULL, 256>, grid, block, lds, P, t);
     else emit_dense(e, k_tick_dense<true, 2, 16, PULL, 256>, grid, block, lds, P, t);
@@ -1174,6 +1177,11 @@ static void emit_dense_lpr(const Emit &e, const Static &S, const DenseArgs &P, i
     if (LPR == 16 && dm == 1 && S.row_gran == 8) {      // day groups of eight replicas: 8-row workgroups
         if (S.blk8s) emit_dense(e, k_tick_dense<true, 1, 16, PULL, DN_TAB, 8>, grid, dim3(8 * 16), lds, P, t);
         else emit_dense(e, k_tick_dense<false, 1, 16, PULL, DN_TAB, 8>, grid, dim3(8 * 16), lds, P, t);
+        return;
+    }
+    if (LPR == 16 && dm == 1 && S.row_gran == 4) {      // ... of four: one wavefront per workgroup
+        if (S.blk8s) emit_dense(e, k_tick_dense<true, 1, 16, PULL, DN_TAB, 4>, grid, dim3(4 * 16), lds, P, t);
+        else emit_dense(e, k_tick_dense<false, 1, 16, PULL, DN_TAB, 4>, grid, dim3(4 * 16), lds, P, t);
         return;
     }
     if (S.blk8s) emit_dense(e, dm == 2 ? k_tick_dense<true, 2, LPR, PULL> : (dm ? k_tick_dense<true, 1, LPR, PULL> : k_tick_dense<true, 0, LPR, PULL>), grid, block, lds, P, t);
@@ -1197,8 +1205,8 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const bool t256 = dense_tab256(S);
     // 32-row workgroups: one shared day, 8 lanes per replica, byte costs, static arrival slots, at least 64 rows in the launch
     const bool rows32 = S.n_days <= 1 && S.dense_lpr == 8 && !t256 && S.blk8s != nullptr && S.pull && slots >= 64 && DN_ROWS32;
-    const bool rows8 = S.n_days > 1 && S.chunk_days && S.row_gran == 8 && S.dense_lpr == 16;
-    const int rows = rows32 ? 32 : (rows8 ? 8 : DN_ROWS);
+    const bool rows8 = S.n_days > 1 && S.chunk_days && S.row_gran < 16 && S.dense_lpr == 16;
+    const int rows = rows32 ? 32 : (rows8 ? S.row_gran : DN_ROWS);
     const int rchunks = (slots + rows - 1) / rows;
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
