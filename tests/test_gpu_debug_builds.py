@@ -90,7 +90,7 @@ def test_guarded_build_replica_days_and_dispatch():
     env = dict(os.environ, VDS_LIB=lib)
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_replica_days.py"),
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
-                        "(replica and not full_size) or tiny_dispatch-fast or tiny_dispatch-generic or tiny_dispatch-dense16 or tiny_dispatch-dense_tiny or tiny_dispatch_dfs2-fast or device_resident or (burst and (fast or dense16))"],
+                        "(replica and not full_size and not full_tables) or tiny_dispatch-fast or tiny_dispatch-generic or tiny_dispatch-dense16 or tiny_dispatch-dense_tiny or tiny_dispatch_dfs2-fast or device_resident or (burst and (fast or dense16))"],
                        env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
 

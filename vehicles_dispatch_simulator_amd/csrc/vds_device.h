@@ -5,7 +5,7 @@
 // replicas, so the cluster's cost block sits in LDS once and every bucket access is a
 // contiguous, coalesced segment.
 //
-//   hdr      [C][R][8]           int32  bucket header (HDR_* below)
+//   hdr      [C][R][16]          int32  bucket header (HDR_* below) + 32-bit partial counters of the dense fast path
 //   cnt      [C][R][8]           int64  bucket-owned partial counters (no atomics; reduced on read)
 //   idle     [C][R][idle_cap]    {veh, loc_local}   Cluster.IdleVehicles, kept in LIST ORDER
 //   ring     [H][C][R][ring_cap] arrival entries indexed by ARRIVAL TICK mod H: the in-flight part of
@@ -30,7 +30,12 @@ enum {
     HDR_FL = 3,         // far list fill
     HDR_INBOX0 = 4,     // far inbox fill, parity 0 (atomic target of other buckets)
     HDR_INBOX1 = 5,     // far inbox fill, parity 1
-    HDR_WORDS = 8
+    // words 8 .. 13: 32-bit partial counters (CNT_ORDERS .. CNT_ARRIVALS) of the dense tick's byte-cost fast path (round 5): the bucket's
+    // header and its counters are ONE 64-byte record - one read request and one write request per bucket and tick instead of two
+    // each (header 32 B + counters 64 B).  Per tick a bucket adds at most 64 orders x 256 candidates / 254 minutes, a day has at most
+    // 65 535 slots: the sums stay below 2^31.  Every other path adds to the 64-bit table `cnt`; k_reduce_counters sums both.
+    HDR_CNT32 = 8,
+    HDR_WORDS = 16
 };
 
 enum {

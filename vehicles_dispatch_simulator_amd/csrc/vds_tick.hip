@@ -113,7 +113,7 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_fast(Static S, Sta
         const size_t b = (size_t)c * S.R + r;
         int4 *h4 = reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS);
         h4[0] = make_int4(total, 0, 0, 0);
-        h4[1] = make_int4(0, 0, 0, 0);
+        h4[1] = make_int4(0, 0, 0, 0); h4[2] = make_int4(0, 0, 0, 0); h4[3] = make_int4(0, 0, 0, 0);
         int4 *c4 = reinterpret_cast<int4 *>(D.cnt + b * CNT_WORDS);
         c4[0] = make_int4(0, 0, 0, 0); c4[1] = make_int4(0, 0, 0, 0); c4[2] = make_int4(0, 0, 0, 0); c4[3] = make_int4(0, 0, 0, 0);
     }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_staged(Static S, S
         const size_t b = (size_t)c * S.R + r;
         int4 *h4 = reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS);
         h4[0] = make_int4(total, 0, 0, 0);
-        h4[1] = make_int4(0, 0, 0, 0);
+        h4[1] = make_int4(0, 0, 0, 0); h4[2] = make_int4(0, 0, 0, 0); h4[3] = make_int4(0, 0, 0, 0);
         int4 *c4 = reinterpret_cast<int4 *>(D.cnt + b * CNT_WORDS);
         c4[0] = make_int4(0, 0, 0, 0); c4[1] = make_int4(0, 0, 0, 0); c4[2] = make_int4(0, 0, 0, 0); c4[3] = make_int4(0, 0, 0, 0);
     }
@@ -1210,6 +1210,18 @@ __global__ __launch_bounds__(256) void k_reduce_counters(Static S, State D, long
             s += (a0 + a1) + (a2 + a3);
         }
         for (; c < c1; ++c) s += p[(size_t)c * stride];
+        // the dense fast path's 32-bit partial counters in the bucket headers (HDR_CNT32)
+        const int w = i % CNT_WORDS, rr = i / CNT_WORDS;
+        if (w < 6) {
+            const int *hp = D.hdr + (size_t)rr * HDR_WORDS + HDR_CNT32 + w;
+            const size_t hs = (size_t)S.R * HDR_WORDS;
+            int cc = c0;
+            for (; cc + 4 <= c1; cc += 4) {
+                const int b0 = hp[(size_t)cc * hs], b1 = hp[(size_t)(cc + 1) * hs], b2 = hp[(size_t)(cc + 2) * hs], b3 = hp[(size_t)(cc + 3) * hs];
+                s += ((long long)b0 + b1) + ((long long)b2 + b3);
+            }
+            for (; cc < c1; ++cc) s += hp[(size_t)cc * hs];
+        }
     }
     part[slice][threadIdx.x & 63] = s;
     __syncthreads();

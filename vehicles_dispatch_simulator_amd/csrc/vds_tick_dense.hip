@@ -626,6 +626,19 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
     }
 }
 
+// The same with the bucket's header and its counters as ONE 64-byte record (HDR_CNT32, byte costs): lane lg < 8 of the group holds words
+// 2 lg, 2 lg + 1 as loaded by the prologue (hw); lanes 0 / 1 take the header words, lanes 4 .. 6 add the slot's deltas to the 32-bit
+// counters, and the five lanes store their pairs with one instruction.  Lane 2's words - the far inboxes other buckets add to
+// atomically - and the spare pairs are not written.
+__device__ __forceinline__ void store_record(int *hdr, int lg, int2 hw, int idle, int pre, int orders, int rej, int wsum, int vsum, int evals, int A) {
+    if (lg == 0) hw = make_int2(idle, pre);
+    if (lg == 1) hw.x = orders;
+    if (lg == 4) { hw.x += orders; hw.y += rej; }
+    if (lg == 5) { hw.x += wsum; hw.y += vsum; }
+    if (lg == 6) { hw.x += evals; hw.y += A; }
+    if (lg < 2 || (lg >= 4 && lg < 7)) *reinterpret_cast<int2 *>(hdr + 2 * lg) = hw;
+}
+
 // Fast path body, specialised on the group width LPR and the table size TS (J = TS / LPR slots per lane).
 //   tab     the row's LDS table (DN_TAB u32): arrival keys during the ranking, then the merged list, then the packed survivors
 // Timing-only ablation switches of the instrumented build (make prof; vds_debug_ablate - results INVALID when non-zero):
@@ -648,8 +661,9 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 template <int LPR, int TS, typename CT, int DM, bool PULL>
 __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &D, int t, int now, int q0, int k, int kmax, int qb, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, const unsigned short *pick, unsigned *tab, int r, bool rowvalid, size_t b, size_t si,
-                                           int m, int A, long long cntv, int n, int Aring, const int2 *lds_drec, const int *lds_slot, bool prof, unsigned long long tprev, int pwave) {
+                                           int m, int A, long long cntv, int2 hw, int n, int Aring, const int2 *lds_drec, const int *lds_slot, bool prof, unsigned long long tprev, int pwave) {
     constexpr int J = TS / LPR;                 // slots per lane
+    constexpr bool REC = sizeof(CT) == 1;       // header + counters as one record (store_record)
     constexpr int NL = (J + 3) / 4;             // packed loc registers
     constexpr int NG = DN_ORDERS / LPR;         // result registers (orders jj * LPR + lg)
     constexpr int DEAD = sizeof(CT) == 1 ? 0xFF : DENSE_DEAD_COST;
@@ -700,8 +714,11 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             }
         }
         if (rowvalid) {
-            if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_ORDERS ? 0 : mnew;
-            if (A > 0) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, 0, 0, 0, 0, 0, A);
+            if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mnew, mnew, 0, 0, 0, 0, 0, A);
+            else {
+                if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_ORDERS ? 0 : mnew;
+                if (A > 0) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, 0, 0, 0, 0, 0, A);
+            }
         }
         return;
     }
@@ -884,8 +901,11 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     rej = grp_sum<LPR>(rej);
     // 8. header, counters
     if (rowvalid && !(abl & 16)) {
-        if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_IDLE ? mfin : (lg == HDR_IDLE_PRE ? mnew : k);
-        if (!(abl & 32768)) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, k, rej, wsum, vsum, evals, A);
+        if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mfin, mnew, k, rej, wsum, vsum, evals, A);
+        else {
+            if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_IDLE ? mfin : (lg == HDR_IDLE_PRE ? mnew : k);
+            if (!(abl & 32768)) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, k, rej, wsum, vsum, evals, A);
+        }
     }
     PROF_STAMP(8);          // results, arrival slots, header, counters
 }
@@ -1031,11 +1051,15 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     long long cntv = 0;
     int4 h0 = make_int4(0, 0, 0, 0);
     int hin = 0, rcw = 0;
+    int2 hw = make_int2(0, 0);           // (byte costs) words 2 lg, 2 lg + 1 of the bucket's 64-byte record: header + 32-bit counters
     if (rowvalid) {
-        h0 = *reinterpret_cast<const int4 *>(D.hdr + b * HDR_WORDS);
-        hin = D.hdr[b * HDR_WORDS + HDR_INBOX0 + p];
+        if (U8) { if (lg < 8) hw = *reinterpret_cast<const int2 *>(D.hdr + b * HDR_WORDS + 2 * lg); }
+        else {
+            h0 = *reinterpret_cast<const int4 *>(D.hdr + b * HDR_WORDS);
+            hin = D.hdr[b * HDR_WORDS + HDR_INBOX0 + p];
+            if (LPR >= CNT_WORDS && lg < CNT_WORDS && !(DN_ABL & 131072)) cntv = D.cnt[b * CNT_WORDS + lg];
+        }
         rcw = D.ring_cnt[si];            // (the raw word: masking it HERE made the compiler wait for it before the loads below went out)
-        if (LPR >= CNT_WORDS && lg < CNT_WORDS && !(DN_ABL & 131072)) cntv = D.cnt[b * CNT_WORDS + lg];
     }
     const char *blk_g = S.blk + cd.y;
     const int4 *blk4 = reinterpret_cast<const int4 *>(blk_g);
@@ -1087,8 +1111,15 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     asm volatile("" : "+v"(rcw));       // (keeps the mask below out of the branch that issued the load: there it would wait for the word)
     int Aring = rcw & 0xFFFF;
     A = Aring + Ac;           // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
-    m = h0.x;
-    far = h0.w | hin;
+    if (U8) {
+        // the record's words through the LDS crossbar: idle length (word 0), far list fill (3), this slot's far inbox (4 + p)
+        const int gb = (lane & ~(LPR - 1)) << 2;
+        m = __builtin_amdgcn_ds_bpermute(gb, hw.x);
+        far = __builtin_amdgcn_ds_bpermute(gb + 4, hw.y) | __builtin_amdgcn_ds_bpermute(gb + 8, p ? hw.y : hw.x);
+    } else {
+        m = h0.x;
+        far = h0.w | hin;
+    }
     if (DN_ABL & 256) { if (m + far + A + (int)cntv == 0x7FFFFFF1) D.err[1] = 1; return; }
     // 2. the staged pieces into LDS: the cluster's cost block (what is left of it: blocks beyond one 16-byte piece per thread), the
     //    bucket's order records and - PULL - the candidates' static records
@@ -1133,10 +1164,10 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
         const int kr = (DM == 2 && !rowvalid) ? 0 : k;
         const int kmax = DM == 2 ? wave_max_of_groups<LPR>(kr) : k;
         const int2 *drec = DM == 2 ? drec_row : lds_drec;
-        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
-        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
-        else if (TABMAX <= 128 || mmax <= 128) dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
-        else dense_body<LPR, (TABMAX > 128 ? 256 : 128), CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else if (TABMAX <= 128 || mmax <= 128) dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else dense_body<LPR, (TABMAX > 128 ? 256 : 128), CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
