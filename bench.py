@@ -333,6 +333,14 @@ def main():
                                        "cycles_per_valu_inst": lim["cycles_per_valu_inst"],
                                        "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source"),
                                        "build": lim.get("build"), "build_matches": (lim.get("build") or "").split("+")[0] == build_id.split("+")[0]}
+                # `bound` names what the counters say limits the kernel: when the VALU floor is a larger share of the launch than the
+                # HBM bytes are, the kernel is bound by instruction issue (index / compare / select work on wave64 VALUs, no MFMA);
+                # achieved / peak / frac stay the HBM figures the contract asks for (how far below the memory roof the kernel runs)
+                if roofline["limiter"]["valu_frac"] > roofline["frac"]:
+                    roofline["bound"] = "valu-issue"
+                    roofline["bound_note"] = ("VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) = %.0f %% of the launch (limiter.valu_frac) vs "
+                                              "HBM bytes / 8 TB/s = %.0f %% (frac): instruction issue bounds this kernel, not HBM and not MFMA (no GEMM-shaped work); "
+                                              "achieved / peak / frac are the HBM figures" % (100 * roofline["limiter"]["valu_frac"], 100 * roofline["frac"]))
 
     # ---- per-replica order days (rank 0, N = 1): the headline replays ONE day in every replica, which lets 16 replicas
     #      share staged order records and keeps per-order control flow wave-uniform.  The same workload with D distinct
