@@ -547,7 +547,7 @@ def main():
     #      the device per episode (vds_reset_random: one random.Random(seed) stream per replica, the reference's InitVehiclesIntoCluster
     #      draws bit for bit), generated on the host and uploaded (vds_reset: what an RL loop with fresh start nodes paid before)
     episode_reset = None
-    if rank == 0 and world == 1 and a.hooked and a.workload == "cfg2":
+    if rank == 0 and world == 1 and a.hooked and a.workload in ("cfg2", "cfg5"):
         try:
             def tm(f, n):
                 f(); env.sync()

@@ -362,6 +362,57 @@ def test_reset_builds_the_same_lists_staged_and_unstaged(shape, fg, monkeypatch)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("fg", [0, 5])
+def test_reset_again_of_a_city_too_large_for_the_staged_reset_copies_the_list_image(fg, monkeypatch):
+    """configs[4]'s reset form at a test size: 30 000 vehicles in 37 clusters do not fit k_reset_staged's LDS.  On the dense layout
+    (force_generic 0) the first reset (k_reset_fast) leaves a packed image of the lists (k_reset_capture) and vds_reset_again copies
+    it back (k_reset_image); new start nodes and another idle capacity make the image stale.  Lists against
+    numpy after every reset; the days against the ones of k_reset_fast alone (VDS_RESET_UNSTAGED=1, and the wide layout)."""
+    from vehicles_dispatch_simulator_amd import workloads
+    N, Cn, V, R = 700, 37, 30000, 2
+    w = workloads.tiny(N=N, C=Cn, vehicles=V, orders=1500, seed=5)
+    init = w.vehicle_nodes(R)
+    init_b = w.vehicle_nodes(R, first_replica=7)
+    n2c = np.asarray(w.city.node2cluster)
+
+    def check_lists(env, nodes):
+        for r in range(R):
+            ls = env.lists(r)
+            cl = n2c[nodes[r]]
+            for c in range(Cn):
+                exp = np.nonzero(cl == c)[0]
+                a, b = ls["idle_off"][c], ls["idle_off"][c + 1]
+                np.testing.assert_array_equal(ls["idle_veh"][a:b], exp, err_msg="replica %d cluster %d" % (r, c))
+                np.testing.assert_array_equal(ls["idle_node"][a:b], nodes[r][exp])
+
+    outs = []
+    for unstaged in ("0", "1"):
+        monkeypatch.setenv("VDS_RESET_UNSTAGED", unstaged)
+        env = w.make_env(R, force_generic=fg)
+        res = []
+        env.reset(init); check_lists(env, init)
+        env.run(env.T); res.append((env.orders(), env.counters().copy()))
+        env.reset_again(); check_lists(env, init)                  # (the image, where the form applies)
+        env.run(env.T); res.append((env.orders(), env.counters().copy()))
+        env.reset_again(); env.run(env.T // 2)
+        env.reset(init_b); check_lists(env, init_b)                # new start nodes: sorted again, a new image
+        env.reset_again(); check_lists(env, init_b)
+        env.run(env.T); res.append((env.orders(), env.counters().copy()))
+        env.set_idle_cap(env.idle_cap + 64)
+        env.reset_again(); check_lists(env, init_b)                # other idle tables: not the old image
+        env.run(env.T); res.append((env.orders(), env.counters().copy()))
+        outs.append(res)
+        env.close()
+    for a, b in zip(outs[0], outs[1]):
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(a[0][k], b[0][k])
+        np.testing.assert_array_equal(a[1], b[1])
+    for res in outs:                                               # same nodes, same day: same results
+        for k in ("status", "vehicle", "wait"):
+            np.testing.assert_array_equal(res[0][0][k], res[1][0][k])
+            np.testing.assert_array_equal(res[2][0][k], res[3][0][k])
+
+
 @pytest.mark.parametrize("shape", [(300, 12, 150, 5), (4139, 192, 3000, 4), (4096, 40, 700, 3), (1, 1, 40, 2), (257, 9, 1, 3)])
 def test_reset_random_draws_the_reference_start_nodes_on_the_device(shape):
     """vds_reset_random: InitVehiclesIntoCluster (:249-258) with `random.Random(seed_r)` per replica, drawn by a device MT19937 -

@@ -21,6 +21,9 @@
 
 namespace vds {
 void launch_reset(const Static &, const State &, const int *, hipStream_t);
+bool reset_uses_image(const Static &);
+void launch_reset_capture(const Static &, const State &, unsigned *, int *, hipStream_t);
+void launch_reset_image(const Static &, const State &, const unsigned *, const int *, hipStream_t);
 void launch_py_random_nodes(const unsigned long long *, int, int, int, int, const int *, int *, int *, hipStream_t);      // vds_random.hip
 void launch_start_nodes_check(const int *, int, int, int, int, const int *, int *, unsigned long long *, hipStream_t);
 void launch_tick_main(const Static &, const State &, int, int, hipStream_t);
@@ -133,6 +136,11 @@ struct vds_handle {
     int *d_veh_node = nullptr;
     unsigned long long *d_seeds = nullptr;   // vds_reset_random: the replicas' seeds, the fullest start list per replica
     int *d_fullest = nullptr;
+    // the lists of the last reset as a packed image (cities too large for the staged reset kernel: vds_tick.hip, k_reset_image),
+    // valid while the start nodes (veh_gen) and the tables (tables_gen) are the ones it was taken from
+    unsigned *d_reset_img = nullptr; int *d_reset_base = nullptr;
+    size_t reset_img_words = 0, reset_base_words = 0;
+    unsigned veh_gen = 0, img_veh_gen = 0, img_tables_gen = 0; bool img_valid = false;
     int *d_veh_stage = nullptr;              // vds_reset: the caller's start nodes land here and are checked on the device before they
     unsigned long long *d_bad = nullptr;     // replace d_veh_node (index of the first node outside every cluster, ~0 if none)
     int *d_obs = nullptr;
@@ -1489,7 +1497,32 @@ static int reset_device(vds_handle *h) {
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
     // D.out needs no clearing: every processed order's slot is written (match or reject) before
     // vds_read_orders may look at it (it only reads orders whose tick has been stepped)
-    launch_reset(S, h->D, h->d_veh_node, h->stream);
+    if (reset_uses_image(S)) {
+        const size_t iw = (size_t)S.R * S.V, bw = (size_t)S.R * (S.C + 1);
+        if (h->reset_img_words < iw || h->reset_base_words < bw) {
+            // (plain allocations owned by the handle: they outlive a re-load of the order tables)
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for (void *old : {(void *)h->d_reset_img, (void *)h->d_reset_base})
+                if (old) { h->dev_allocs.erase(std::remove(h->dev_allocs.begin(), h->dev_allocs.end(), old), h->dev_allocs.end()); dev_free(old); }
+            h->d_reset_img = nullptr; h->d_reset_base = nullptr;
+            h->reset_img_words = h->reset_base_words = 0; h->img_valid = false;
+            std::vector<void *> *sink = h->alloc_sink; h->alloc_sink = nullptr;
+            int rc = dev_alloc(h, &h->d_reset_img, iw);
+            if (!rc) rc = dev_alloc(h, &h->d_reset_base, bw);
+            h->alloc_sink = sink;
+            if (rc) return rc;
+            h->reset_img_words = iw; h->reset_base_words = bw;
+        }
+        if (h->img_valid && h->img_veh_gen == h->veh_gen && h->img_tables_gen == h->tables_gen) {
+            launch_reset_image(S, h->D, h->d_reset_img, h->d_reset_base, h->stream);
+        } else {
+            launch_reset(S, h->D, h->d_veh_node, h->stream);
+            launch_reset_capture(S, h->D, h->d_reset_img, h->d_reset_base, h->stream);
+            h->img_valid = true; h->img_veh_gen = h->veh_gen; h->img_tables_gen = h->tables_gen;
+        }
+    } else {
+        launch_reset(S, h->D, h->d_veh_node, h->stream);
+    }
     HIPCHK(h, hipGetLastError());
     h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
     h->have_reset = true;
@@ -1562,6 +1595,7 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
         }
         // (a copy, not a pointer swap: d_veh_node belongs to the state tables, which a later vds_load_orders* re-allocates)
         HIPCHK(h, hipMemcpyAsync(h->d_veh_node, h->d_veh_stage, n * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        h->veh_gen++;
         if ((rc0 = reset_device(h))) return rc0;
         return vds_sync(h);
     }
@@ -1587,6 +1621,7 @@ static int reset_impl(vds_handle *h, const int32_t *veh_init_node) {
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_veh_node, veh_init_node, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->veh_gen++;
     int rc = reset_device(h);
     if (rc) return rc;
     return vds_sync(h);   // veh_init_node is caller-owned: do not retain it; also reports idle_cap overflow
@@ -1623,6 +1658,7 @@ static int reset_random_impl(vds_handle *h, const uint64_t *seeds) {
         if (want > S.idle_cap && (rc = set_idle_cap_impl(h, want))) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->d_veh_node, h->d_veh_stage, (size_t)h->R_ext * S.V * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    h->veh_gen++;
     if ((rc = reset_device(h))) return rc;
     return vds_sync(h);
 }

@@ -252,6 +252,79 @@ __global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_staged(Static S, S
         }
     }
 }
+// Cities whose lists do not fit k_reset_staged's LDS (configs[4]: V = 100 000, C = 2048) keep k_reset_fast for NEW start nodes -
+// one 32-byte write request per vehicle (PMC: 523 MB written for 76 MB of lists and headers; splitting the clusters of a replica
+// over eight staging workgroups was 2.6 x slower, every workgroup has to rank all vehicles: profiles/r05/reset_split_experiment.patch).
+// The episode reset of the SAME start nodes (vds_reset_again: what an episode loop calls) does not sort again: k_reset_capture
+// keeps the lists k_reset_fast built as one packed image per replica (entries in list order, `base` = first entry of every
+// cluster), k_reset_image copies it back as runs and clears headers and counters.  Dense layout (one word per entry) only.
+#define RESET_IMG_SPLIT 8
+__global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_capture(Static S, State D, unsigned *img, int *base) {
+    extern __shared__ int lds_dyn[];                    // [C + 1]
+    const int r = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const int C = S.C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) lds_dyn[c] = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
+    __syncthreads();
+    if (wave == 0) {            // exclusive prefix of the list lengths
+        int run = 0;
+        for (int cb = 0; cb < C; cb += WAVE) {
+            const int c = cb + lane;
+            const int v = c < C ? lds_dyn[c] : 0;
+            int inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+            if (c < C) lds_dyn[c] = run + inc - v;
+            run += rdlane(inc, WAVE - 1);
+        }
+        if (lane == 0) lds_dyn[C] = run;
+    }
+    __syncthreads();
+    int *bs = base + (size_t)r * (C + 1);
+    for (int c = threadIdx.x; c <= C; c += blockDim.x) bs[c] = lds_dyn[c];
+    unsigned *im = img + (size_t)r * S.V;
+    for (int c = wave; c < C; c += RESET_WAVES) {
+        const int b0 = lds_dyn[c], n = lds_dyn[c + 1] - b0;
+        const unsigned *src = reinterpret_cast<const unsigned *>(D.idle) + ((size_t)c * S.R + r) * S.idle_cap;
+        for (int i = lane; i < n; i += WAVE) im[b0 + i] = src[i];
+    }
+}
+__global__ __launch_bounds__(RESET_WAVES * WAVE) void k_reset_image(Static S, State D, const unsigned *img, const int *base) {
+    const int r = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const int C = S.C;
+    const int per = (C + RESET_IMG_SPLIT - 1) / RESET_IMG_SPLIT;
+    const int c_lo = blockIdx.y * per, c_hi = min(C, c_lo + per);
+    const int *bs = base + (size_t)r * (C + 1);
+    const unsigned *im = img + (size_t)r * S.V;
+    // headers and counters of the range: {m, 0 ...} and zeros (as the reset kernels write them)
+    for (int c = c_lo + (int)threadIdx.x; c < c_hi; c += blockDim.x) {
+        const int total = bs[c + 1] - bs[c];
+        const size_t b = (size_t)c * S.R + r;
+        int4 *h4 = reinterpret_cast<int4 *>(D.hdr + b * HDR_WORDS);
+        h4[0] = make_int4(total, 0, 0, 0);
+        h4[1] = make_int4(0, 0, 0, 0); h4[2] = make_int4(0, 0, 0, 0); h4[3] = make_int4(0, 0, 0, 0);
+        int4 *c4 = reinterpret_cast<int4 *>(D.cnt + b * CNT_WORDS);
+        c4[0] = make_int4(0, 0, 0, 0); c4[1] = make_int4(0, 0, 0, 0); c4[2] = make_int4(0, 0, 0, 0); c4[3] = make_int4(0, 0, 0, 0);
+    }
+    // the lists as runs: one wavefront per list, four lists' loads in flight
+    for (int c0 = c_lo + wave * 4; c0 < c_hi; c0 += RESET_WAVES * 4) {
+        int b0[4], n[4];
+        unsigned e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + u, c_hi - 1);
+            b0[u] = bs[c]; n[u] = (c0 + u < c_hi) ? bs[c + 1] - b0[u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = lane < n[u] ? im[b0[u] + lane] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned *dst = reinterpret_cast<unsigned *>(D.idle) + ((size_t)(c0 + u) * S.R + r) * S.idle_cap;
+            if (lane < n[u]) dst[lane] = e[u];
+            for (int i = WAVE + lane; i < n[u]; i += WAVE) dst[i] = im[b0[u] + i];
+        }
+    }
+}
 // ---------------------------------------------------------------------------------------
 // Generic match phase of one bucket (own-cluster scan, :924-965).  Lane l holds idle positions
 // l*J .. l*J+J-1, so "lowest position" == "lowest lane, then lowest slot".
@@ -1359,6 +1432,17 @@ __global__ __launch_bounds__(64) void k_dispatch_dense(Static S, State D, int t,
 static bool reset_unstaged() {           // VDS_RESET_UNSTAGED=1: k_reset_fast everywhere (A/B, tests of both forms; read per call)
     const char *e = getenv("VDS_RESET_UNSTAGED");
     return e && e[0] == '1';
+}
+// the reset keeps an image of the lists (k_reset_capture / k_reset_image): dense layout, lists too long for k_reset_staged
+bool reset_uses_image(const Static &S) {
+    const size_t staged = ((size_t)(RESET_WAVES + 1) * S.C + 1 + (size_t)S.V) * sizeof(int);
+    return S.dense && S.C <= 2048 && staged > (size_t)RESET_STAGED_MAX_LDS && !reset_unstaged();
+}
+void launch_reset_capture(const Static &S, const State &D, unsigned *img, int *base, hipStream_t st) {
+    hipLaunchKernelGGL(k_reset_capture, dim3(S.R), dim3(RESET_WAVES * WAVE), (size_t)(S.C + 1) * sizeof(int), st, S, D, img, base);
+}
+void launch_reset_image(const Static &S, const State &D, const unsigned *img, const int *base, hipStream_t st) {
+    hipLaunchKernelGGL(k_reset_image, dim3(S.R, RESET_IMG_SPLIT), dim3(RESET_WAVES * WAVE), 0, st, S, D, img, base);
 }
 void launch_reset(const Static &S, const State &D, const int *veh_node, hipStream_t st) {
     // the staged form while its LDS image of the lists fits (together with the counters) in 96 KB - configs[0] - [3]
