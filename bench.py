@@ -472,8 +472,41 @@ def main():
         except Exception as e:       # (a reported extra)
             graph_error = repr(e)
 
+        # the same with the observations read IN PLACE (vds_obs_inplace: idle_now / cl_orders are words of the bucket records, strided
+        # views - no k_pack_obs per slot; a policy that does not need SupplyExpect): surplus = idle - demand
+        pol_inplace, inplace_error = None, None
+        try:
+            views = env.obs_inplace_torch()
+
+            def policy_inplace():
+                idle, demand = views["idle_now"], views["cl_orders"]
+                surplus = idle - demand
+                src = torch.topk(surplus, K, dim=1).indices
+                dst = torch.topk(surplus, K, dim=1, largest=False).indices
+                ok = (idle.gather(1, src) > 0) & (surplus.gather(1, src) - surplus.gather(1, dst) > 4)
+                return torch.stack([torch.where(ok, src.int(), minus1), zeros_k, some_node_of[dst]], dim=2).contiguous()
+
+            side = torch.cuda.Stream()
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    actions_static.copy_(policy_inplace())
+            stream.wait_stream(side)
+            torch.cuda.synchronize()
+            pol_inplace = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(pol_inplace):
+                actions_static.copy_(policy_inplace())
+        except Exception as e:       # (a reported extra)
+            inplace_error = repr(e)
+
         def hooked_day(kind):
             env.reset_again()
+            if kind == "fixed_day_graph_inplace":         # tick -> k_dispatch_dense per slot: no observation pass
+                env.run_hooked(T, actions=fixed_both, idle_pre=False, idle_now=False, supply=False, cl_orders=False, inflight=False)
+                return
+            if kind == "policy_day_graph_inplace":
+                env.run_hooked(T, actions=actions_static, policy_graph=pol_inplace, idle_pre=False, idle_now=False, supply=False, cl_orders=False, inflight=False)
+                return
             if kind == "fixed_day_graph":         # one graph launch: T x (tick -> k_pack_obs -> k_dispatch_dense), replica groups as branches
                 env.run_hooked(T, actions=fixed_both, inflight=False)
                 return
@@ -510,6 +543,7 @@ def main():
         res = {}
         kinds = ([("step_advance_only", "none"), ("engine_hook_fixed_actions", "fixed"), ("engine_hook_fixed_actions_both_moves", "fixed_both"), ("engine_hook_day_graph", "fixed_day_graph")]
                  + ([("torch_policy_graph", "graph")] if pol_graph is not None else []) + ([("torch_policy_day_graph", "policy_day_graph")] if pol_graph_keep is not None else [])
+                 + [("engine_hook_day_graph_obs_in_place", "fixed_day_graph_inplace")] + ([("torch_policy_day_graph_obs_in_place", "policy_day_graph_inplace")] if pol_inplace is not None else [])
                  + [("torch_policy_eager", "eager")])
         for label, kind in kinds:
             hooked_day(kind); torch.cuda.synchronize()            # warm
@@ -532,6 +566,8 @@ def main():
                   # replica groups as parallel branches) against the hook-less day graph of the headline
                   "engine_hook_vs_hookless_tick": res["engine_hook_day_graph"]["slot_us"] / hookless_us,
                   "engine_hook_call_by_call_vs_hookless_tick": res["engine_hook_fixed_actions"]["slot_us"] / hookless_us,
+                  # observations read in place (vds_obs_inplace: no k_pack_obs; policies that do not need supply / inflight)
+                  "engine_hook_obs_in_place_vs_hookless_tick": res["engine_hook_day_graph_obs_in_place"]["slot_us"] / hookless_us,
                   "policy_slot_vs_hookless_tick": res[best]["slot_us"] / hookless_us,
                   "host_issue_us_per_slot": res[best]["host_issue_us_per_slot"],
                   "variants": res,
@@ -540,6 +576,8 @@ def main():
                           "(vds_step / vds_obs_device_planes / policy / vds_apply_dispatch_device / vds_advance); engine_hook_* = the boundary without a policy"}
         if graph_error:
             hooked["policy_graph_error"] = graph_error
+        if inplace_error:
+            hooked["obs_in_place_error"] = inplace_error
         if hook_errors:
             hooked["INVALID"] = "engine errors during the hooked days (timings are not those of a valid run): " + " | ".join(sorted(set(hook_errors)))
 

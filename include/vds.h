@@ -271,6 +271,16 @@ int vds_obs_device(vds_handle *h, void **dev_ptr);
  * cluster's whole VehiclesArrivetime table, :1011) the pass reads only what the next slot's SupplyExpect needs - what a per-slot
  * hook (:1057-1087) that does not look at len(VehiclesArrivetime) should call. */
 int vds_obs_device_planes(vds_handle *h, int32_t planes, void **dev_ptr);
+/* Three of the planes IN PLACE - no pass, no copy: idle_pre (plane index 0: Cluster.PerMatchIdleVehicles :909-910), idle_now
+ * (1: len(Cluster.IdleVehicles) :1080-1081 / :1086-1087) and cl_orders (3: len(Cluster.Orders) :919) are words of the per-(cluster,
+ * replica) bucket records the tick kernels keep, so a device-side hook (:1057-1087) can read them where they are: element
+ * (replica r, cluster c) of the plane is dev_ptr[r * stride_replica + c * stride_cluster] (strides in int32 elements; the
+ * storage is cluster-major).  Always current: what the last vds_step / vds_apply_dispatch* left.  Read-only for the caller.
+ * supply (SupplyExpect :880-891) and inflight are counts over arrival tables and stay with vds_obs_device_planes.
+ * VDS_ESTATE when the replicas are stored regrouped by order day (vds_load_order_days / vds_set_replica_days with more than
+ * one day: storage order is not the caller's replica order); the pointer stays valid until the tables are re-made
+ * (vds_load_orders* with other sizes, vds_set_idle_cap, vds_set_replica_days, vds_destroy). */
+int vds_obs_inplace(vds_handle *h, int32_t plane, void **dev_ptr, int64_t *stride_replica, int64_t *stride_cluster);
 
 /* counters: int64 [R * VDS_NUM_COUNTERS]. */
 int vds_read_counters(vds_handle *h, int64_t *out);

@@ -27,13 +27,15 @@ def build(target, name):
 
 
 WORKER = r"""
-import sys
+import sys, time
+T0 = time.perf_counter()
 import numpy as np
 sys.path.insert(0, %r)
 from oracle.oracle import Oracle
 from vehicles_dispatch_simulator_amd import workloads, _lib
 assert _lib.load().vds_build_id().decode().endswith(%r), _lib.load().vds_build_id()
 for neighbor, fg, R, veh, dd in %r:
+    t1 = time.perf_counter()
     w = workloads.tiny(neighbor=neighbor, vehicles=veh, orders=4000)
     init = w.vehicle_nodes(R)
     env = w.make_env(R, force_generic=fg, dense_debug=dd)
@@ -47,8 +49,10 @@ for neighbor, fg, R, veh, dd in %r:
         for k in ("status", "vehicle", "wait"):
             assert np.array_equal(got[k][r], exp[k]), (neighbor, fg, r, k)
         assert cn[r, 7] == oc["evals"] and cn[r, 1] == oc["reject_num"]
+    t2 = time.perf_counter()
     print("ok", neighbor, fg, env.main_kernel())
     env.close()          # guarded build: raises when a guard zone was written
+    print("   %%.2f s engine + oracle, %%.2f s close, %%.2f s since start" %% (t2 - t1, time.perf_counter() - t2, time.perf_counter() - T0))
 print("WORKER DONE")
 """
 
@@ -90,7 +94,7 @@ def test_guarded_build_replica_days_and_dispatch():
     env = dict(os.environ, VDS_LIB=lib)
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_replica_days.py"),
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
-                        "(replica and not full_size and not full_tables) or tiny_dispatch-fast or tiny_dispatch-generic or tiny_dispatch-dense16 or tiny_dispatch-dense_tiny or tiny_dispatch_dfs2-fast or device_resident or (burst and (fast or dense16))"],
+                        "(every_replica_replays and (fast or dense16 or rows)) or changes_every_episode or blocks_of_sixteen or tiny_dispatch-fast or tiny_dispatch-dense16 or tiny_dispatch_dfs2-fast or device_resident or (burst and dense16)"],
                        env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
 

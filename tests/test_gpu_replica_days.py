@@ -121,7 +121,7 @@ def test_every_replica_replays_its_own_day(name, mode):
 
 
 @pytest.mark.parametrize("mode", ["fast", "dense16", "dense8_tiny", "dense_ring", "rows"])
-@pytest.mark.parametrize("V", [32, 33, 64, 96, 127, 128, 129, 200, 255, 256, 257])      # (order days per replica: 16 lanes per replica, tables of up to 256 entries)
+@pytest.mark.parametrize("V", [33, 64, 127, 128, 129, 255, 256, 257])      # (order days per replica: 16 lanes per replica, tables of up to 256 entries)
 def test_full_tables_rows_with_and_without_an_order_at_each_step(V, mode):
     """Constructed case for the class of bug the round-3 fuzz found by luck (a row WITHOUT an order at a match step, next to rows
     with one, while its register table is FULL, lost the vehicle in the table's last slot): sixteen replicas, every one on its own

@@ -147,3 +147,74 @@ def test_hooked_day_with_fixed_actions_no_policy_and_observation_subsets():
         env_b.run_hooked(1)
     for e in (env_a, env_b, env_c):
         e.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_kmeans", "tiny_kmeans_dfs2"])
+def test_observations_in_place_are_the_packed_planes_and_feed_a_hooked_day_without_an_observation_pass(name):
+    """vds_obs_inplace: idle_pre / idle_now / cl_orders read where the tick keeps them (strided [R, C] views of the bucket records)
+    equal the packed planes after every step and after every dispatch; a policy graph over the views with NO observation planes in
+    the hooked day (planes = 0: no k_pack_obs per slot) gives the day of the stepwise loop over the packed block."""
+    import torch
+    g = load_golden(name)
+    R, K = 24, 2
+    stream = torch.cuda.current_stream()
+    n2c = np.asarray(g["node2cluster"])
+    C = int(g["C"])
+    some_node_of = torch.tensor([int(np.flatnonzero(n2c == c)[0]) if (n2c == c).any() else int(np.flatnonzero(n2c >= 0)[0]) for c in range(C)], dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(9)
+    init = np.stack([rng.permutation(g["veh_node"]) for _ in range(R)]).astype(np.int32)
+
+    def policy(idle, orders):
+        src = torch.topk(idle - orders, K, dim=1).indices
+        dst = torch.topk(idle - orders, K, dim=1, largest=False).indices
+        ok = idle.gather(1, src) > 1
+        return torch.stack([torch.where(ok, src.int(), torch.full_like(src, -1).int()), torch.zeros_like(src).int(), some_node_of[dst]], dim=2).contiguous()
+
+    env_a = make_env(g, R, stream.cuda_stream)
+    env_a.reset(init)
+    views = env_a.obs_inplace_torch()
+    assert all(v.shape == (R, C) and v.dtype == torch.int32 and v.is_cuda for v in views.values())
+    for t in range(env_a.T):
+        env_a.step()
+        packed = env_a.obs_torch(inflight=False)
+        for i, k in ((0, "idle_pre"), (1, "idle_now"), (3, "cl_orders")):
+            assert torch.equal(views[k], packed[i]), (t, k)
+        env_a.apply_dispatch_torch(policy(packed[1], packed[3]))
+        assert torch.equal(views["idle_now"], env_a.obs_torch(idle_pre=False, supply=False, cl_orders=False, inflight=False)[1]), t
+        env_a.advance()
+    ref = state_of(env_a)
+    env_b = make_env(g, R, stream.cuda_stream)
+    env_b.reset(init)
+    vb = env_b.obs_inplace_torch()
+    actions = torch.zeros((R, K, 3), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(stream)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            actions.copy_(policy(vb["idle_now"], vb["cl_orders"]))
+    stream.wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(graph):
+        actions.copy_(policy(vb["idle_now"], vb["cl_orders"]))
+    for day in range(2):
+        env_b.reset_again()
+        env_b.run_hooked(env_b.T, actions=actions, policy_graph=graph, idle_pre=False, idle_now=False, supply=False, cl_orders=False)
+        assert_same(state_of(env_b), ref)
+    env_a.close(); env_b.close()
+
+
+def test_observations_in_place_are_refused_when_replicas_are_stored_by_order_day():
+    from vehicles_dispatch_simulator_amd import workloads
+    w = workloads.tiny(vehicles=150, orders=1500)
+    days = workloads.distinct_days(w, 3)
+    env = w.make_env(48, load=False)
+    env.load_order_days(days, (np.arange(48) % 3).astype(np.int32))
+    env.reset(w.vehicle_nodes(48))
+    with pytest.raises(Exception, match="regrouped"):
+        env.obs_inplace_torch()
+    with pytest.raises(Exception, match="not kept in place"):
+        import ctypes as C
+        p, a, b = C.c_void_p(), C.c_int64(), C.c_int64()
+        env._chk(env._lib.vds_obs_inplace(env._h, 2, C.byref(p), C.byref(a), C.byref(b)))
+    env.close()

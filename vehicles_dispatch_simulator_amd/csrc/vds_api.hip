@@ -2192,6 +2192,19 @@ int vds_obs_device_planes(vds_handle *h, int32_t planes, void **dev_ptr) {
 
 int vds_obs_device(vds_handle *h, void **dev_ptr) { return vds_obs_device_planes(h, 31, dev_ptr); }
 
+int vds_obs_inplace(vds_handle *h, int32_t plane, void **dev_ptr, int64_t *stride_replica, int64_t *stride_cluster) {
+    if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_obs_inplace: load orders first (the state tables are made by the load)");
+    if (!dev_ptr || !stride_replica || !stride_cluster) return fail(h, VDS_EINVAL, "vds_obs_inplace: null output pointer");
+    const int word = plane == 0 ? HDR_IDLE_PRE : (plane == 1 ? HDR_IDLE : (plane == 3 ? HDR_ORDERS : -1));
+    if (word < 0) return fail(h, VDS_EINVAL, "vds_obs_inplace: plane %d is not kept in place (0 idle_pre, 1 idle_now, 3 cl_orders are; supply and inflight: vds_obs_device_planes)", plane);
+    if (h->S.int2ext != nullptr || h->S.rperm != nullptr || h->S.R != h->R_ext)
+        return fail(h, VDS_ESTATE, "vds_obs_inplace: the replicas are stored regrouped by order day (not in the caller's order): use vds_obs_device_planes");
+    *dev_ptr = h->D.hdr + word;
+    *stride_replica = HDR_WORDS;
+    *stride_cluster = (int64_t)h->S.R * HDR_WORDS;
+    return VDS_OK;
+}
+
 static int read_obs_impl(vds_handle *h, int32_t *idle_pre, int32_t *idle_now, int32_t *supply, int32_t *cl_orders, int32_t *inflight) {
     int rc = vds_obs_device(h, nullptr);
     if (rc) return rc;

@@ -295,6 +295,26 @@ class BatchedDispatchEnv:
                                         "version": 2, "strides": None}
         return torch.as_tensor(blk, device=torch.device("cuda", self.device))
 
+    def obs_inplace_torch(self):
+        """``idle_pre``, ``idle_now`` and ``cl_orders`` as zero-copy strided ``torch`` int32 views ``[R, C]`` of the bucket records
+        the tick kernels keep (``vds_obs_inplace``): always current, no pass per slot - what a device-side policy that does not
+        need ``supply`` / ``inflight`` reads.  Read-only.  Raises when the replicas are stored regrouped by order day."""
+        import torch
+
+        out = {}
+        for name, k in (("idle_pre", 0), ("idle_now", 1), ("cl_orders", 3)):
+            p, sr, sc = C.c_void_p(), C.c_int64(), C.c_int64()
+            self._chk(self._lib.vds_obs_inplace(self._h, k, C.byref(p), C.byref(sr), C.byref(sc)))
+
+            class _Block:
+                pass
+
+            blk = _Block()
+            blk.__cuda_array_interface__ = {"shape": (self.R, self.C), "typestr": "<i4", "data": (p.value, False), "version": 2,
+                                            "strides": (4 * sr.value, 4 * sc.value)}
+            out[name] = torch.as_tensor(blk, device=torch.device("cuda", self.device))
+        return out
+
     def counters_torch(self):
         """Per-replica counters as a zero-copy ``torch`` int64 tensor ``[R, 8]`` on the GPU, in device order
         ``(orders, rejects, wait_sum, matched_value_sum, evals, arrivals, dispatch_num, dispatch_cost)``;
