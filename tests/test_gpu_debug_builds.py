@@ -89,12 +89,13 @@ def test_guarded_build_all_tick_paths():
 
 
 def test_guarded_build_replica_days_and_dispatch():
-    """The parity files that move the most tables, run whole under the guarded library."""
+    """The tests that move the most tables (order days per replica, the map changes, dispatch, the list image of the reset, the hooked day graph, observations in place) under the guarded library."""
     lib = build("canary", "libvds_canary.so")
     env = dict(os.environ, VDS_LIB=lib)
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_replica_days.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
-                        "(every_replica_replays and (fast or dense16 or rows)) or changes_every_episode or blocks_of_sixteen or tiny_dispatch-fast or tiny_dispatch-dense16 or tiny_dispatch_dfs2-fast or device_resident or (burst and dense16)"],
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_edge_cases.py"), os.path.join(ROOT, "tests", "test_gpu_run_hooked.py"), "-k",
+                        "(every_replica_replays and (fast or dense16 or rows)) or changes_every_episode or blocks_of_sixteen or tiny_dispatch-fast or tiny_dispatch-dense16 or tiny_dispatch_dfs2-fast or device_resident or (burst and dense16)"
+                        " or reset_again_of_a_city or observations_in_place or (hooked_day_graph and tiny_kmeans-1)"],
                        env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
 
