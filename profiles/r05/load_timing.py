@@ -14,5 +14,7 @@ for i in range(3):
 env.reset(w.vehicle_nodes(R)); env.run(env.T); env.sync()
 days = workloads.distinct_days(w, 16)
 print("---- 16 days", file=sys.stderr, flush=True)
-t0 = time.perf_counter(); env.load_order_days(days, (np.arange(R) % 16).astype(np.int32)); print("vds_load_order_days(16): %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+for i in range(3):
+    print("---- 16 days, load %d" % i, file=sys.stderr, flush=True)
+    t0 = time.perf_counter(); env.load_order_days(days, (np.arange(R) % 16).astype(np.int32)); print("vds_load_order_days(16) #%d: %.1f ms" % (i, (time.perf_counter() - t0) * 1e3), flush=True)
 env.close()

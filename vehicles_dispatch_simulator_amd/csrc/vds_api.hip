@@ -5,6 +5,7 @@
 #include "vds_device.h"
 
 #include <algorithm>
+#include <unordered_map>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -72,6 +73,81 @@ struct DayHost {
     long long value_all = 0;
 };
 
+// host tables that are written completely before they are read (the sorted order records of a load: 50 MB at 16 days): resize()
+// default-initialises, so the pages are first touched by the day workers that fill them, not zeroed by the calling thread first
+template <typename T>
+struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+    bool operator==(const NoInitAlloc &) const { return true; }
+    bool operator!=(const NoInitAlloc &) const { return false; }
+};
+template <typename T> using hvec = std::vector<T, NoInitAlloc<T>>;
+
+// ... and the largest of them in PINNED host memory (the sorted order records, the arrival-slot records and indices: 90 MB at 16 days,
+// uploaded at ~5 GB/s from pageable memory - 18 of a 16-day load's 50 ms - and at the link's rate from pinned).  Page-locking costs
+// milliseconds per block, so blocks are pooled per process and handed out again (a Reload asks for the same sizes); a block that
+// cannot be pinned is ordinary memory.
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> idle;          // pinned blocks not in use
+    std::unordered_map<void *, std::pair<size_t, bool>> live;      // block -> {bytes, pinned}
+    size_t idle_bytes = 0;
+    void *get(size_t bytes) {
+        bytes = (bytes + 65535) & ~(size_t)65535;
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (int i = 0; i < (int)idle.size(); ++i)
+            if (idle[i].second >= bytes && idle[i].second <= bytes + bytes / 2 + (1u << 20) && (best < 0 || idle[i].second < idle[best].second)) best = i;
+        if (best >= 0) {
+            void *p = idle[best].first; const size_t b = idle[best].second;
+            idle.erase(idle.begin() + best); idle_bytes -= b;
+            live[p] = {b, true};
+            return p;
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) { live[p] = {bytes, true}; return p; }
+        (void)hipGetLastError();
+        p = ::operator new(bytes);
+        live[p] = {bytes, false};
+        return p;
+    }
+    void put(void *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        const size_t b = it->second.first; const bool pinned = it->second.second;
+        live.erase(it);
+        if (!pinned) { ::operator delete(p); return; }
+        idle.emplace_back(p, b); idle_bytes += b;
+        while (idle_bytes > ((size_t)1 << 30) && !idle.empty()) {      // (at most 1 GB parked)
+            (void)hipHostFree(idle.front().first); idle_bytes -= idle.front().second; idle.erase(idle.begin());
+        }
+    }
+};
+static PinnedPool &pinned_pool() { static PinnedPool *pool = new PinnedPool(); return *pool; }      // (never destroyed: blocks may outlive static destructors)
+template <typename T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(pinned_pool().get(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { pinned_pool().put(p); }
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+    bool operator==(const PinnedAlloc &) const { return true; }
+    bool operator!=(const PinnedAlloc &) const { return false; }
+};
+template <typename T> using pvec = std::vector<T, PinnedAlloc<T>>;
+
+
 struct vds_handle {
     vds_config cfg{};
     Static S{};
@@ -94,7 +170,7 @@ struct vds_handle {
     Static S_up{};
     State D_up{};
     bool have_up = false;
-    std::vector<int2> pull_drec;             // host copy of Static.d_rec
+    pvec<int2> pull_drec;                    // host copy of Static.d_rec (the vector it was uploaded from: pinned)
     std::vector<int> pull_slot_q;            // slot (absolute d_rec position) -> q - q_base of its order
     std::vector<int4> pull_desc;             // per day {d_first base, d_rec base, TA, 0} (static arrival slots of the dense tick)
     int pull_Od_max = 0;
@@ -123,9 +199,15 @@ struct vds_handle {
     int alloc_R = 0;                     // replica count the state tables were allocated for
     std::vector<void *> dev_allocs;          // static tables, scratch
     std::vector<void *> order_allocs;        // tables of the loaded day (replaced by the next vds_load_orders)
+    // blocks of the day before, handed out again to the next load's tables of about the same size (a Reload replaces ~20 tables; hipFree +
+    // hipMalloc of the large ones took 1 ms or 80 ms from one call to the next: profiles/r05/load_timing_results_tables.txt); what a load
+    // does not take again is freed when it ends.  Not in the guarded build (a reused block's guard would not sit behind the table).
+    std::unordered_map<void *, size_t> order_bytes;
+    std::vector<std::pair<void *, size_t>> order_cache;
     std::vector<void *> map_allocs;          // the replica -> day map's device arrays (replaced by vds_set_replica_days / the next load)
     std::vector<void *> result_allocs;       // per-replica result tables out / arr / slog (sized by S.R)
     std::vector<DayDesc> ddesc_host;         // the loaded days (+ the empty day of padding replicas, last)
+    size_t res_cap_out = 0, res_cap_arr = 0, res_cap_slog = 0;      // elements the result tables (alloc_results) were allocated for
     int alloc_O = 0;                         // what alloc_state was sized for (orders per day)
     int Oqmax = 0;
     std::vector<void *> state_allocs;        // per-replica state (kept across days while the capacities still fit)
@@ -226,6 +308,21 @@ static int dev_alloc(vds_handle *h, T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
     const size_t bytes = n * sizeof(T);
+    if (!GUARDED && h->alloc_sink == &h->order_allocs) {
+        // best fit among the cached blocks: large enough, at most 1.5 x + 64 KB of what is asked for
+        int best = -1;
+        for (int i = 0; i < (int)h->order_cache.size(); ++i) {
+            const size_t cb = h->order_cache[i].second;
+            if (cb >= bytes && cb <= bytes + bytes / 2 + 65536 && (best < 0 || cb < h->order_cache[best].second)) best = i;
+        }
+        if (best >= 0) {
+            *p = reinterpret_cast<T *>(h->order_cache[best].first);
+            h->order_bytes[(void *)*p] = h->order_cache[best].second;
+            h->order_cache.erase(h->order_cache.begin() + best);
+            h->order_allocs.push_back((void *)*p);
+            return VDS_OK;
+        }
+    }
     char *base = nullptr;
     hipError_t e = hipMalloc((void **)&base, bytes + GUARD_FRONT + GUARD_BACK);
     if (e != hipSuccess) return fail(h, VDS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
@@ -237,11 +334,12 @@ static int dev_alloc(vds_handle *h, T **p, size_t n) {
     }
     *p = reinterpret_cast<T *>(base + GUARD_FRONT);
     (h->alloc_sink ? *h->alloc_sink : h->dev_allocs).push_back((void *)*p);
+    if (!GUARDED && h->alloc_sink == &h->order_allocs) h->order_bytes[(void *)*p] = bytes;
     return VDS_OK;
 }
 
-template <typename T>
-static int upload(vds_handle *h, T **p, const std::vector<T> &v) {
+template <typename T, typename A>
+static int upload(vds_handle *h, T **p, const std::vector<T, A> &v) {
     int rc = dev_alloc(h, p, v.size());
     if (rc) return rc;
     if (!v.empty()) HIPCHK(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -541,6 +639,7 @@ int vds_destroy(vds_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->dev_allocs) dev_free(p);
     for (void *p : h->order_allocs) dev_free(p);
+    for (auto &b : h->order_cache) dev_free(b.first);
     for (void *p : h->map_allocs) dev_free(p);
     for (void *p : h->result_allocs) dev_free(p);
     for (void *p : h->state_allocs) dev_free(p);
@@ -996,16 +1095,27 @@ static int apply_replica_map(vds_handle *h) {
 // per-replica result tables (strided / sized by S.R): out [R][Oq], arr [slots][R] (static arrival slots), slog (hybrid tick)
 static int alloc_results(vds_handle *h) {
     Static &S = h->S;
+    S.arr_slots = std::max(h->pull_Od_max, 1);
+    const size_t need_out = (size_t)S.R * std::max(h->Oqmax, 1);
+    const size_t need_arr = S.pull ? (size_t)S.R * S.arr_slots : 0;                        // [Od][R] (arr_index)
+    const size_t need_slog = h->hybrid_ok ? (size_t)S.R * std::max(S.max_tick_orders, 1) : 0;
+    // the tables of the load before are kept when they are large enough (a Reload with another day of about the same size: freeing and
+    // allocating 1.6 + 0.8 GB took 0.4 ms or 100 ms, whichever way the driver felt - profiles/r05/load_timing_results_tables.txt); none of
+    // them needs its old contents cleared (every processed order writes its result and its arrival slot before either is read)
+    if (h->D.out != nullptr && need_out <= h->res_cap_out && need_arr <= h->res_cap_arr && need_slog <= h->res_cap_slog) {
+        if (need_arr == 0) { /* the table stays allocated, unused */ }
+        return VDS_OK;
+    }
     for (void *p : h->result_allocs) dev_free(p);
     h->result_allocs.clear();
+    h->D.out = nullptr; h->D.arr = nullptr; h->D.slog = nullptr;
+    h->res_cap_out = h->res_cap_arr = h->res_cap_slog = 0;
     struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
     h->alloc_sink = &h->result_allocs;
-    int rc = dev_alloc(h, &h->D.out, (size_t)S.R * std::max(h->Oqmax, 1));
-    h->D.arr = nullptr;
-    S.arr_slots = std::max(h->pull_Od_max, 1);
-    if (!rc && S.pull) rc = dev_alloc(h, &h->D.arr, (size_t)S.R * S.arr_slots);       // [Od][R] (arr_index)
-    h->D.slog = nullptr;
-    if (!rc && h->hybrid_ok) rc = dev_alloc(h, &h->D.slog, (size_t)S.R * std::max(S.max_tick_orders, 1));
+    int rc = dev_alloc(h, &h->D.out, need_out);
+    if (!rc && need_arr) rc = dev_alloc(h, &h->D.arr, need_arr);
+    if (!rc && need_slog) rc = dev_alloc(h, &h->D.slog, need_slog);
+    if (!rc) { h->res_cap_out = need_out; h->res_cap_arr = need_arr; h->res_cap_slog = need_slog; }
     return rc;
 }
 
@@ -1035,7 +1145,7 @@ static int set_replica_days_impl(vds_handle *h, const int32_t *replica_day) {
     return VDS_OK;
 }
 
-static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min, const int32_t *pickup,
+static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min, const int32_t *pickup,
                           const int32_t *delivery, const int32_t *replica_day) {
     LoadTimer lt;
     if (!h || !h->have_static) return fail(h, VDS_EINVAL, "vds_load_orders: call vds_load_static first");
@@ -1047,7 +1157,11 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         // another day on the same handle (Reload, :130-212): the previous day's tables go, the static tables stay,
         // the state tables stay while their capacities still fit; vds_reset must follow
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (void *p : h->order_allocs) dev_free(p);
+        for (void *p : h->order_allocs) {
+            auto it = h->order_bytes.find(p);
+            if (!GUARDED && it != h->order_bytes.end()) { h->order_cache.emplace_back(p, it->second); h->order_bytes.erase(it); }
+            else dev_free(p);
+        }
         h->order_allocs.clear();
         { h->run_stale = true; h->tables_gen++; }
         h->have_orders = false; h->have_reset = false;
@@ -1068,8 +1182,8 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         h->replica_day[r] = d;
     }
     h->days.assign(n_days, DayHost());
-    std::vector<int4> so_rec;
-    std::vector<int> bkt_off, tick_off, ord_q, so_pnode;
+    pvec<int4> so_rec;                    // (every position is written by its day's worker: bucket fill / cursor order; pinned: uploaded whole)
+    hvec<int> bkt_off, tick_off, ord_q, so_pnode;
     std::vector<DayDesc> ddesc(n_days);
     int Tmax = 0, Oqmax = 0, Omax = 0, mto = 0;
     long long Ototal = 0;
@@ -1273,8 +1387,8 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
         const int Hc = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
         const int tk = S.tick_minutes;
         auto slots_of = [&](long long rel) -> int { return rel <= 0 ? 1 : (int)((rel + tk - 1) / tk); };      // post_arrival's d
-        std::vector<int> so_slot(so_rec.size(), -1);
-        std::vector<int2> d_rec;
+        pvec<int> so_slot(so_rec.size(), -1);
+        pvec<int2> d_rec;
         std::vector<int> d_first;
         std::vector<int4> ddesc2(ddesc.size(), make_int4(0, 0, 0, 0));
         int W = 0, hmax = 0;
@@ -1348,8 +1462,8 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
             if ((rc = upload(h, &d, d_first))) return rc; S.d_first = d;
             h->pull_desc = ddesc2;
             d_first_keep = d_first;
-            h->pull_drec = d_rec;
-            h->pull_slot_q.assign(d_rec.size(), 0);
+            h->pull_drec = std::move(d_rec);          // (uploaded above; not read again below: a 25 MB copy at 16 days)
+            h->pull_slot_q.assign(h->pull_drec.size(), 0);
             for_each_day(n_days, [&](int dd) {
                 const int qb = ddesc[dd].q_base;
                 for (int q = qb; q < qb + ddesc[dd].Oq; ++q)
@@ -1412,6 +1526,18 @@ static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off,
     lt.lap("results, arrival slots, steal log");
     h->have_orders = true;
     return VDS_OK;
+}
+
+static void drop_order_cache(vds_handle *h) {
+    for (auto &b : h->order_cache) dev_free(b.first);
+    h->order_cache.clear();
+}
+
+static int load_days_impl(vds_handle *h, int32_t n_days, const int64_t *day_off, const int32_t *release_min, const int32_t *pickup,
+                          const int32_t *delivery, const int32_t *replica_day) {
+    const int rc = load_days_body(h, n_days, day_off, release_min, pickup, delivery, replica_day);
+    drop_order_cache(h);         // blocks of the day before that this load did not take again
+    return rc;
 }
 
 static int load_orders_impl(vds_handle *h, const int32_t *release_min, const int32_t *pickup, const int32_t *delivery, int32_t O) {
