@@ -36,6 +36,8 @@ ar = torch.arange(R, device="cuda", dtype=torch.int32)
 acts = torch.full((R, K, 3), -1, dtype=torch.int32, device="cuda"); acts[:, :, 1] = 0; acts[:, :, 2] = node_of[0]
 acts[:, 0, 0] = ar % env.C; acts[:, 0, 2] = node_of[((ar + 97) % env.C).long()]
 acts[:, 1, 0] = (ar + 97) % env.C; acts[:, 1, 2] = node_of[(ar % env.C).long()]
+import os
+if os.environ.get("HOOK_NO_ACTIONS") == "1": acts[:, :, 0] = -1          # every action slot empty: what the launch costs by itself
 env.set_run_groups(1, -1)
 for _ in range(3):
     env.reset_again(); env.run_hooked(T, actions=acts, inflight=False)
