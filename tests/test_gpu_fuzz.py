@@ -84,12 +84,12 @@ def medium_case(seed):
     return cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_MEDIUM_N", "16")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_MEDIUM_N", "12")))))
 def test_medium_city_matches_oracle(seed):
     run_case(seed, medium_case(seed), idle_cap=1024)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "100")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "90")))))
 def test_random_city_matches_oracle(seed):
     run_case(seed, random_case(seed))
 
@@ -197,7 +197,7 @@ def days_case(seed):
 
 # 1906: one cluster, 134 vehicles, per-row days - a row without an order at a match step while its 128-slot table is full (the
 # round-3 tag-register match loop retired slot 127 of such a row)
-DAYS_SEEDS = sorted(set(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "100")))) | {1906})
+DAYS_SEEDS = sorted(set(range(int(os.environ.get("VDS_FUZZ_DAYS_N", "90")))) | {1906})
 
 
 @pytest.mark.parametrize("seed", DAYS_SEEDS)
