@@ -69,11 +69,14 @@ def test_self_checking_walk_build():
     lib = build("dbg", "libvds_dbg.so")
     # scarce vehicles: most orders run dry, redo chains and rejects; two replica counts
     out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)])
-    assert "k_dfs_hybrid" in out
+    assert "k_dfs_dense" in out
     assert "check" not in out.replace("vds_debug_check", ""), out[-3000:]
     # (the deferred-acceptance form has no walk that could count the evaluations a second time: its bounds checks only)
     out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 5, 90, None)], VDS_WALK_DA="1")
-    assert "k_dfs_hybrid_da" in out and "check" not in out.replace("vds_debug_check", ""), out[-3000:]
+    assert "k_dfs_dense_da" in out and "check" not in out.replace("vds_debug_check", ""), out[-3000:]
+    # the same on the wide layout (k_tick_rows in stamp mode + the committing walk)
+    out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 5, 90, None)], VDS_DENSE_DFS="0")
+    assert "k_dfs_hybrid" in out and "check" not in out.replace("vds_debug_check", ""), out[-3000:]
 
 
 def test_guarded_build_all_tick_paths():
@@ -85,7 +88,9 @@ def test_guarded_build_all_tick_paths():
     # the hybrid tick with the dry orders by deferred acceptance: scarce vehicles, most orders dry
     da = [(True, 0, 9, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)]
     out = run_worker(lib, "+canary", da, VDS_WALK_DA="1")
-    assert out.count("ok ") == len(da) and out.count("k_dfs_hybrid_da") == len(da)
+    assert out.count("ok ") == len(da) and out.count("k_dfs_dense_da") == len(da)
+    out = run_worker(lib, "+canary", da[:2], VDS_DENSE_DFS="0")
+    assert out.count("ok ") == 2 and out.count("k_dfs_hybrid") == 2
 
 
 def test_guarded_build_replica_days_and_dispatch():

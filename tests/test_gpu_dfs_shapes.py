@@ -15,7 +15,7 @@ from vehicles_dispatch_simulator_amd.env import neighbors_to_csr
 pytestmark = pytest.mark.gpu
 
 
-def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_dfs_hybrid", **kw):
+def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_dfs_dense", **kw):
     start, p0, d0 = synth.make_orders(oseed, city.N, O)
     pick = p0 if pick is None else pick
     dele = d0 if dele is None else dele
@@ -23,17 +23,20 @@ def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_df
     off, idx = neighbors_to_csr(city.neighbors)
     results = {}
     import os
-    # mode 7: the hybrid tick with the dry orders served by deferred acceptance (VDS_WALK_DA=1, read when the orders are loaded)
-    for mode in (0, 3, 1) + ((7,) if kernel0 == "k_dfs_hybrid" else ()):
-        env = BatchedDispatchEnv(city.cost, city.node2cluster, off, idx, replicas=R, vehicles=V, depth_limit=depth,
-                                 neighbor_can_server=True, force_generic=0 if mode == 7 else mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
-        if mode == 7:
-            os.environ["VDS_WALK_DA"] = "1"
+    # mode 7: the dry orders served by deferred acceptance (VDS_WALK_DA=1, read when the orders are loaded); 8 / 9: the hybrid tick on the
+    # WIDE layout (VDS_DENSE_DFS=0, read when the static tables are loaded: k_tick_rows in stamp mode + the committing walk), serial / DA
+    switches = {7: {"VDS_WALK_DA": "1"}, 8: {"VDS_DENSE_DFS": "0"}, 9: {"VDS_DENSE_DFS": "0", "VDS_WALK_DA": "1"}}
+    extra = (7, 8, 9) if kernel0 == "k_dfs_dense" else ((7,) if kernel0 == "k_dfs_hybrid" else ())
+    for mode in (0, 3, 1) + extra:
+        os.environ.update(switches.get(mode, {}))
         try:
+            env = BatchedDispatchEnv(city.cost, city.node2cluster, off, idx, replicas=R, vehicles=V, depth_limit=depth,
+                                     neighbor_can_server=True, force_generic=0 if mode >= 7 else mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
             env.load_orders(rel, pick, dele)
         finally:
-            os.environ.pop("VDS_WALK_DA", None)
-        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs", 7: "k_dfs_hybrid_da"}[mode]
+            for k in switches.get(mode, {}):
+                os.environ.pop(k, None)
+        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs", 7: kernel0 + "_da", 8: "k_dfs_hybrid", 9: "k_dfs_hybrid_da"}[mode]
         env.reset(init)
         env.run(env.T)
         results[mode] = (env.orders(), env.counters(), env.obs(), [env.lists(r) for r in range(R)])

@@ -336,7 +336,7 @@ def test_reloading_days_on_one_handle_neighbour_search():
     env = mk_env(g, R)
     for d in (0, 1, 2, 0):
         env.load_orders(*days[d])
-        assert env.main_kernel() == "k_dfs_hybrid"
+        assert env.main_kernel() == "k_dfs_dense"
         env.reset(init)
         env.run(env.T)
         env.sync()

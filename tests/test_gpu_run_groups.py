@@ -47,7 +47,7 @@ def test_shared_day_every_replica_equals_the_oracle(groups, stagger, graph, monk
     init = _init(g, R, 400)
     env = mk_env(g, R)
     env.load_orders(*day[0])
-    assert env.main_kernel() == "k_dfs_hybrid"
+    assert env.main_kernel() == "k_dfs_dense"
     env.set_run_groups(groups, stagger)
     assert env.run_groups() == (min(groups, 3) if graph == "graph" else 1)       # (groups exist only as branches of the day's graph)
     env.reset(init)

@@ -35,7 +35,7 @@ def test_two_ranks_share_the_job(neighbor):
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert out["world"] == 2 and out["allreduce_calls"] == 1
-    assert out["kernel"] == ("k_dfs_hybrid" if neighbor else "k_tick_dense")
+    assert out["kernel"] == ("k_dfs_dense" if neighbor else "k_tick_dense")
     w = workloads.tiny(neighbor=neighbor, vehicles=60 if neighbor else 150)
     init = w.vehicle_nodes(total)
     exp = np.zeros(8, dtype=np.int64)

@@ -53,6 +53,7 @@ void set_ablate_dense(int, hipStream_t);
 void read_prof_dense(unsigned long long *, hipStream_t);
 void read_span_dense(unsigned long long *, int, hipStream_t);
 void emit_tick_dense(const Emit &, const Static &, const State &, int, int, int);
+void emit_dense_flush(const Emit &, const Static &, const State &, int, int);
 void emit_pack_obs(const Emit &, const Static &, const State &, int, int, int, int *, int, int);
 void emit_dispatch_dense(const Emit &, const Static &, const State &, int, int, const int *, int, int, int);
 }  // namespace vds
@@ -161,7 +162,9 @@ struct vds_handle {
     long long blk_ints = 0; // total size of the per-cluster cost blocks
     // dense layout (k_tick_dense): static preconditions, the layout the state tables were allocated for
     bool dense_static_ok = false;
-    int alloc_dense = -1;
+    bool dense_dfs_static_ok = false;        // ... of the dense layout for the neighbour-search tick (stamp form, Static.dense_st; round 6)
+    bool nodes_valid = false;                // d_veh_node holds the start nodes of the last vds_reset* (false once the state tables were re-allocated)
+    int alloc_dense = -1, alloc_st = -1;
     int seq_tick0 = 0;                       // dispatch_seq at the first dispatch call of the current slot (dense keys carry the sequence number inside the slot)
     int seq_tick = -1;                       // the slot seq_tick0 belongs to
     // device-resident copies of S / D for the slow path of k_tick_dense (Static.self_dev / state_dev), and what they hold
@@ -607,6 +610,7 @@ void vds_config_init(vds_config *cfg) {
 const char *vds_main_kernel(const vds_handle *h) {
     if (!h || !h->have_orders) return "";
     if (!h->dfs_mode) return h->S.dense ? "k_tick_dense" : (h->S.fast_ok ? "k_tick_rows" : "k_tick");
+    if (h->hybrid_ok && h->cfg.force_generic == 0 && h->S.dense_st) return h->S.walk_da ? "k_dfs_dense_da" : "k_dfs_dense";      // (k_tick_dense in stamp form + k_dfs_walk on the dense layout)
     if (h->hybrid_ok && h->cfg.force_generic == 0) return h->S.walk_da ? "k_dfs_hybrid_da" : "k_dfs_hybrid";      // (deferred acceptance / the serial walk)
     if (h->dfs2_ok && h->cfg.force_generic != 1) return "k_tick_replica2";
     return "k_match_dfs";
@@ -897,7 +901,8 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
                 unsigned char *db; if ((rc = upload(h, &db, bs))) return rc;
                 if (d8) S.blk8s = db; else S.blk32s = reinterpret_cast<const int *>(db);
                 std::vector<int4> cdd(C);
-                for (int i = 0; i < C; ++i) cdd[i] = make_int4(cdesc[corder[i]].x, (int)doff[corder[i]], corder[i], 0);
+                // (.w: the cluster has a visit sequence - its unserved orders search the neighbours, :936 - read by the stamp form)
+                for (int i = 0; i < C; ++i) cdd[i] = make_int4(cdesc[corder[i]].x, (int)doff[corder[i]], corder[i], dfs_off[corder[i] + 1] > dfs_off[corder[i]] ? 1 : 0);
                 int4 *d4d; if ((rc = upload(h, &d4d, cdd))) return rc; S.cdesc_dense = d4d;
             }
         }
@@ -938,8 +943,12 @@ static int load_static_impl(vds_handle *h, const int32_t *cost, int32_t N, const
     h->lds_ints = std::min((max_nc * max_nc + 3) / 4 * 4, lds_budget_ints);
     {   // dense layout: no neighbour search, packed keys, 24-bit vehicle ids, the largest block (stride n_c + 1) within the LDS budget
         const long long esz = S.blk8s ? 1 : 4;
-        h->dense_static_ok = h->dense_static_ok && !h->dfs_mode && S.fast_ok && S.V < (1 << 24) &&
-                             (long long)max_nc * (max_nc + 1) * esz <= 64 * 1024 && h->cfg.force_generic == 0;
+        const bool common = h->dense_static_ok && S.fast_ok && S.V < (1 << 24) && (long long)max_nc * (max_nc + 1) * esz <= 64 * 1024 && h->cfg.force_generic == 0;
+        h->dense_static_ok = common && !h->dfs_mode;
+        // neighbour search on the dense layout (k_tick_dense in stamp form + k_dfs_walk on dense lists): byte costs, and what the
+        // walk needs whatever the day (16-bit ranks / positions: every list fits 16 384 entries)
+        h->dense_dfs_static_ok = common && h->dfs_mode && S.blk8s != nullptr && S.u8_ok && S.cost8 != nullptr && S.V <= 16384 && h->max_seq <= 256 &&
+                                 !(getenv("VDS_DENSE_DFS") && getenv("VDS_DENSE_DFS")[0] == '0');
     }
     h->have_static = true;
     return VDS_OK;
@@ -964,14 +973,15 @@ static int alloc_state(vds_handle *h, int O) {
     if (ring_cap > 65520) return fail(h, VDS_EINVAL, "ring_cap=%d > 65520 unsupported", ring_cap);
     int far_cap = h->cfg.far_cap > 0 ? round_up(h->cfg.far_cap, 64) : std::min(round_up(std::max(V, 1), 64), 256);
     if (S.dense && H > 32) { S.dense = 0; S.pull = 0; }  // (load_days_impl already decided this; kept as a guard: never a dense flag without its tables)
-    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_dense == S.dense && h->alloc_R == R)
+    if (!h->state_allocs.empty() && S.idle_cap >= idle_cap && S.fl_cap == far_cap && S.H == H && S.ring_cap >= ring_cap && h->alloc_dense == S.dense && h->alloc_st == S.dense_st && h->alloc_R == R)
         return VDS_OK;                                   // another day on the same handle: the state tables still fit
     for (void *p : h->state_allocs) dev_free(p);
     h->state_allocs.clear();
     S.idle_cap = idle_cap; S.fl_cap = far_cap; S.in_cap = far_cap; S.H = H; S.ring_cap = ring_cap;
     const size_t B = (size_t)C * R;
-    h->alloc_dense = S.dense;
+    h->alloc_dense = S.dense; h->alloc_st = S.dense_st;
     h->alloc_R = R;
+    h->nodes_valid = false;                              // (d_veh_node is re-allocated below)
     int rc;
     struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
     h->alloc_sink = &h->state_allocs;
@@ -983,9 +993,13 @@ static int alloc_state(vds_handle *h, int O) {
         for (void *p : h->idle_allocs) dev_free(p);
         h->idle_allocs.clear();
         rc = dev_alloc(h, &D.idle, S.dense ? (B * idle_cap + 1) / 2 : B * idle_cap);      // (dense layout: 4-byte entries)
+        D.stamp = nullptr;
+        if (!rc && S.dense_st) rc = dev_alloc(h, &D.stamp, B * idle_cap);                 // (stamp form: one u16 per idle entry)
         h->alloc_sink = keep;
         if (rc) return rc;
     }
+    D.dry = nullptr;
+    if (S.dense_st && (rc = dev_alloc(h, &D.dry, (size_t)R))) return rc;
     if ((rc = dev_alloc(h, &D.ring, S.dense ? ((size_t)H * B * ring_cap + 1) / 2 : (size_t)H * B * ring_cap))) return rc;      // (dense: 8-byte entries)
     D.ring_min = nullptr;
     if (S.dense && (rc = dev_alloc(h, &D.ring_min, (size_t)H * B * ring_cap))) return rc;
@@ -1358,6 +1372,16 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
     // set for a layout it then drops - ADVICE r4)
     const int ring_H = h->cfg.ring_ticks > 0 ? h->cfg.ring_ticks : 32;
     S.dense = (h->dense_static_ok && Omax < (1 << DENSE_ID_BITS) && ring_H <= 32) ? 1 : 0;
+    // neighbour search on the dense layout (stamp form): one shared day, the walk's per-order visit rows, 16-bit ranks - and (checked
+    // below, once the slots are laid out) a static arrival slot for EVERY processed order: what k_tick_dense commits for an order whose
+    // vehicle a neighbour's dry order steals afterwards must be revocable by overwriting its slot
+    S.dense_st = 0;
+    if (h->dense_dfs_static_ok && n_days == 1 && Omax < (1 << DENSE_ID_BITS) && ring_H <= 32 && mto < 65535 && S.so_vis != nullptr &&
+        S.max_nc * S.max_nc <= h->lds_ints && S.N <= 65534 && h->cost_max < (1 << 15) && h->cfg.idle_cap <= 16384) {
+        Static Z = S;
+        Z.dense_st = 1; Z.walk_pool = 0;
+        if (dfs_walk_lds(Z) + 1024 <= 64 * 1024) { S.dense = 1; S.dense_st = 1; }          // (the walk's LDS footprint with the smallest record pool)
+    }
     // (static arrival slots: the all-ones vehicle field marks a rejected order)
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
@@ -1368,7 +1392,7 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
         const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", n_days > 1 ? 16 : DENSE_LPR_DEFAULT);
         S.dense_lpr = (lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
         // entries of a bucket the fast path holds: 128; 256 with order days per replica at 16 lanes per replica and byte costs (emit_tick_dense)
-        const int tab_max = (S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0) ? 256 : 128;
+        const int tab_max = (S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0 && !S.dense_st) ? 256 : 128;
         // (another day on the handle: the choice between 8 and 16 lanes per replica is open again, unless the caller fixed it)
         h->dense_adapt = (h->dbg_dense_lpr > 0 || h->dbg_dense_tab > 0 || getenv("VDS_DENSE_LPR") || env_int("VDS_DENSE_ADAPT", 1) == 0) ? -1 : 0;
         h->pin_bucket_ticks = 0;
@@ -1376,6 +1400,7 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
         S.dense_force_slow = h->dbg_dense_slow & 1;
         S.pull = (S.dense && S.V < (1 << 24) - 1 && !(h->dbg_dense_slow & 2) && env_int("VDS_DENSE_PULL", 1) != 0) ? 1 : 0;
+        if (S.dense_st && !S.pull) { S.dense = 0; S.dense_st = 0; }          // (the stamp form needs the static arrival slots)
     }
     // ---- static arrival slots of the dense tick ("pull", vds_device.h): every processed order owns one u32 slot per replica in
     //      D.arr, in the order (destination cluster, earliest arrival slot a0, id); the destination bucket reads the slots of the
@@ -1452,6 +1477,9 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
             });
         }
         if ((long long)d_first.size() >= (1ll << 31) || W > DENSE_PULL_WMAX) ok = false;
+        if (ok && S.dense_st)               // (stamp form: every processed order owns a slot)
+            for (int dd = 0; dd < n_days; ++dd) ok = ok && PD[dd].npull == ddesc[dd].Oq;
+        if (!ok && S.dense_st) { S.dense = 0; S.dense_st = 0; }              // neighbour search keeps the wide layout (hybrid tick on k_tick_rows)
         if (!ok) S.pull = 0;
         else {
             struct Sink2 { vds_handle *h; ~Sink2() { h->alloc_sink = nullptr; } } sink2{h};
@@ -1521,6 +1549,9 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
                        Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&
                        dfs_walk_lds(Z) + 1024 <= 64 * 1024 && Z.so_vis != nullptr;
+        if (Z.dense_st && !h->hybrid_ok)
+            return fail(h, VDS_ECAPACITY, "vds_load_orders: neighbour search on the dense layout needs the walk's tables (idle_cap %d <= 16384, %zu bytes of LDS <= 64 KB); VDS_DENSE_DFS=0 keeps the wide layout",
+                        Z.idle_cap, dfs_walk_lds(Z) + 1024);
     }
     if ((rc = alloc_results(h))) return rc;
     lt.lap("results, arrival slots, steal log");
@@ -1621,6 +1652,10 @@ static int reset_device(vds_handle *h) {
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 16 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
+    if (S.dense_st) {     // stamp form: every entry free, no replica with a dry bucket (the reset kernels write HDR_RAW = 0: compact lists)
+        HIPCHK(h, hipMemsetAsync(h->D.stamp, 0xFF, (size_t)S.C * S.R * S.idle_cap * sizeof(unsigned short), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->D.dry, 0, (size_t)S.R * sizeof(int), h->stream));
+    }
     // D.out needs no clearing: every processed order's slot is written (match or reject) before
     // vds_read_orders may look at it (it only reads orders whose tick has been stepped)
     if (reset_uses_image(S)) {
@@ -1651,7 +1686,7 @@ static int reset_device(vds_handle *h) {
     }
     HIPCHK(h, hipGetLastError());
     h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
-    h->have_reset = true;
+    h->have_reset = true; h->nodes_valid = true;
     return VDS_OK;
 }
 
@@ -1666,11 +1701,14 @@ static int set_idle_cap_impl(vds_handle *h, int32_t cap) {
     cap = std::min(round_up(cap, 64), round_up(std::max(h->S.V, 1), 64));
     if (cap > (1 << 24)) return fail(h, VDS_EINVAL, "vds_set_idle_cap: %d > 2^24 unsupported", cap);
     if (cap == h->S.idle_cap) return VDS_OK;
+    if (h->S.dense_st && cap > 16384) return fail(h, VDS_ECAPACITY, "vds_set_idle_cap: neighbour search on the dense layout holds at most 16384 entries per list (VDS_DENSE_DFS=0 keeps the wide layout)");
     for (void *p : h->idle_allocs) dev_free(p);
     h->idle_allocs.clear();
     h->alloc_sink = &h->idle_allocs;
     const size_t B0 = (size_t)h->S.C * h->S.R;
-    const int rc = dev_alloc(h, &h->D.idle, h->S.dense ? (B0 * cap + 1) / 2 : B0 * cap);
+    int rc = dev_alloc(h, &h->D.idle, h->S.dense ? (B0 * cap + 1) / 2 : B0 * cap);
+    h->D.stamp = nullptr;
+    if (!rc && h->S.dense_st) rc = dev_alloc(h, &h->D.stamp, B0 * cap);
     h->alloc_sink = nullptr;
     if (rc) return rc;
     h->S.idle_cap = cap;
@@ -1790,7 +1828,10 @@ static int reset_random_impl(vds_handle *h, const uint64_t *seeds) {
 }
 
 int vds_reset_again(vds_handle *h) {
-    if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_reset_again: needs a previous vds_reset");
+    // (after vds_set_replica_days the episode state is gone - have_reset is false - but the start nodes of the last vds_reset* are
+    // still on the device unless the state tables had to be re-allocated: the same nodes again is a valid follow-up then)
+    if (!h || !(h->have_reset || (h->have_orders && h->nodes_valid)))
+        return fail(h, VDS_EINVAL, "vds_reset_again: needs a previous vds_reset (after a load or a map that re-allocated the state tables: vds_reset / vds_reset_random)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return reset_device(h);   // asynchronous
 }
@@ -1822,7 +1863,9 @@ static int profile_read_impl(vds_handle *h, float *ms, int32_t cap, int32_t *n) 
     return VDS_OK;
 }
 
-static int step_impl(vds_handle *h) {
+// flush (stamp form, Static.dense_st): pack the lists at once (k_dense_flush) - what a hooked slot needs, since the hook may look at
+// the lists; vds_run leaves it to the next slot's tick and flushes once at the end
+static int step_impl(vds_handle *h, bool flush = true) {
     if (!h || !h->have_reset) return fail(h, VDS_EINVAL, "vds_step: call vds_reset first");
     if (h->last_stepped == h->t) return fail(h, VDS_EINVAL, "vds_step: tick %d already stepped; call vds_advance", h->t);
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1852,7 +1895,17 @@ static int step_impl(vds_handle *h) {
             if (!a || !b) return fail(h, VDS_EHIP, "vds_step: hipEventCreate failed");
             HIPCHK(h, hipEventRecord(a, h->stream));
         }
-        launch_tick_hybrid(h->S, h->D, h->t, h->lds_ints, h->stream);
+        if (h->S.dense_st) {
+            // ... on the dense layout: k_tick_dense in stamp form commits the slot as if nothing were stolen, k_dfs_walk serves the dry
+            // orders of the replicas that have any and writes out what moved
+            const int rcs = dev_copy_sync(h);
+            if (rcs) return rcs;
+            Emit e; e.st = h->stream;
+            emit_tick_dense(e, h->S, h->D, h->t, 0, 0);
+            emit_hybrid_walk(e, h->S, h->D, h->t, 0, 0);
+            if (flush) emit_dense_flush(e, h->S, h->D, 0, 0);
+        }
+        else launch_tick_hybrid(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
     } else if (h->dfs2_ok && h->cfg.force_generic != 1) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -1882,10 +1935,15 @@ int vds_advance(vds_handle *h) {
 
 static int run_eager(vds_handle *h, int32_t n_ticks) {
     for (int i = 0; i < n_ticks; ++i) {
-        int rc = vds_step(h);
+        int rc = guarded(h, "vds_run", [&] { return step_impl(h, false); });
         if (rc) return rc;
         rc = vds_advance(h);
         if (rc) return rc;
+    }
+    if (h->S.dense_st && n_ticks > 0) {          // (stamp form: the lists packed once, behind the last slot)
+        Emit e; e.st = h->stream;
+        emit_dense_flush(e, h->S, h->D, 0, 0);
+        HIPCHK(h, hipGetLastError());
     }
     return VDS_OK;
 }
@@ -1962,12 +2020,19 @@ static int build_group_graph(vds_handle *h, int32_t n_ticks, int G, hipGraph_t *
                 last[gi] = rows;
                 continue;
             }
-            emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+            if (h->S.dense_st) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);          // (stamp form)
+            else emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
             if (err != hipSuccess) break;
             prev_rows = rows;
             e.deps = &rows; e.ndeps = 1; e.node = &walk;
             emit_hybrid_walk(e, h->S, h->D, t, r_lo, r_n);
             last[gi] = walk;
+            if (h->S.dense_st && i == n_ticks - 1 && err == hipSuccess) {              // the group's lists packed behind its last slot
+                hipGraphNode_t fl = nullptr;
+                e.deps = &walk; e.ndeps = 1; e.node = &fl;
+                emit_dense_flush(e, h->S, h->D, r_lo, r_n);
+                last[gi] = fl;
+            }
         }
     }
     if (err != hipSuccess) {
@@ -2130,11 +2195,18 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
                     if (h->S.dense) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
                     else emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
                 } else {
-                    emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
+                    if (h->S.dense_st) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
+                    else emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
                     if (err != hipSuccess) break;
                     e.deps = &n1; e.ndeps = 1; e.node = &n2;
                     emit_hybrid_walk(e, h->S, h->D, t, r_lo, r_n);
                     n1 = n2;
+                    if (h->S.dense_st && err == hipSuccess) {      // (stamp form: the hook may look at the lists - packed now)
+                        hipGraphNode_t nf = nullptr;
+                        e.deps = &n1; e.ndeps = 1; e.node = &nf;
+                        emit_dense_flush(e, h->S, h->D, r_lo, r_n);
+                        n1 = nf;
+                    }
                 }
                 if (err != hipSuccess) break;
                 tail[gi] = n1;

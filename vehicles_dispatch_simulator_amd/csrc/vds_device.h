@@ -30,6 +30,9 @@ enum {
     HDR_FL = 3,         // far list fill
     HDR_INBOX0 = 4,     // far inbox fill, parity 0 (atomic target of other buckets)
     HDR_INBOX1 = 5,     // far inbox fill, parity 1
+    HDR_RAW = 6,        // dense neighbour-search tick (Static.dense_st): 0, or 1 + the list's RAW length - entries taken during the
+                        // last slot (stamp != free, State.stamp) are still inside, positions [0, raw); HDR_IDLE counts the ones alive.
+                        // Every other writer of a header leaves 0 here ("the list is compact") and needs to know nothing about it
     // words 8 .. 13: 32-bit partial counters (CNT_ORDERS .. CNT_ARRIVALS) of the dense tick's byte-cost fast path (round 5): the bucket's
     // header and its counters are ONE 64-byte record - one read request and one write request per bucket and tick instead of two
     // each (header 32 B + counters 64 B).  Per tick a bucket adds at most 64 orders x 256 candidates / 254 minutes, a day has at most
@@ -154,6 +157,9 @@ struct Static {
     const unsigned char *blk8s;      // (dense, byte costs <= 254) the same as bytes, column n_c = 0xFF: the loc byte of a taken / absent
                                      // entry names that column, so the entry loses every comparison without a test in the match loop
     const int4 *cdesc_dense;         // [C] {n_c, offset into blk8s / blk32s, cluster, 0}, heaviest cluster first
+    int dense_st;                    // 1: neighbour search on the dense layout (round 6): k_tick_dense in STAMP form + k_dfs_walk reading dense lists
+                                     //    (taken entries stay in the list, stamped with the rank of their order, until the NEXT slot's tick drops
+                                     //    them while it loads the list; dry orders are counted per replica in State.dry)
     const int4 *tdesc;               // (dense, one shared order day) [T][C][2] in cdesc_dense's cluster order: {first sorted order, orders, first
                                      // candidate slot, candidate slots} of the (slot, cluster) bucket - one scalar load next to cdesc_dense's
                                      // instead of four that depend on it (the workgroup's prologue is a chain of dependent loads)
@@ -182,6 +188,10 @@ struct State {
     int *err;
     int *work;   // [2] deferred-bucket counters by tick parity, then [2][C*R] bucket indices
     unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] pull_entry / pull_reject (arr_index)
+    unsigned short *stamp; // dense neighbour-search tick: [C][R][idle_cap] per idle entry 0xFFFF (alive) or the rank - position in id order inside
+                         // the slot - of the order that took it during the last slot; valid for positions below the list's raw length
+    int *dry;            // dense neighbour-search tick: [R] buckets of the replica whose orders outran the list in a searching cluster
+                         // during this slot (k_tick_dense adds, k_dfs_walk reads and clears: 0 = nothing to walk)
     int *ring_min;       // dense layout: [H][C][R][ring_cap] arrival minute of a DISPATCHED vehicle's entry (order-carrying entries: recomputed
                          // from the order's result on the read side); written by the dispatch kernels only, never read by a tick
 };

@@ -846,10 +846,10 @@ static_assert(WK_G >= 1 && WK_G <= 3, "dfs_scan is instantiated for 1, 2 and 3 o
 #define WKCHK(cond, code, a, b2) do { } while (0)
 #endif
 
-__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int ns = WK_NS) {
+__host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int ns = WK_NS, int dn = 0) {
     const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
-    return ((size_t)8 * C + 1 + ids + 2 * words + (1 + ns) * WK_REC + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)8 * C + 1 + ids + (dn ? 3 : 2) * words + (1 + ns) * WK_REC + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
 }
 
 template <bool U8>
@@ -902,7 +902,13 @@ __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
 // lowers the stamp of the entry it takes) and ls_l is published once per served order, so whatever mixture of states the scan
 // reads, the vehicles it considers are a superset of those alive when the order's turn comes, and the list a sorted prefix of
 // that superset: its first entry still alive at that time IS the winner (none kept: nothing was alive, the order is rejected).
-template <bool U8, int JB, int G = 1, bool PRE = (WK_REDO_PRE != 0)>
+// DN: the idle lists are the DENSE layout's packed entries {veh << 8 | loc_local} (neighbour search on the dense layout, round 6)
+template <bool DN>
+__device__ __forceinline__ unsigned idle_loc(const State &D, size_t elem) {
+    if (DN) return reinterpret_cast<const unsigned *>(D.idle)[elem] & 0xFFu;
+    return D.idle[elem].y & 0xFFFFu;
+}
+template <bool U8, int JB, int G = 1, bool PRE = (WK_REDO_PRE != 0), bool DN = false>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, const int (&rho)[G], const int (&pnode)[G],
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
                                          const unsigned short *st_l, const unsigned short *qr_l, int tq0, unsigned *const (&rec)[G], unsigned long long *pacc = nullptr) {
@@ -984,11 +990,11 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
             int in[G][8], seq[8], sidx[8];
             unsigned yv[8];
             int cof[8];
-            const uint2 *ip[8];
+            size_t ip[8];
             bool any = false;
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
-                seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0; sidx[k8] = 0; ip[k8] = D.idle;
+                seq[k8] = 0; yv[k8] = 0u; cof[k8] = 0; sidx[k8] = 0; ip[k8] = 0;
 #pragma unroll
                 for (int o = 0; o < G; ++o) in[o][k8] = 0;
                 while (cl == 0ull && jbc + 1 < JB) { ++jbc; cl = pick_mask<JB>(live, jbc); b = 0; }
@@ -1001,7 +1007,7 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
 #pragma unroll
                     for (int o = 0; o < G; ++o) in[o][k8] = i < m0c ? 1 : 0;
                     sidx[k8] = moc + min(i, m0c - 1);
-                    ip[k8] = D.idle + ((size_t)cc * S.R + r) * S.idle_cap + i;
+                    ip[k8] = ((size_t)cc * S.R + r) * S.idle_cap + i;
                     cof[k8] = pick_lane<JB>(cofj, jbc, j);
                     seq[k8] = (((jbc << 6) | j) << 8) | b;
                     ++b;
@@ -1016,7 +1022,7 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                 for (int o = 0; o < G; ++o) in[o][k8] &= (st > rho[o] ? 1 : 0);
             }
 #pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) if (in[0][k8]) yv[k8] = ip[k8]->y;        // (alive for a later order = alive for the first)
+            for (int k8 = 0; k8 < 8; ++k8) if (in[0][k8]) yv[k8] = idle_loc<DN>(D, ip[k8]);        // (alive for a later order = alive for the first)
 #pragma unroll
             for (int o = 0; o < G; ++o) {
                 int cst[8];
@@ -1084,7 +1090,7 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                     const bool al = lane < m0w && (int)st_l[mow + min(lane, m0w - 1)] > a0;
                     int key = IMAX;
                     if (al) {
-                        const int lo2 = (int)(D.idle[((size_t)wcl * S.R + r) * S.idle_cap + lane].y & 0xFFFF);
+                        const int lo2 = (int)idle_loc<DN>(D, ((size_t)wcl * S.R + r) * S.idle_cap + lane);
                         key = (cost_elem<U8>(U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk),
                                              (unsigned)((U8 ? cd.z : cd.y) + pick * ncw + lo2)) << 16) | lane;
                     }
@@ -1100,18 +1106,24 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
     SCT(4);
 }
 // one order
-template <bool U8, int JB>
+template <bool U8, int JB, bool DN = false>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
                                          const unsigned short *st_l, const unsigned short *qr_l, int tq0, unsigned *rec, unsigned long long *pacc = nullptr) {
     const int rho1[1] = {rho}, pn1[1] = {pnode};
     unsigned *const rec1[1] = {rec};
-    dfs_scan<U8, JB, 1>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, qr_l, tq0, rec1, pacc);
+    dfs_scan<U8, JB, 1, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, qr_l, tq0, rec1, pacc);
 }
 
 // JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
 // DA: the dry orders are served by DEFERRED ACCEPTANCE (round 5) instead of the serial walk: see the branch below.
-template <bool U8, int JB, bool DA = false>
+// DN: neighbour search on the DENSE layout (round 6; Static.dense_st).  The first half is k_tick_dense in stamp form, which - unlike
+//     k_tick_rows' - COMMITS what it does: results with vehicle ids, static arrival slots, counters, the entries' stamps in HBM
+//     (State.stamp); nothing is left for a per-replica commit.  This kernel then returns at once unless a searching bucket of the
+//     replica ran dry (State.dry); otherwise it loads the stamps, serves the dry orders as before and writes out only what MOVED:
+//     the served dry orders and the own-cluster orders whose vehicle was stolen (result, arrival slot / ring post, stamp, counter
+//     deltas, the lists' alive counts).  The lists themselves are packed by the next slot's tick (or k_dense_flush).
+template <bool U8, int JB, bool DA = false, bool DN = false>
 __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
@@ -1132,7 +1144,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
     const int nwords = (mto + 31) / 32 + 1;
     unsigned *clm_bits = dry_bits + nwords;                                           // dry orders somebody has claimed for scanning
-    unsigned *slot_l = clm_bits + nwords;                                             // one record, for the scans wavefront 0 does itself
+    unsigned *mov_bits = clm_bits + nwords;                                           // (DN) own-cluster orders whose vehicle was stolen: they picked again
+    unsigned *slot_l = mov_bits + (DN ? nwords : 0);                                  // one record, for the scans wavefront 0 does itself
     unsigned *pool_l = slot_l + WK_REC;                                               // WK_NS records, filled by wavefronts 1..3
     const int bmw = (C + 31) / 32;
     const int ns = S.walk_pool;
@@ -1149,6 +1162,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     __shared__ int s_slot[WK_NS];         // pool record s: 0 free, else rank of its dry order << 2 | 1 being filled / 2 ready
     const int r = S.r_lo + (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    if (DN && D.dry[r] == 0) return;          // no searching bucket of this replica ran dry in this slot: k_tick_dense has done it all
     const DayView dv = day_view(S, r);
     if (t >= dv.T) return;
     const int now = dv.now0 + t * S.tick_minutes;
@@ -1175,11 +1189,12 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
         const bool capable = S.dfs_off[c + 1] > S.dfs_off[c];
         cdA_l[c] = cd.x | (S.cl_off[c] << 11) | (capable ? CAPABLE : 0);
         const int q0 = bkt_off[(size_t)t * C + c], q1 = bkt_off[(size_t)t * C + c + 1];
-        const int m0 = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
+        int m0 = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_IDLE];
+        if (DN) { const int rw = D.hdr[((size_t)c * S.R + r) * HDR_WORDS + HDR_RAW]; if (rw) m0 = rw - 1; }      // (the raw length: this slot's taken entries are inside)
         const int own = min(q1 - q0, m0);                 // the fast kernel matched while vehicles remained
         m0_l[c] = m0; qend_l[c] = q1; lm_l[c] = own; sc_l[c] = 0; ls_l[c] = own << 16; tk_l[c] = 0;
     }
-    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) { dry_bits[w] = 0u; clm_bits[w] = 0u; }
+    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) { dry_bits[w] = 0u; clm_bits[w] = 0u; if (DN) mov_bits[w] = 0u; }
     if (threadIdx.x == 0) { s_ev = 0; s_cursor = 0; s_done = 0; s_nlog = 0; s_nmid = 0; }
     if (threadIdx.x < WK_NS) s_slot[threadIdx.x] = 0;
     __syncthreads();
@@ -1199,6 +1214,28 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     __syncthreads();
     PROF_STAMP(25);
     // ---- stamps: free, or the rank of the own-cluster order the fast kernel gave the entry to (its preliminary result says which)
+    if (DN) {
+        // (dense layout) the stamps as k_tick_dense wrote them: one list per wavefront step, eight lists in flight
+        for (int c0 = wave * 8; c0 < C; c0 += 8 * WK_WAVES) {
+            unsigned short sv[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = min(c0 + u, C - 1);
+                const int m0 = c0 + u < C ? m0_l[c] : 0;
+                const unsigned short *sp = D.stamp + ((size_t)c * S.R + r) * S.idle_cap;
+                sv[u][0] = lane < m0 ? sp[lane] : (unsigned short)0xFFFFu;
+                sv[u][1] = WAVE + lane < m0 ? sp[WAVE + lane] : (unsigned short)0xFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (c0 + u >= C) break;
+                const int c = c0 + u, m0 = m0_l[c], mo = moff_l[c];
+                if (lane < m0) st_l[mo + lane] = sv[u][0];
+                if (WAVE + lane < m0) st_l[mo + WAVE + lane] = sv[u][1];
+                for (int i = 2 * WAVE + lane; i < m0; i += WAVE) st_l[mo + i] = D.stamp[((size_t)c * S.R + r) * S.idle_cap + i];
+            }
+        }
+    } else {
     for (int i = threadIdx.x; i < (moff_l[C] + 1) / 2; i += WK_THREADS) reinterpret_cast<unsigned *>(st_l)[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (int i0 = threadIdx.x; i0 < nord; i0 += 6 * WK_THREADS) {
@@ -1208,6 +1245,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
 #pragma unroll
         for (int u = 0; u < 6; ++u)
             if (pr[u].x != -1) st_l[moff_l[(unsigned)pr[u].x >> 16] + (pr[u].x & 0xFFFF)] = rq_l[i0 + u * WK_THREADS];
+    }
     }
     PROF_STAMP(26);
     // dry orders: everything behind a searching cluster's exhaustion point
@@ -1243,7 +1281,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     //      steal log are read off the final stamps (one pass over the entries).
     unsigned *scn_bits = clm_bits;                                                    // dry orders waiting for a scan
     unsigned *recs_l = slot_l;                                                        // WK_WAVES x WK_G records: each wavefront's own
-    unsigned *chg_bits = slot_l + WK_WAVES * WK_G * WK_REC;                           // own-cluster orders that proposed again
+    unsigned *chg_bits = DN ? mov_bits : slot_l + WK_WAVES * WK_G * WK_REC;           // own-cluster orders that proposed again
     __shared__ int s_busy;                                                            // wavefronts inside a task
     for (int w = threadIdx.x; w < nwords; w += WK_THREADS) { scn_bits[w] = dry_bits[w]; chg_bits[w] = 0u; }
     if (threadIdx.x == 0) s_busy = 0;
@@ -1273,9 +1311,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             const int4 cd = S.cdesc[wcl];
             const int boff = U8 ? cd.z : cd.y;
             const int m0 = m0_l[wcl], mo = moff_l[wcl];
-            const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
+            const size_t ibase = ((size_t)wcl * S.R + r) * S.idle_cap;
             unsigned yv0 = 0u;
-            if (m0 <= WAVE && lane < m0) yv0 = idle[lane].y;          // (travels together with the order's record below)
+            if (m0 <= WAVE && lane < m0) yv0 = idle_loc<DN>(D, ibase + lane);          // (travels together with the order's record below)
             int pick = -1;
             while (true) {
                 if (pick < 0) {
@@ -1289,7 +1327,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                     for (int base = 0; base < m0; base += WAVE) {
                         const int ii = base + lane;
                         if (ii < m0 && (int)st_l[mo + ii] > a) {
-                            const int lo2 = (int)(idle[ii].y & 0xFFFF);
+                            const int lo2 = (int)idle_loc<DN>(D, ibase + ii);
                             const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
                             if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
                         }
@@ -1388,7 +1426,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 const int rho3[3] = {rk[0], rk[1], rk[2]}, pn3[3] = {pn[0], pn[1], pn[2]};
                 unsigned *const rec3[3] = {myrec, myrec + WK_REC, myrec + 2 * WK_REC};
                 DSEG(d_claim);
-                dfs_scan<U8, JB, 3, false>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 DA_PACC);
+                dfs_scan<U8, JB, 3, false, DN>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 DA_PACC);
             } else
 #endif
 #if WK_G >= 2
@@ -1396,14 +1434,14 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 const int rho2[2] = {rk[0], rk[1]}, pn2[2] = {pn[0], pn[1]};
                 unsigned *const rec2[2] = {myrec, myrec + WK_REC};
                 DSEG(d_claim);
-                dfs_scan<U8, JB, 2, false>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 DA_PACC);
+                dfs_scan<U8, JB, 2, false, DN>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 DA_PACC);
             } else
 #endif
             {
                 const int rho1[1] = {rk[0]}, pn1[1] = {pn[0]};
                 unsigned *const rec1[1] = {myrec};
                 DSEG(d_claim);
-                dfs_scan<U8, JB, 1, false>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec1 DA_PACC);
+                dfs_scan<U8, JB, 1, false, DN>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec1 DA_PACC);
             }
             wg_order();
             DSEG(d_scan); DCNT(d_nscan); DADD(d_nord, g);
@@ -1452,6 +1490,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     }
     __syncthreads();
     PROF_STAMP(1);
+    if constexpr (!DN) {
     // ---- what moved, read off the final stamps.  (1) every order that proposed during the phase above (the dry ones, the own-cluster
     //      orders that picked again) gets "no vehicle"; (2) one pass over the idle entries: an entry held by such an order is its
     //      result - a dry holder is a steal: log entry {rank, victim cluster | orders of that cluster before the thief << 16,
@@ -1524,6 +1563,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             }
         }
     }
+    }
 #ifdef WKDEBUG
     if (threadIdx.x == 0) s_dbg = 0x7FFFFFFF;            // (no walk to count the dry orders' evaluations a second time)
 #endif
@@ -1587,7 +1627,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 rec = pool_l + slot * WK_REC;
             } else {
                 const int q = q_of();
-                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
+                dfs_scan<U8, JB, DN>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
                 wg_order();
 #ifdef VDS_PROF
                 p_cnt[2] += 1;
@@ -1605,7 +1645,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             unsigned long long okb = ballot(stv > rho);
             if (nl > 0 && okb == 0ull) {           // every kept candidate has been taken since: scan again, on the state as it is
                 const int q = q_of();
-                dfs_scan<U8, JB>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
+                dfs_scan<U8, JB, DN>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
                 wg_order();
                 e = make_int4(IMAX, 0, 0, 0);
                 if (lane < WK_K) e = reinterpret_cast<const int4 *>(slot_l)[lane];
@@ -1652,6 +1692,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                     if ((nlog & (WAVE - 1)) == 0)
                         slog[nlog - WAVE + lane] = make_int4(lg_l[4 * lane], lg_l[4 * lane + 1], lg_l[4 * lane + 2], lg_l[4 * lane + 3]);
                     wg_order();
+                    // (DN: the log is kept as before - the evaluation pass reads it; the orders' results come from the final stamps)
 #ifdef VDS_PROF
                     p_cnt[0] += 1; if (a != (int)WK_FREE) p_cnt[1] += 1;
 #endif
@@ -1671,7 +1712,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                         const int4 cd = S.cdesc[wcl];
                         const int boff = U8 ? cd.z : cd.y;
                         const int m0 = m0_l[wcl];
-                        const uint2 *idle = D.idle + ((size_t)wcl * S.R + r) * S.idle_cap;
+                        const size_t ibase = ((size_t)wcl * S.R + r) * S.idle_cap;
                         // the list's node words travel together with the first victim's pickup node (one HBM level, not two), and
                         // serve every step of the chain; lists of more than 64 entries read them step by step
                         // first step from the record, when the scan worked it out for this very holder: the first of its two entries
@@ -1686,7 +1727,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                                 const int bst = s1 > a ? s1 : s2;
                                 if (lane == 0) {
                                     st_l[mo + pk] = (unsigned short)a;
-                                    out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)pk), (s1 > a ? rr1 : rr2) >> 16);
+                                    if (DN) atomicOr(&mov_bits[a >> 5], 1u << (a & 31));
+                                    else out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)pk), (s1 > a ? rr1 : rr2) >> 16);
                                 }
                                 wg_order();
                                 if (bst == (int)WK_FREE) chain = false; else a = bst;
@@ -1695,13 +1737,14 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                                 exhausted = 1;
                                 if (lane == 0) {
                                     if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
-                                    out_r[y] = make_int2(-1, -1);
+                                    if (DN) atomicOr(&mov_bits[a >> 5], 1u << (a & 31));
+                                    else out_r[y] = make_int2(-1, -1);
                                 }
                                 chain = false;
                             }
                         }
                         unsigned yv0 = 0u;
-                        if (chain && m0 <= WAVE && lane < m0) yv0 = idle[lane].y;
+                        if (chain && m0 <= WAVE && lane < m0) yv0 = idle_loc<DN>(D, ibase + lane);
                         while (chain) {
                             const int y = tq0 + (int)qr_l[a];
                             const int pick = S.so_rec[y].y & 0xFFFF;
@@ -1712,7 +1755,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                                 for (int base = 0; base < m0; base += WAVE) {
                                     const int ii = base + lane;
                                     if (ii < m0 && (int)st_l[mo + ii] > a) {
-                                        const int lo2 = (int)(idle[ii].y & 0xFFFF);
+                                        const int lo2 = (int)idle_loc<DN>(D, ibase + ii);
                                         const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
                                         if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
                                     }
@@ -1723,7 +1766,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                                 exhausted = 1;
                                 if (lane == 0) {
                                     if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
-                                    out_r[y] = make_int2(-1, -1);           // (rejected, unless the search serves it - then the log says so)
+                                    if (DN) atomicOr(&mov_bits[a >> 5], 1u << (a & 31));
+                                    else out_r[y] = make_int2(-1, -1);      // (rejected, unless the search serves it - then the log says so)
                                 }
                                 break;
                             }
@@ -1732,7 +1776,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                             wg_order();
                             if (lane == 0) {
                                 st_l[mo + minp] = (unsigned short)a;
-                                out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
+                                if (DN) atomicOr(&mov_bits[a >> 5], 1u << (a & 31));
+                                else out_r[y] = make_int2((int)(((unsigned)wcl << 16) | (unsigned)minp), minc);
                             }
                             wg_order();
                             if (bst == (int)WK_FREE) break;
@@ -1845,18 +1890,18 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             if (g == 3) {
                 const int rho3[3] = {rk[0], rk[1], rk[2]}, pn3[3] = {pn[0], pn[1], pn[2]};
                 unsigned *const rec3[3] = {pool_l + sl[0] * WK_REC, pool_l + sl[1] * WK_REC, pool_l + sl[2] * WK_REC};
-                dfs_scan<U8, JB, 3>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 WK_PACC);
+                dfs_scan<U8, JB, 3, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 WK_PACC);
             } else
 #endif
 #if WK_G >= 2
             if (g == 2) {
                 const int rho2[2] = {rk[0], rk[1]}, pn2[2] = {pn[0], pn[1]};
                 unsigned *const rec2[2] = {pool_l + sl[0] * WK_REC, pool_l + sl[1] * WK_REC};
-                dfs_scan<U8, JB, 2>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 WK_PACC);
+                dfs_scan<U8, JB, 2, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 WK_PACC);
             } else
 #endif
             {
-                dfs_scan<U8, JB>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, pool_l + slot * WK_REC WK_PACC);
+                dfs_scan<U8, JB, DN>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, pool_l + slot * WK_REC WK_PACC);
             }
             wg_order();
             if (lane == 0) {
@@ -1880,6 +1925,124 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     }   // (walk / deferred acceptance)
     __syncthreads();
     if constexpr (!DA) { PROF_STAMP(1); }
+    __shared__ int s_dw, s_dv, s_drej;            // (DN) what the moved orders change in the replica's counters: wait, value, rejects
+    if constexpr (DN) {
+    // ---- dense layout: what MOVED, read off the final stamps.  k_tick_dense has committed every order as if nothing were stolen
+    //      (result, arrival slot, counters); the orders whose answer differs now are the dry ones (dry_bits) and the own-cluster
+    //      orders that picked again (mov_bits).  (1) every idle entry whose stamp names such an order IS that order's vehicle: result
+    //      {vehicle, cost}, arrival (:954-960: its static slot when the arrival stays inside the slot's window, else the ring), the
+    //      entry's stamp in HBM (what the next slot's tick - or k_dense_flush - drops), the counters' difference to what was
+    //      committed; (2) a moved order that holds nothing is unserved now.
+    unsigned *got_bits = clm_bits;
+    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) got_bits[w] = 0u;
+    if (threadIdx.x == 0) { s_dw = 0; s_dv = 0; s_drej = 0; }
+    __syncthreads();
+    {
+        int4 *slog_w = D.slog + (size_t)r * mto;
+        const unsigned *idle32 = reinterpret_cast<const unsigned *>(D.idle);
+        const int total = moff_l[C];
+        int dw = 0, dv = 0, drej = 0;
+        int i = (int)threadIdx.x;
+        while (i < total) {
+            int mi[4], msv[4];
+            int nm = 0;
+            for (; i < total && nm < 4; i += WK_THREADS) {
+                const int sv = (int)st_l[i];
+                if (sv == (int)WK_FREE) continue;
+                if (!(((dry_bits[sv >> 5] | mov_bits[sv >> 5]) >> (sv & 31)) & 1u)) continue;
+                mi[nm] = i; msv[nm] = sv; ++nm;
+            }
+            int mc[4], mpos[4], my[4], mpn[4], mslot[4];
+            unsigned ment[4];
+            int4 mrec[4];
+            int2 mold[4];
+            bool mdry[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mc[u] = 0; mpos[u] = 0; my[u] = tq0; mpn[u] = 0; mslot[u] = -1; ment[u] = 0u; mrec[u] = make_int4(0, 0, 0, 0); mold[u] = make_int2(-1, -1); mdry[u] = false;
+                if (u < nm) {
+                    int lo = 0, hi = C;                          // cluster of stamp index i: the last c with moff_l[c] <= i
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (moff_l[mid] <= mi[u]) lo = mid; else hi = mid; }
+                    // (empty clusters share their start with the next one: the LAST cluster starting at or before i holds it)
+                    mc[u] = lo; mpos[u] = mi[u] - moff_l[lo];
+                    my[u] = tq0 + (int)qr_l[msv[u]];
+                    mdry[u] = (dry_bits[msv[u] >> 5] >> (msv[u] & 31)) & 1u;
+                    ment[u] = idle32[((size_t)mc[u] * S.R + r) * S.idle_cap + mpos[u]];
+                    mrec[u] = S.so_rec[my[u]];
+                    mold[u] = out_r[my[u]];
+                    mpn[u] = S.so_pnode[my[u]];
+                    mslot[u] = S.so_slot[my[u]];
+                }
+            }
+            int mcst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mcst[u] = 0;
+                if (u < nm) {
+                    const int cda = cdA_l[mc[u]];
+                    const int loc = (int)(ment[u] & 0xFFu);
+                    // a dry order that now holds a vehicle of its OWN cluster cannot exist (it searched because that list was
+                    // exhausted for it), so dry = the pickup node's row of the matrix, own = the cluster's block
+                    if (mdry[u]) {
+                        const char *crow = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)mpn[u] * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)mpn[u] * S.N);
+                        mcst[u] = cost_elem<U8>(crow, (unsigned)(((cda >> 11) & 0xFFFF) + loc));
+                    } else {
+                        const int4 cd = S.cdesc[mc[u]];
+                        mcst[u] = cost_elem<U8>(blk_b, (unsigned)((U8 ? cd.z : cd.y) + (mrec[u].y & 0xFFFF) * (cda & 2047) + loc));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nm) continue;
+                const int c = mc[u], sv = msv[u];
+                const int veh = (int)(ment[u] >> 8), cst = mcst[u];
+                if (DA && mdry[u]) {
+                    // (deferred acceptance keeps no log while it runs: the steal's entry {rank, victim cluster | orders of that cluster
+                    // before the thief << 16, ..} for the evaluation pass)
+                    const int qa0 = (c == 0 ? tq0 : qend_l[c - 1]) - tq0;
+                    int a0 = qa0, a1 = qend_l[c] - tq0;
+                    while (a0 < a1) { const int mid = (a0 + a1) >> 1; if ((int)rq_l[mid] < sv) a0 = mid + 1; else a1 = mid; }
+                    const int n = atomicAdd(&s_nlog, 1);
+                    slog_w[n] = make_int4(sv, c | ((a0 - qa0) << 16), (int)(((unsigned)c << 16) | (unsigned)mpos[u]), cst);
+                    atomicAdd(&ls_l[c], 1);
+                }
+                out_r[my[u]] = make_int2(veh, cst);
+                D.stamp[((size_t)c * S.R + r) * S.idle_cap + mpos[u]] = (unsigned short)sv;
+                const int rel = cst + mrec[u].w;
+                const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
+                const int dmin = mrec[u].w <= 0 ? 1 : ticks_until<true>(S, mrec[u].w);
+                const int dl = (int)((unsigned)mrec[u].y >> 16);
+                if (mslot[u] >= 0 && d - dmin <= S.pull_W) D.arr[arr_index(S.R, mslot[u], r)] = pull_entry(veh, t + d);
+                else {
+                    if (mslot[u] >= 0) D.arr[arr_index(S.R, mslot[u], r)] = pull_reject(t);
+                    post_arrival<true, true>(S, D, mrec[u].z & 0xFFFF, r, t, now, veh, mrec[u].x, now + rel, 0, dl);
+                }
+                if (mold[u].x == -1) { drej -= 1; dw += cst; dv += mrec[u].w; }
+                else dw += cst - mold[u].y;
+                atomicOr(&got_bits[sv >> 5], 1u << (sv & 31));
+            }
+        }
+        __syncthreads();
+        // (2) moved orders without a vehicle: committed as matched by k_tick_dense, unserved now
+        for (int rk = (int)threadIdx.x; rk < nord; rk += WK_THREADS) {
+            const unsigned w = (dry_bits[rk >> 5] | mov_bits[rk >> 5]) & ~got_bits[rk >> 5];
+            if (!((w >> (rk & 31)) & 1u)) continue;
+            const int y = tq0 + (int)qr_l[rk];
+            const int2 old = out_r[y];
+            if (old.x == -1) continue;              // (a dry order nobody could serve: committed as a reject already)
+            const int4 rec = S.so_rec[y];
+            const int slot = S.so_slot[y];
+            out_r[y] = make_int2(-1, -1);
+            if (slot >= 0) D.arr[arr_index(S.R, slot, r)] = pull_reject(t);
+            drej += 1; dw -= old.y; dv -= rec.w;
+        }
+        if (dw) atomicAdd(&s_dw, dw);
+        if (dv) atomicAdd(&s_dv, dv);
+        if (drej) atomicAdd(&s_drej, drej);
+    }
+    __syncthreads();
+    }
     // ---- evaluations (:986-991 for the dry orders, :924 for the own-cluster ones), after the fact: with the final own matches
     //      lm of every bucket and the steal log {rank of the thief, cluster | orders of that cluster before the thief << 16},
     //        dry order of rank p:  sum over its visited clusters c of  m0_c - min(k_c(p), lm_c) - #steals from c by ranks < p
@@ -1895,7 +2058,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
         const int4 sl = slog[i];
         const int c = sl.y & 0xFFFF;
         atomicAdd(&tk_l[c], min((int)((unsigned)sl.y >> 16), lm_l[c]));
-        out_r[tq0 + (int)qr_l[sl.x]] = make_int2(sl.z, sl.w);          // the served dry order's result
+        if (!DN) out_r[tq0 + (int)qr_l[sl.x]] = make_int2(sl.z, sl.w);          // the served dry order's result
     }
     PROF_STAMP(29);
     {
@@ -1980,6 +2143,34 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
 #ifdef WKDEBUG
     if (threadIdx.x == 0 && s_dbg != 0x7FFFFFFF && s_ev != s_dbg) printf("k_dfs_walk evals: r %d t %d post-hoc %d walk %d nlog %d\n", r, t, s_ev, s_dbg, nlog);
 #endif
+    if constexpr (DN) {
+        // dense layout: the counters' difference to what k_tick_dense committed (it counted every bucket as if nothing were stolen:
+        // min(k, m0) own matches, evaluations lm0 * m0 - lm0 (lm0 - 1) / 2), the alive counts of the lists that lost more than that,
+        // and HDR_RAW for a list k_tick_dense had left compact
+        int dev = 0;
+        for (int c = threadIdx.x; c < C; c += WK_THREADS) {
+            const int nm = lm_l[c], m0 = m0_l[c], sc = sc_l[c];
+            const int kc = qend_l[c] - (c == 0 ? tq0 : qend_l[c - 1]);
+            const int lm0 = min(kc, m0);
+            dev += (nm * m0 - (nm * (nm - 1)) / 2 - (sc * nm - tk_l[c])) - (lm0 * m0 - (lm0 * (lm0 - 1)) / 2);
+            if (nm != lm0 || sc != 0) {
+                const size_t b = (size_t)c * S.R + r;
+                D.hdr[b * HDR_WORDS + HDR_IDLE] = m0 - nm - sc;
+                D.hdr[b * HDR_WORDS + HDR_RAW] = m0 + 1;
+            }
+        }
+        if (dev) atomicAdd(&s_ev, dev);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long *cnt = D.cnt + (size_t)r * CNT_WORDS;         // (cluster 0's row: the counters are summed over the clusters on read)
+            if (s_drej) cnt[CNT_REJECTS] += s_drej;
+            if (s_dw) cnt[CNT_WAIT] += s_dw;
+            if (s_dv) cnt[CNT_VALUE] += s_dv;
+            if (s_ev) cnt[CNT_EVALS] += s_ev;
+            D.dry[r] = 0;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += WK_THREADS) {
         const int nm = lm_l[c], m0 = m0_l[c], sc = sc_l[c];
         const int ev = nm * m0 - (nm * (nm - 1)) / 2 - (sc * nm - tk_l[c]);
@@ -2192,11 +2383,11 @@ void launch_tick_replica2(const Static &S, const State &D, int t, hipStream_t st
     else hipLaunchKernelGGL(k_tick_replica2<false>, dim3(S.R), dim3(REPL_THREADS), lds, st, S, D, t);
 }
 
-size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, S.walk_pool > 0 ? S.walk_pool : WK_NS_MIN); }
+size_t dfs_walk_lds(const Static &S) { return dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, S.walk_pool > 0 ? S.walk_pool : WK_NS_MIN, S.dense_st); }
 // the record pool: WK_NS records, fewer (down to WK_NS_MIN) when that keeps the walk's workgroup within 40 KB - four per CU
 int dfs_walk_pool(const Static &S) {
     int ns = WK_NS;
-    while (ns > WK_NS_MIN && dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, ns) + 128 > 40 * 1024) --ns;
+    while (ns > WK_NS_MIN && dfs_walk_lds_bytes(S.C, S.V, S.max_tick_orders, ns, S.dense_st) + 128 > 40 * 1024) --ns;
     return ns;
 }
 
@@ -2218,6 +2409,12 @@ void emit_hybrid_walk(const Emit &e, const Static &S0, const State &D, int t, in
     // Static.walk_da: the dry orders by deferred acceptance (VDS_WALK_DA=1; its wavefronts' records and the bitmap of the
     // own-cluster orders that moved live where the walk keeps its record pool)
     const bool da = S.walk_da != 0 && (size_t)(1 + S.walk_pool) * WK_REC >= (size_t)WK_WAVES * WK_G * WK_REC + (size_t)(S.max_tick_orders + 31) / 32 + 1;
+    if (S.dense_st) {
+        // the dense layout's walk (byte costs: vds_api.hip grants the stamp form only then)
+        if (da) emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, true, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, true, true> : k_dfs_walk<true, 4, true, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
+        else emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, false, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, false, true> : k_dfs_walk<true, 4, false, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
+        return;
+    }
     if (da) {
         if (S.u8_ok) emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, true> : k_dfs_walk<true, 4, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
         else emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<false, 1, true> : (S.seq_pad <= 128 ? k_dfs_walk<false, 2, true> : k_dfs_walk<false, 4, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);

@@ -87,6 +87,8 @@ struct DenseArgs {
     // static arrival slots ("pull", vds_device.h)
     unsigned *arr; const int *so_slot; const int2 *d_rec; const int *d_first; const int4 *replica_desc2; int pull_W;
     const int4 *tdesc;               // (one shared day) per-bucket descriptors, Static.tdesc
+    // stamp form (ST: neighbour search on the dense layout, vds_device.h Static.dense_st)
+    unsigned short *stamp; int *dry; const int *so_rank;
     const Static *Sdev; const State *Ddev;
 };
 __device__ __forceinline__ uint2 *ring2(const DenseArgs &D) { return D.ring; }
@@ -267,7 +269,9 @@ __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, i
 // (insert_tick, is_dispatch, id).  An order-carrying far entry due at the NEXT slot is announced in that slot's counter (high
 // half of ring_cnt = SupplyExpect, :880-891).
 // lds_blk: the cluster's cost block in LDS (null: not staged - a bucket without orders)
-template <typename CT>
+// ST (stamp form, see dense_body): the entries taken during the last slot are dropped first (in place), this slot's own matches
+// stamp their entries (State.stamp) instead of removing them, every order scans the list in place.
+template <typename CT, bool ST = false>
 __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r, int t, const CT *blk_g, int nc, const CT *lds_blk) {
     const int lane = lane_id();
     const int p = t & 1;
@@ -283,6 +287,25 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
     const int f = rdlane(hv, HDR_FL);
     const int qin = rdlane(hv, HDR_INBOX0 + p);
     unsigned *idle = reinterpret_cast<unsigned *>(D.idle) + b * S.idle_cap;
+    unsigned short *stamp = ST ? D.stamp + b * S.idle_cap : nullptr;
+    if (ST) {
+        const int rw = rdlane(hv, HDR_RAW);
+        if (rw != 0 && rw - 1 != m) {            // taken entries inside: order-preserving removal (:963), chunk by chunk (targets never lie ahead)
+            const int raw = rw - 1;
+            int newm = 0;
+            for (int base = 0; base < raw; base += WAVE) {
+                const int i = base + lane;
+                const unsigned e = i < raw ? idle[i] : 0u;
+                const bool keep = i < raw && stamp[i] == 0xFFFFu;
+                const unsigned long long kb = ballot(keep);
+                wave_fence();
+                if (keep) idle[newm + popc64(kb & lanemask_lt())] = e;
+                newm += popc64(kb);
+                wave_fence();
+            }
+            // (newm == m: HDR_IDLE counts the entries alive)
+        }
+    }
     int4 *fl = D.fl + b * S.fl_cap;
     const int4 *inb = D.inbox + ((size_t)p * S.C * S.R + b) * S.in_cap;
     const size_t si = (size_t)(t & (S.H - 1)) * S.C * S.R + b;
@@ -399,11 +422,15 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
     m += Atot;
     const int m_pre = m;
     wave_fence();
+    if (ST) {                                     // every entry of the new raw list starts free
+        for (int i = lane; i < m_pre; i += WAVE) stamp[i] = (unsigned short)0xFFFFu;
+        wave_fence();
+    }
     long long wait_sum = 0, value_sum = 0, evals = 0;
     int rejects = 0, navail = m;
     // ---- match (:912-973).  Byte costs and at most 1024 entries: the list in registers, cost block in LDS
     bool done = false;
-    if (sizeof(CT) == 1 && lds_blk != nullptr && k > 0 && m <= 16 * WAVE) {
+    if (!ST && sizeof(CT) == 1 && lds_blk != nullptr && k > 0 && m <= 16 * WAVE) {
         int ws = 0, vs = 0;
         const unsigned char *lb = reinterpret_cast<const unsigned char *>(lds_blk);
         if (m <= 4 * WAVE) m = dense_match_wave<4>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
@@ -425,7 +452,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
                 const int i = base + lane;
                 if (i < m) {
                     const unsigned e = idle[i];
-                    if (e != 0xFFFFFFFFu) {
+                    if (ST ? stamp[i] == 0xFFFFu : e != 0xFFFFFFFFu) {
                         const int cst = (int)row[e & 0xFFu];
                         if (lp < 0 || cst < lc) { lc = cst; lp = i; }
                     }
@@ -437,7 +464,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
             res_veh = (int)(idle[minp] >> 8);
             res_wait = minc;
             wave_fence();
-            if (lane == 0) idle[minp] = 0xFFFFFFFFu;
+            if (lane == 0) { if (ST) stamp[minp] = (unsigned short)S.so_rank[q0 + j]; else idle[minp] = 0xFFFFFFFFu; }
             wave_fence();
             navail--;
             wait_sum += minc;
@@ -457,7 +484,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
     }
     wave_fence();
     // ---- order-preserving compaction (:963)
-    if (!done && navail != m) {
+    if (!ST && !done && navail != m) {
         int newm = 0;
         for (int base = 0; base < m; base += WAVE) {
             const int i = base + lane;
@@ -472,11 +499,15 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
         m = newm;
     }
     if (lane == 0) {
-        hdr[HDR_IDLE] = m;
+        hdr[HDR_IDLE] = ST ? navail : m;
         hdr[HDR_FL] = newf;
         hdr[HDR_INBOX0 + p] = 0;
         hdr[HDR_IDLE_PRE] = m_pre;
         hdr[HDR_ORDERS] = k;
+        if (ST) {
+            hdr[HDR_RAW] = navail != m_pre ? m_pre + 1 : 0;
+            if (k > m_pre && S.dfs_off[c + 1] > S.dfs_off[c]) atomicAdd(&D.dry[r], 1);      // a searching cluster ran dry: k_dfs_walk has work
+        }
     }
     if (k > 0 || Atot > 0) {
         long long *cnt = D.cnt + b * CNT_WORDS;
@@ -554,8 +585,11 @@ __device__ __forceinline__ void merge_arrivals_any(const uint2 *ring, unsigned *
 // the wavefront's largest A; every key is ranked among the A keys (dict insertion order), then the table takes the list chunks
 // and the arrivals behind position m.
 #define DN_TH (DN_TAB / 2)
+// cmp (stamp form): the list's chunks hold entries taken during the last slot - only the slots named by `am` (bit s = e[s]) are
+// written, packed from position wp0 on (the lane's exclusive prefix of alive entries inside its group)
 template <int LPR, int NAP, int J>
-__device__ __forceinline__ void pull_rank_place(const uint2 *ring, unsigned *tab, const int2 *drec, int lg, int m, int Ac, int A, int Amax, unsigned tbase, const unsigned *e) {
+__device__ __forceinline__ void pull_rank_place(const uint2 *ring, unsigned *tab, const int2 *drec, int lg, int m, int Ac, int A, int Amax, unsigned tbase, const unsigned *e,
+                                                bool cmp = false, unsigned am = 0u, int wp0 = 0) {
     unsigned key[NAP], ent[NAP];
     int rank[NAP];
 #pragma unroll
@@ -584,7 +618,12 @@ __device__ __forceinline__ void pull_rank_place(const uint2 *ring, unsigned *tab
     wave_order();          // every key has been read: the table now takes the list
     if (J > 0) {
         const int lbase = lg * J;
-        if (lbase < m) {
+        if (cmp) {
+            int wp = wp0;
+#pragma unroll
+            for (int s = 0; s < (J > 0 ? J : 1); ++s)
+                if ((am >> s) & 1u) { tab[wp] = e[s]; ++wp; }
+        } else if (lbase < m) {
             if (J >= 4) {
 #pragma unroll
                 for (int s = 0; s < J; s += 4) *reinterpret_cast<uint4 *>(tab + lbase + s) = make_uint4(e[s], e[s + 1], e[s + 2], e[s + 3]);
@@ -600,11 +639,12 @@ __device__ __forceinline__ void pull_rank_place(const uint2 *ring, unsigned *tab
     wave_order();
 }
 template <int LPR, int J>
-__device__ __forceinline__ void pull_rank_place_any(const uint2 *ring, unsigned *tab, const int2 *drec, int lg, int m, int Ac, int A, int Amax, unsigned tbase, const unsigned *e) {
-    if (Amax <= LPR) pull_rank_place<LPR, 1, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
-    else if (Amax <= 2 * LPR) pull_rank_place<LPR, 2, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
-    else if (Amax <= 4 * LPR || LPR == 16) pull_rank_place<LPR, 4, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
-    else pull_rank_place<LPR, 8, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e);
+__device__ __forceinline__ void pull_rank_place_any(const uint2 *ring, unsigned *tab, const int2 *drec, int lg, int m, int Ac, int A, int Amax, unsigned tbase, const unsigned *e,
+                                                    bool cmp = false, unsigned am = 0u, int wp0 = 0) {
+    if (Amax <= LPR) pull_rank_place<LPR, 1, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e, cmp, am, wp0);
+    else if (Amax <= 2 * LPR) pull_rank_place<LPR, 2, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e, cmp, am, wp0);
+    else if (Amax <= 4 * LPR || LPR == 16) pull_rank_place<LPR, 4, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e, cmp, am, wp0);
+    else pull_rank_place<LPR, 8, J>(ring, tab, drec, lg, m, Ac, A, Amax, tbase, e, cmp, am, wp0);
 }
 
 // counters of one bucket: lanes 0..7 of a 16- / 8-lane group hold the preloaded words (cntv), 4-lane groups add in place
@@ -630,13 +670,16 @@ __device__ __forceinline__ void store_counters(long long *cnt, int lg, long long
 // 2 lg, 2 lg + 1 as loaded by the prologue (hw); lanes 0 / 1 take the header words, lanes 4 .. 6 add the slot's deltas to the 32-bit
 // counters, and the five lanes store their pairs with one instruction.  Lane 2's words - the far inboxes other buckets add to
 // atomically - and the spare pairs are not written.
-__device__ __forceinline__ void store_record(int *hdr, int lg, int2 hw, int idle, int pre, int orders, int rej, int wsum, int vsum, int evals, int A) {
+// RAW (stamp form): lane 3 writes word HDR_RAW as well (raw: 0 = the list is compact, else 1 + its raw length)
+template <bool RAW = false>
+__device__ __forceinline__ void store_record(int *hdr, int lg, int2 hw, int idle, int pre, int orders, int rej, int wsum, int vsum, int evals, int A, int raw = 0) {
     if (lg == 0) hw = make_int2(idle, pre);
     if (lg == 1) hw.x = orders;
+    if (RAW && lg == 3) hw.x = raw;
     if (lg == 4) { hw.x += orders; hw.y += rej; }
     if (lg == 5) { hw.x += wsum; hw.y += vsum; }
     if (lg == 6) { hw.x += evals; hw.y += A; }
-    if (lg < 2 || (lg >= 4 && lg < 7)) *reinterpret_cast<int2 *>(hdr + 2 * lg) = hw;
+    if (lg < 2 || (RAW && lg == 3) || (lg >= 4 && lg < 7)) *reinterpret_cast<int2 *>(hdr + 2 * lg) = hw;
 }
 
 // Fast path body, specialised on the group width LPR and the table size TS (J = TS / LPR slots per lane).
@@ -658,10 +701,17 @@ __device__ __forceinline__ void store_record(int *hdr, int lg, int2 hw, int idle
 // PER ROW, kmax = the largest k of the wavefront's rows (the match loop runs that long; a row without an order at a step takes
 // nothing), the orders' pickup rows come from `pick` (u16 row offsets into the cost block, [64] per row, written by the prologue)
 // and their records from so_rec in HBM.
-template <int LPR, int TS, typename CT, int DM, bool PULL>
+// ST (stamp form, neighbour search on the dense layout - Static.dense_st): m = the entries ALIVE, m_raw = the list's raw length - the
+// entries taken during the last slot (by own-cluster orders here, by neighbours' dry orders in k_dfs_walk) are still inside and
+// carry the taker's rank in State.stamp; they are dropped while the list passes through the row's table for the arrival merge.
+// This slot's own matches are not removed either: the entries stay where they are, their stamps are written, and the walk - one
+// workgroup per replica, only when a bucket of a searching cluster ran dry (State.dry) - serves the dry orders against them.
+template <int LPR, int TS, typename CT, int DM, bool PULL, bool ST = false>
 __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &D, int t, int now, int q0, int k, int kmax, int qb, const CT *lds_blk, int nc,
                                            const int4 *lds_rec, const unsigned short *pick, unsigned *tab, int r, bool rowvalid, size_t b, size_t si,
-                                           int m, int A, long long cntv, int2 hw, int n, int Aring, const int2 *lds_drec, const int *lds_slot, bool prof, unsigned long long tprev, int pwave) {
+                                           int m, int A, long long cntv, int2 hw, int n, int Aring, const int2 *lds_drec, const int *lds_slot, bool prof, unsigned long long tprev, int pwave,
+                                           int m_raw = 0, bool capable = false, const int *lds_rank = nullptr) {
+    static_assert(!ST || (PULL && DM == 0 && sizeof(CT) == 1 && TS / LPR >= 2), "stamp form: static arrival slots, one shared day, byte costs");
     constexpr int J = TS / LPR;                 // slots per lane
     constexpr bool REC = sizeof(CT) == 1;       // header + counters as one record (store_record)
     constexpr int NL = (J + 3) / 4;             // packed loc registers
@@ -681,7 +731,9 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     unsigned e[J];
 #pragma unroll
     for (int s = 0; s < J; ++s) e[s] = 0u;
-    if (kmax > 0 && lbase < m && !(abl & 2048)) {
+    const bool dl = ST && m_raw != m;                      // this row's list holds entries taken during the last slot
+    const bool anydl = ST && ballot(dl) != 0ull;
+    if ((kmax > 0 || anydl) && lbase < (ST ? m_raw : m) && !(abl & 2048)) {
         if (J >= 4) {
 #pragma unroll
             for (int s = 0; s < J; s += 4) {
@@ -703,18 +755,38 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 #endif
     const unsigned tbase = (unsigned)((t - 32) & 63) << 26;
     const uint2 *ring = ring2(D) + si * S.ring_cap;
-    if (kmax == 0) {
+    // (stamp form) which of the lane's entries are alive: below the raw length and not stamped.  J stamps = J / 2 words per lane
+    unsigned am = 0u;
+    if (ST) {
+        const int nv = min(max(m_raw - lbase, 0), J);
+        am = nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+        if (dl && lbase < m_raw) {
+            const unsigned *sp = reinterpret_cast<const unsigned *>(D.stamp + b * S.idle_cap + lbase);
+            unsigned sw[(J + 1) / 2];
+            if (J >= 8) {
+#pragma unroll
+                for (int s = 0; s < J / 2; s += 4) { const uint4 v = *reinterpret_cast<const uint4 *>(sp + s); sw[s] = v.x; sw[s + 1] = v.y; sw[s + 2] = v.z; sw[s + 3] = v.w; }
+            } else if (J == 4) { const uint2 v = *reinterpret_cast<const uint2 *>(sp); sw[0] = v.x; sw[1] = v.y; }
+            else sw[0] = sp[0];
+            unsigned fm = 0u;
+#pragma unroll
+            for (int s = 0; s < J; ++s) fm |= (((sw[s >> 1] >> ((s & 1) << 4)) & 0xFFFFu) == 0xFFFFu ? 1u : 0u) << s;
+            am &= fm;
+        }
+    }
+    if (kmax == 0 && !anydl) {
         // no order in this (tick, cluster) bucket: the list is not read - the ranked arrivals are appended behind it in HBM
         if (Ntot > 0) {
             if (PULL) pull_rank_place_any<LPR, 0>(ring, tab, lds_drec, lg, 0, A - Aring, A, Ntot, tbase, nullptr);
             else merge_arrivals_any<LPR, 0>(ring, tab, lg, 0, A, Amax, tbase, nullptr);
             if (rowvalid) {
-                for (int idx = lg; idx < A; idx += LPR) idle[m + idx] = tab[idx];
+                for (int idx = lg; idx < A; idx += LPR) { idle[m + idx] = tab[idx]; if (ST) D.stamp[b * S.idle_cap + m + idx] = (unsigned short)0xFFFFu; }
                 if (lg == 0 && (PULL ? Aring : A) > 0) D.ring_cnt[si] = 0;
             }
         }
         if (rowvalid) {
-            if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mnew, mnew, 0, 0, 0, 0, 0, A);
+            if (REC && ST) store_record<true>(D.hdr + b * HDR_WORDS, lg, hw, mnew, mnew, 0, 0, 0, 0, 0, A, 0);
+            else if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mnew, mnew, 0, 0, 0, 0, 0, A);
             else {
                 if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_ORDERS ? 0 : mnew;
                 if (A > 0) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, 0, 0, 0, 0, 0, A);
@@ -723,6 +795,35 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         return;
     }
     // 4. arrivals ranked by dict insertion key; list + arrivals merged in the row's table, merged chunks read back
+    //    (stamp form: the entries taken during the last slot are dropped on the way - the lanes write their ALIVE entries, packed)
+    int fdl = IMAX;                             // (stamp form) first position of the raw list that held a taken entry
+    if (ST && anydl) {
+        const int na = __popc(am);
+        const int wp0 = grp_incl_scan<LPR>(na, lg) - na;
+        const int nv = min(max(m_raw - lbase, 0), J);
+        const unsigned gone = ~am & (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+        fdl = grp_min<LPR>(gone ? lbase + __ffs((int)gone) - 1 : IMAX);
+        if (Ntot > 0) pull_rank_place_any<LPR, J>(ring, tab, lds_drec, lg, m, A - Aring, A, Ntot, tbase, e, true, am, wp0);
+        else {
+            wave_order();
+            int wp = wp0;
+#pragma unroll
+            for (int s = 0; s < J; ++s)
+                if ((am >> s) & 1u) { tab[wp] = e[s]; ++wp; }
+            wave_order();
+        }
+        if (rowvalid && lg == 0 && Aring > 0) D.ring_cnt[si] = 0;
+        if (J >= 4) {
+#pragma unroll
+            for (int s = 0; s < J; s += 4) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(tab + lbase + s);
+                e[s] = v.x; e[s + 1] = v.y; e[s + 2] = v.z; e[s + 3] = v.w;
+            }
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2 *>(tab + lbase);
+            e[0] = v.x; e[1] = v.y;
+        }
+    } else
     if (Ntot > 0) {
         if (PULL) pull_rank_place_any<LPR, J>(ring, tab, lds_drec, lg, m, A - Aring, A, Ntot, tbase, e);
         else merge_arrivals_any<LPR, J>(ring, tab, lg, m, A, Amax, tbase, e);
@@ -798,6 +899,30 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     PROF_STAMP(6);          // match loop
     // 6. order-preserving compaction of the survivors (:963) through the row's table, written back with whole-chunk stores from
     //    the first changed position on
+    int mfin = navail;
+    if (ST) {
+        // stamp form: nothing is removed.  The merged list goes back as it stands - from the first position the load-time packing or
+        // the arrivals changed - and the row's table takes the stamps: free everywhere, then (results loop below) the rank of the
+        // order that took an entry
+        const int fc = A > 0 ? min(fdl, m) : fdl;
+        if (rowvalid && lbase < mnew && lbase + J > fc && !(abl & 2)) {
+            if (J >= 4) {
+#pragma unroll
+                for (int s = 0; s < J; s += 4)
+                    if (lbase + s < mnew && lbase + s + 4 > fc) *reinterpret_cast<uint4 *>(idle + lbase + s) = make_uint4(e[s], e[s + 1], e[s + 2], e[s + 3]);
+            } else {
+                *reinterpret_cast<uint2 *>(idle + lbase) = make_uint2(e[0], e[1]);
+            }
+        }
+        wave_order();
+        if (J >= 4) {
+#pragma unroll
+            for (int s = 0; s < J; s += 4) *reinterpret_cast<uint4 *>(tab + lbase + s) = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+        } else {
+            *reinterpret_cast<uint2 *>(tab + lbase) = make_uint2(0xFFFFu, 0xFFFFu);
+        }
+        wave_order();
+    } else {
     int alive = 0, firstdead = IMAX;
 #pragma unroll
     for (int s = J - 1; s >= 0; --s) {
@@ -806,7 +931,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         firstdead = dead ? lbase + s : firstdead;
     }
     const int incl = grp_incl_scan<LPR>(alive, lg);
-    const int mfin = grp_sum<LPR>(alive);
+    mfin = grp_sum<LPR>(alive);
     int fc = grp_min<LPR>(firstdead);           // first position that changes: the first dead slot (slots behind mnew are dead too) ...
     fc = A > 0 ? min(fc, m) : fc;               // ... or the first appended arrival
     wave_order();
@@ -827,6 +952,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         } else {
             *reinterpret_cast<uint2 *>(idle + lbase) = *reinterpret_cast<const uint2 *>(tab + lbase);
         }
+    }
     }
     PROF_STAMP(7);          // compaction + write-back
     // 7. results (:947-965): vehicle ids through the LDS crossbar, the arrival posts (ring-slot atomic, then the entry)
@@ -853,6 +979,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         }
         const int vid = matched ? (int)(went >> 8) : -1;
         if (has && !(abl & 8)) out_r[j] = make_int2(vid, matched ? wait : -1);
+        if (ST && matched) tab[wpos] = (unsigned)lds_rank[j];          // the entry's stamp: rank of its order inside the slot
         int slot = -1;
         if (PULL) { if (DM == 2) { if (has) slot = S.so_slot[q0 + j]; } else slot = lds_slot[j < k ? j : 0]; }
         if (PULL && slot >= 0) {
@@ -899,9 +1026,27 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
     wsum = grp_sum<LPR>(wsum);
     vsum = grp_sum<LPR>(vsum);
     rej = grp_sum<LPR>(rej);
+    if (ST) {
+        // the stamps of positions [0, mnew) (free behind the list, up to the old raw length: what a reader may look at), and the
+        // replica's count of searching buckets whose orders outran the list: k_dfs_walk has work
+        wave_order();
+        if (rowvalid && lbase < max(mnew, m_raw)) {
+            unsigned pk[(J + 1) / 2];
+#pragma unroll
+            for (int s = 0; s < J; s += 2) pk[s >> 1] = (tab[lbase + s] & 0xFFFFu) | (tab[lbase + s + 1] << 16);
+            unsigned *sp = reinterpret_cast<unsigned *>(D.stamp + b * S.idle_cap + lbase);
+            if (J >= 8) {
+#pragma unroll
+                for (int s = 0; s < J / 2; s += 4) *reinterpret_cast<uint4 *>(sp + s) = make_uint4(pk[s], pk[s + 1], pk[s + 2], pk[s + 3]);
+            } else if (J == 4) *reinterpret_cast<uint2 *>(sp) = make_uint2(pk[0], pk[1]);
+            else sp[0] = pk[0];
+        }
+        if (rowvalid && lg == 0 && capable && k > mnew) atomicAdd(&D.dry[r], 1);
+    }
     // 8. header, counters
     if (rowvalid && !(abl & 16)) {
-        if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mfin, mnew, k, rej, wsum, vsum, evals, A);
+        if (REC && ST) store_record<true>(D.hdr + b * HDR_WORDS, lg, hw, mfin, mnew, k, rej, wsum, vsum, evals, A, mfin != mnew ? mnew + 1 : 0);
+        else if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mfin, mnew, k, rej, wsum, vsum, evals, A);
         else {
             if (lg < 3) D.hdr[b * HDR_WORDS + lg] = lg == HDR_IDLE ? mfin : (lg == HDR_IDLE_PRE ? mnew : k);
             if (!(abl & 32768)) store_counters<LPR>(D.cnt + b * CNT_WORDS, lg, cntv, k, rej, wsum, vsum, evals, A);
@@ -935,9 +1080,11 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 // ROWS: replicas per workgroup - 16, or 32 with one shared day at 8 lanes per replica (256 threads: half the workgroups, the cost
 // block / order records / candidate records staged once for twice the rows, and the prologue's chain of dependent loads - the
 // largest part of the kernel, profiles/r04/r04_ablate_dense.txt - paid once per 32 rows)
-template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS>
+// ST: stamp form - Update + own-cluster matching of the neighbour-search tick on the dense layout (dense_body; Static.dense_st)
+template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS, bool ST = false>
 __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
+    static_assert(!ST || (U8 && DM == 0 && PULL && TABMAX == 128), "stamp form: byte costs, one shared day, static arrival slots, 128-entry tables");
     static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8) || ((ROWS == 8 || ROWS == 4) && DM == 1 && LPR == 16),
                   "32-row workgroups: one shared day, 8 lanes per replica; 8- / 4-row workgroups: one day per workgroup, 16 lanes per replica");
     const DenseArgs &S = P, &D = P;
@@ -955,7 +1102,8 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     //              | per-row tables [16][DN_TAB] u32 | cost block (row stride n_c + 1)
     int4 *lds_rec = reinterpret_cast<int4 *>(lds_dyn);
     int *lds_slot = reinterpret_cast<int *>(lds_rec + (DM == 2 ? DN_ROWS * DN_ORDERS * 2 / 16 : DN_ORDERS));      // (DM == 2: the area holds u16 [16][64] pickup offsets)
-    int2 *lds_drec = reinterpret_cast<int2 *>(lds_slot + (PULL ? DN_ORDERS : 0));
+    int *lds_rank = lds_slot + (PULL ? DN_ORDERS : 0);           // (stamp form) rank of the bucket's orders inside the slot, int[64]
+    int2 *lds_drec = reinterpret_cast<int2 *>(lds_rank + (ST ? DN_ORDERS : 0));
     unsigned *tab_all = reinterpret_cast<unsigned *>(lds_drec + (PULL ? DN_CAND : 0));
     CT *lds_blk = reinterpret_cast<CT *>(tab_all + ROWS * (TABMAX + DN_TPAD));
     // longest-processing-time-first: all replica chunks of the biggest cluster lead the grid
@@ -1068,10 +1216,10 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     const bool mine = stage && (int)threadIdx.x < min(k, DN_ORDERS);
     const bool dmine = PULL && DM != 2 && wg_ok && (int)threadIdx.x < n;
     int4 sblk = make_int4(0, 0, 0, 0), srec = make_int4(0, 0, 0, 0);
-    int sslot = -1;
+    int sslot = -1, srank = 0;
     int2 sdrec = make_int2(0, 0);
     if (stage && (int)threadIdx.x < n4 && !(DN_ABL & 1024)) sblk = blk4[threadIdx.x];
-    if (mine) { srec = S.so_rec[q0 + threadIdx.x]; if (PULL) sslot = S.so_slot[q0 + threadIdx.x]; }
+    if (mine) { srec = S.so_rec[q0 + threadIdx.x]; if (PULL) sslot = S.so_slot[q0 + threadIdx.x]; if (ST) srank = S.so_rank[q0 + threadIdx.x]; }
     if (dmine) sdrec = S.d_rec[clo + threadIdx.x];
 #ifdef DN_PREFETCH
     // the head of the idle list (read after the barrier, once its length is known) touched now: lane lg one word of every 64 bytes
@@ -1111,11 +1259,13 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     asm volatile("" : "+v"(rcw));       // (keeps the mask below out of the branch that issued the load: there it would wait for the word)
     int Aring = rcw & 0xFFFF;
     A = Aring + Ac;           // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
+    int m_raw = 0;                     // (stamp form) raw length of the list: entries taken during the last slot included
     if (U8) {
         // the record's words through the LDS crossbar: idle length (word 0), far list fill (3), this slot's far inbox (4 + p)
         const int gb = (lane & ~(LPR - 1)) << 2;
         m = __builtin_amdgcn_ds_bpermute(gb, hw.x);
         far = __builtin_amdgcn_ds_bpermute(gb + 4, hw.y) | __builtin_amdgcn_ds_bpermute(gb + 8, p ? hw.y : hw.x);
+        if (ST) { const int rw = __builtin_amdgcn_ds_bpermute(gb + 12, hw.x); m_raw = rw ? rw - 1 : m; }       // (word HDR_RAW)
     } else {
         m = h0.x;
         far = h0.w | hin;
@@ -1135,7 +1285,7 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
             if ((int)threadIdx.x < n4) lds4[threadIdx.x] = sblk;
             for (int i = threadIdx.x + NTHR; i < n4; i += NTHR) lds4[i] = blk4[i];
         }
-        if (mine) { lds_rec[threadIdx.x] = srec; if (PULL) lds_slot[threadIdx.x] = sslot; }
+        if (mine) { lds_rec[threadIdx.x] = srec; if (PULL) lds_slot[threadIdx.x] = sslot; if (ST) lds_rank[threadIdx.x] = srank; }
     }
     if (dmine) lds_drec[threadIdx.x] = sdrec;
     if (NTHR < DN_CAND && PULL && DM != 2 && wg_ok)          // (4-row workgroups: more candidates than threads)
@@ -1143,7 +1293,7 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     PROF_STAMP(0);          // scalar loads, header words, candidate entries, staging loads: all arrived
     __syncthreads();
     PROF_STAMP_NW(1);       // barrier
-    const int mnew0 = m + A;
+    const int mnew0 = ST ? max(m + A, m_raw) : m + A;          // (stamp form: the raw list passes through the table as well)
     const bool bad = rowvalid && (!wg_ok || far != 0 || Aring > S.dense_keys || Aring > S.ring_cap || A > DN_TAB || mnew0 > min(S.dense_tab, TABMAX) || mnew0 > S.idle_cap || S.dense_force_slow ||
                                   (PULL && (A - Aring > S.dense_keys * 2 || A > DN_TH)));
 #ifdef VDS_PROF
@@ -1156,24 +1306,70 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     const unsigned long long badrows = ballot(bad && lg == 0);
     if (badrows != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(badrows));      // buckets that leave the fast path: vds_read_work
     if (bad) { rowvalid = false; m = 0; A = 0; Aring = 0; }
+    if (!rowvalid) m_raw = 0;
     const bool any = ballot(rowvalid) != 0;
-    const int mmax = wave_max_of_groups<LPR>(m + A);
+    const int mmax = wave_max_of_groups<LPR>(ST ? max(m + A, m_raw) : m + A);
     PROF_STAMP_NW(2);       // arrival count, row classification
     if (any) {
         const int nn = (wg_ok && rowvalid) ? n : 0;
         const int kr = (DM == 2 && !rowvalid) ? 0 : k;
         const int kmax = DM == 2 ? wave_max_of_groups<LPR>(kr) : k;
         const int2 *drec = DM == 2 ? drec_row : lds_drec;
-        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
-        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
-        else if (TABMAX <= 128 || mmax <= 128) dense_body<LPR, 128, CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        const bool capable = ST && cd.w != 0;               // (stamp form) the cluster has a visit sequence: its unserved orders search (:936)
+        if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
+        else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
+        else if (TABMAX <= 128 || mmax <= 128) dense_body<LPR, 128, CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
         else dense_body<LPR, (TABMAX > 128 ? 256 : 128), CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
         const int l0 = __ffsll((long long)rest) - 1;
-        dense_bucket_slow<CT>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc, (DM == 2 || k > 0) ? lds_blk : (const CT *)nullptr);
+        dense_bucket_slow<CT, ST>(*P.Sdev, *P.Ddev, c, rdlane(r, l0), t, reinterpret_cast<const CT *>(blk_g), nc, (DM == 2 || k > 0) ? lds_blk : (const CT *)nullptr);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_dense_flush (stamp form): IdleVehicles.remove (:963) made physical.  The stamp-form tick leaves the entries it (and the walk)
+// took inside the lists until the next slot's tick reads them; whatever looks at the lists in between - a dispatch hook, the
+// container views, the end of vds_run - first has every bucket with HDR_RAW != 0 packed: one wavefront per bucket, four buckets
+// per workgroup, order kept; the stamps of the packed list are free again, HDR_RAW = 0.
+__global__ __launch_bounds__(256) void k_dense_flush(int *hdr, unsigned *idle_all, unsigned short *stamp_all, int R, int C, int idle_cap, int r_lo, int r_n) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const long long bi = (long long)blockIdx.x * 4 + wave;
+    if (bi >= (long long)C * r_n) return;
+    const int c = (int)(bi / r_n), r = r_lo + (int)(bi % r_n);
+    const size_t b = (size_t)c * R + r;
+    const int rw = hdr[b * HDR_WORDS + HDR_RAW];
+    if (rw == 0) return;
+    const int raw = rw - 1;
+    unsigned *idle = idle_all + b * idle_cap;
+    unsigned short *stamp = stamp_all + b * idle_cap;
+    int newm = 0;
+    for (int base = 0; base < raw; base += WAVE) {
+        const int i = base + lane;
+        const unsigned e = i < raw ? idle[i] : 0u;
+        const bool keep = i < raw && stamp[i] == 0xFFFFu;
+        const unsigned long long kb = ballot(keep);
+        wave_fence();
+        if (keep) idle[newm + popc64(kb & lanemask_lt())] = e;
+        if (i < raw) stamp[i] = (unsigned short)0xFFFFu;
+        newm += popc64(kb);
+        wave_fence();
+    }
+    if (lane == 0) hdr[b * HDR_WORDS + HDR_RAW] = 0;
+}
+
+void emit_dense_flush(const Emit &e, const Static &S, const State &D, int r_lo, int r_n) {
+    if (r_n <= 0) r_n = S.R - r_lo;
+    const long long nb = (long long)S.C * r_n;
+    const dim3 grid((unsigned)((nb + 3) / 4)), block(256);
+    int *hdr = D.hdr; unsigned *idle = reinterpret_cast<unsigned *>(D.idle); unsigned short *stamp = D.stamp;
+    int R = S.R, C = S.C, cap = S.idle_cap;
+    if (!e.graph) { hipLaunchKernelGGL(k_dense_flush, grid, block, 0, e.st, hdr, idle, stamp, R, C, cap, r_lo, r_n); return; }
+    void *args[8] = {&hdr, &idle, &stamp, &R, &C, &cap, &r_lo, &r_n};
+    hipKernelNodeParams p{};
+    p.func = reinterpret_cast<void *>(k_dense_flush); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = args; p.extra = nullptr;
+    *e.err = hipGraphAddKernelNode(e.node, e.graph, e.deps, e.ndeps, &p);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1231,6 +1427,7 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     P.r_lo = r_lo; P.r_hi = r_lo + (r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo); P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
     P.Sdev = S.self_dev; P.Ddev = S.state_dev; P.ring_min = D.ring_min;
     P.tdesc = S.tdesc;
+    P.stamp = D.stamp; P.dry = D.dry; P.so_rank = S.so_rank;
     P.arr = D.arr; P.so_slot = S.so_slot; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
     const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo;
     const bool t256 = dense_tab256(S);
@@ -1242,7 +1439,15 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const dim3 grid(S.C * rchunks);
     const int bb = (S.max_nc * (S.max_nc + 1) * (S.blk8s ? 1 : 4) + 15) / 16 * 16;
     // (one order day per replica: the order-record area holds the rows' pickup offsets instead, u16 [16][64] = 2 KB)
-    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + rows * ((t256 ? 256 : DN_TAB) + DN_TPAD) * 4 + bb;
+    const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + (S.dense_st ? DN_ORDERS * 4 : 0) +
+                       rows * ((t256 ? 256 : DN_TAB) + DN_TPAD) * 4 + bb;
+    if (S.dense_st) {
+        // stamp form (neighbour search; vds_api.hip grants it for byte costs, one shared day, static arrival slots, 128-entry tables)
+        if (rows32) emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, 32, true>, grid, dim3(32 * 8), lds, P, t);
+        else if (S.dense_lpr == 8) emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, DN_ROWS, true>, grid, dim3(DN_ROWS * 8), lds, P, t);
+        else emit_dense(e, k_tick_dense<true, 0, 16, true, DN_TAB, DN_ROWS, true>, grid, dim3(DN_ROWS * 16), lds, P, t);
+        return;
+    }
     if (rows32) {
         emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, 32>, grid, dim3(32 * 8), lds, P, t);
         return;
