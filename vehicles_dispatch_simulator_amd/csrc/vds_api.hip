@@ -1392,7 +1392,7 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
         const int lpr = h->dbg_dense_lpr > 0 ? h->dbg_dense_lpr : env_int("VDS_DENSE_LPR", n_days > 1 ? 16 : DENSE_LPR_DEFAULT);
         S.dense_lpr = (lpr == 8 || lpr == 16) ? lpr : DENSE_LPR_DEFAULT;
         // entries of a bucket the fast path holds: 128; 256 with order days per replica at 16 lanes per replica and byte costs (emit_tick_dense)
-        const int tab_max = (S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0 && !S.dense_st) ? 256 : 128;
+        const int tab_max = (S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0) ? 256 : 128;
         // (another day on the handle: the choice between 8 and 16 lanes per replica is open again, unless the caller fixed it)
         h->dense_adapt = (h->dbg_dense_lpr > 0 || h->dbg_dense_tab > 0 || getenv("VDS_DENSE_LPR") || env_int("VDS_DENSE_ADAPT", 1) == 0) ? -1 : 0;
         h->pin_bucket_ticks = 0;
@@ -1621,7 +1621,7 @@ int vds_num_ticks(const vds_handle *h, int32_t *T) {
 #endif
 static void adapt_dense(vds_handle *h) {
     Static &S = h->S;
-    if (!S.dense || h->dfs_mode || S.n_days > 1 || h->dense_adapt != 0 || !S.blk8s) return;
+    if (!S.dense || (h->dfs_mode && !S.dense_st) || S.n_days > 1 || h->dense_adapt != 0 || !S.blk8s) return;
     if (!h->pin_slow) {
         if (hipHostMalloc((void **)&h->pin_slow, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError(); h->dense_adapt = -1; return;

@@ -1215,24 +1215,23 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     PROF_STAMP(25);
     // ---- stamps: free, or the rank of the own-cluster order the fast kernel gave the entry to (its preliminary result says which)
     if (DN) {
-        // (dense layout) the stamps as k_tick_dense wrote them: one list per wavefront step, eight lists in flight
-        for (int c0 = wave * 8; c0 < C; c0 += 8 * WK_WAVES) {
-            unsigned short sv[8][2];
+        // (dense layout) the stamps as k_tick_dense wrote them: one list per thread, eight 16-byte pieces (64 stamps) in flight
+        for (int c = threadIdx.x; c < C; c += WK_THREADS) {
+            const int m0 = m0_l[c], mo = moff_l[c];
+            const uint4 *sp4 = reinterpret_cast<const uint4 *>(D.stamp + ((size_t)c * S.R + r) * S.idle_cap);
+            for (int i0 = 0; i0 < m0; i0 += 64) {
+                uint4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = min(c0 + u, C - 1);
-                const int m0 = c0 + u < C ? m0_l[c] : 0;
-                const unsigned short *sp = D.stamp + ((size_t)c * S.R + r) * S.idle_cap;
-                sv[u][0] = lane < m0 ? sp[lane] : (unsigned short)0xFFFFu;
-                sv[u][1] = WAVE + lane < m0 ? sp[WAVE + lane] : (unsigned short)0xFFFFu;
-            }
+                for (int u = 0; u < 8; ++u) { v[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); if (i0 + 8 * u < m0) v[u] = sp4[(i0 >> 3) + u]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (c0 + u >= C) break;
-                const int c = c0 + u, m0 = m0_l[c], mo = moff_l[c];
-                if (lane < m0) st_l[mo + lane] = sv[u][0];
-                if (WAVE + lane < m0) st_l[mo + WAVE + lane] = sv[u][1];
-                for (int i = 2 * WAVE + lane; i < m0; i += WAVE) st_l[mo + i] = D.stamp[((size_t)c * S.R + r) * S.idle_cap + i];
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = i0 + 8 * u + e;
+                        if (i < m0) st_l[mo + i] = (unsigned short)(w4[e >> 1] >> ((e & 1) << 4));
+                    }
+                }
             }
         }
     } else {

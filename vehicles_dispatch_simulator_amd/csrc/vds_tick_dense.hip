@@ -168,9 +168,10 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // Match + results + compaction of ONE bucket by the whole wavefront with the list in registers (slow path of k_tick_dense for
 // lists of up to 64 * J entries: beyond the 128-entry tables of the row groups).  Byte costs, cost block in LDS.  Lane l holds
 // positions l*J .. l*J+J-1; candidate key (cost << 10 | position), wave-wide DPP minimum.  Returns the new list length.
-template <int J>
+// ST (stamp form): nothing is removed - the taken entries get their order's rank in `stamp`; returns the entries still alive.
+template <int J, bool ST = false>
 __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, int now, int m, int q0, int k, const unsigned char *lds_blk, int nc,
-                                unsigned *idle, int &wait_sum, int &value_sum, long long &evals, int &rejects) {
+                                unsigned *idle, int &wait_sum, int &value_sum, long long &evals, int &rejects, unsigned short *stamp = nullptr) {
     constexpr int NL = J / 4;
     const int lane = lane_id();
     const int lbase = lane * J;
@@ -197,8 +198,8 @@ __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, i
     for (int base = 0; base < k; base += WAVE) {
         const int kk = min(WAVE, k - base);
         int4 rec = make_int4(0, 0, 0, 0);
-        int slot = -1;
-        if (lane < kk) { rec = S.so_rec[q0 + base + lane]; if (S.pull) slot = S.so_slot[q0 + base + lane]; }
+        int slot = -1, rank = 0;
+        if (lane < kk) { rec = S.so_rec[q0 + base + lane]; if (S.pull) slot = S.so_slot[q0 + base + lane]; if (ST) rank = S.so_rank[q0 + base + lane]; }
         int res = IMAX;
         for (int j = 0; j < kk; ++j) {
             const int p = rdlane(rec.y, j) & 0xFFFF;
@@ -228,6 +229,7 @@ __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, i
             went = (wpos % J) == s ? got : went;
         }
         const int vid = matched ? (int)(went >> 8) : -1;
+        if (ST && matched) stamp[wpos] = (unsigned short)rank;
         if (has) {
             out_r[q0 + base + lane] = make_int2(vid, matched ? wait : -1);
             if (slot >= 0) {            // static arrival slot
@@ -240,6 +242,7 @@ __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, i
         value_sum += wave_sum_i32(matched ? rec.w : 0);
         rejects += wave_sum_i32((has && !matched) ? 1 : 0);
     }
+    if (ST) return navail;
     // order-preserving compaction (:963): survivors from the first taken position on
     int alive = 0, firstdead = IMAX;
 #pragma unroll
@@ -430,13 +433,15 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
     int rejects = 0, navail = m;
     // ---- match (:912-973).  Byte costs and at most 1024 entries: the list in registers, cost block in LDS
     bool done = false;
-    if (!ST && sizeof(CT) == 1 && lds_blk != nullptr && k > 0 && m <= 16 * WAVE) {
+    if (sizeof(CT) == 1 && lds_blk != nullptr && k > 0 && m <= 16 * WAVE) {
         int ws = 0, vs = 0;
         const unsigned char *lb = reinterpret_cast<const unsigned char *>(lds_blk);
-        if (m <= 4 * WAVE) m = dense_match_wave<4>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
-        else if (m <= 8 * WAVE) m = dense_match_wave<8>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
-        else m = dense_match_wave<16>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects);
-        wait_sum = ws; value_sum = vs; navail = m;
+        int left;
+        if (m <= 4 * WAVE) left = dense_match_wave<4, ST>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects, stamp);
+        else if (m <= 8 * WAVE) left = dense_match_wave<8, ST>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects, stamp);
+        else left = dense_match_wave<16, ST>(S, D, r, t, now, m, q0, k, lb, nc, idle, ws, vs, evals, rejects, stamp);
+        wait_sum = ws; value_sum = vs; navail = left;
+        if (!ST) m = left;
         done = true;
     }
     // ... otherwise every order scans the list in place; a taken entry is marked 0xFFFFFFFF and skipped from then on
@@ -1084,7 +1089,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 template <bool U8, int DM, int LPR, bool PULL, int TABMAX = DN_TAB, int ROWS = DN_ROWS, bool ST = false>
 __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR == 16 ? DN_MIN_WAVES16 : (LPR == 8 ? DN_MIN_WAVES8 : DN_MIN_WAVES4))) void k_tick_dense(DenseArgs P, int t) {
     static_assert(TABMAX == 128 || (TABMAX == 256 && LPR == 16 && U8), "256-entry tables: 16 lanes per replica, byte costs");
-    static_assert(!ST || (U8 && DM == 0 && PULL && TABMAX == 128), "stamp form: byte costs, one shared day, static arrival slots, 128-entry tables");
+    static_assert(!ST || (U8 && DM == 0 && PULL), "stamp form: byte costs, one shared day, static arrival slots");
     static_assert(ROWS == DN_ROWS || (ROWS == 32 && DM == 0 && LPR == 8) || ((ROWS == 8 || ROWS == 4) && DM == 1 && LPR == 16),
                   "32-row workgroups: one shared day, 8 lanes per replica; 8- / 4-row workgroups: one day per workgroup, 16 lanes per replica");
     const DenseArgs &S = P, &D = P;
@@ -1319,7 +1324,7 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
         if (mmax <= 32) dense_body<LPR, 32, CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
         else if (mmax <= 64) dense_body<LPR, 64, CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
         else if (TABMAX <= 128 || mmax <= 128) dense_body<LPR, 128, CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
-        else dense_body<LPR, (TABMAX > 128 ? 256 : 128), CT, DM, PULL>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave);
+        else dense_body<LPR, (TABMAX > 128 ? 256 : 128), CT, DM, PULL, ST>(S, D, t, now, q0, kr, kmax, qb, lds_blk, nc, lds_rec, pick, tab, r, rowvalid, b, si, m, A, cntv, hw, nn, Aring, drec, lds_slot, prof, tprev, pwave, m_raw, capable, lds_rank);
     }
     // the rows set aside above, one after the other, all 64 lanes on one bucket
     for (unsigned long long rest = badrows; rest; rest &= rest - 1) {
@@ -1442,8 +1447,9 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     const size_t lds = (S.n_days > 1 && !S.chunk_days ? DN_ROWS * DN_ORDERS * 2 : DN_ORDERS * 16) + (S.pull ? DN_ORDERS * 8 + DN_CAND * 8 : 0) + (S.dense_st ? DN_ORDERS * 4 : 0) +
                        rows * ((t256 ? 256 : DN_TAB) + DN_TPAD) * 4 + bb;
     if (S.dense_st) {
-        // stamp form (neighbour search; vds_api.hip grants it for byte costs, one shared day, static arrival slots, 128-entry tables)
-        if (rows32) emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, 32, true>, grid, dim3(32 * 8), lds, P, t);
+        // stamp form (neighbour search; vds_api.hip grants it for byte costs, one shared day, static arrival slots)
+        if (t256) emit_dense(e, k_tick_dense<true, 0, 16, true, 256, DN_ROWS, true>, grid, dim3(DN_ROWS * 16), lds, P, t);
+        else if (rows32) emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, 32, true>, grid, dim3(32 * 8), lds, P, t);
         else if (S.dense_lpr == 8) emit_dense(e, k_tick_dense<true, 0, 8, true, DN_TAB, DN_ROWS, true>, grid, dim3(DN_ROWS * 8), lds, P, t);
         else emit_dense(e, k_tick_dense<true, 0, 16, true, DN_TAB, DN_ROWS, true>, grid, dim3(DN_ROWS * 16), lds, P, t);
         return;
