@@ -635,7 +635,7 @@ def main():
             fallbacks["configs[1] wide layout, row-mapped kernel (force_generic 5: clusters above 255 nodes, V >= 2^24, costs beyond the dense keys)"] = leg(w, R, 5, 3)
             fallbacks["configs[1] generic kernel, one wavefront per bucket (force_generic 1: costs >= 2^23 or above the pickup window)"] = leg(w, R, 1, 2)
             fallbacks["configs[1] dense tick with the arrival ring instead of static arrival slots (VDS_DENSE_PULL=0)"] = leg(w, R, 0, 3, {"VDS_DENSE_PULL": "0"})
-            fallbacks["configs[3] hybrid tick with deferred acceptance (VDS_WALK_DA=1)"] = leg(w4f, R, 0, 2, {"VDS_WALK_DA": "1"})
+            fallbacks["configs[3] hybrid tick on the wide layout (VDS_DENSE_DFS=0: order days per replica, costs beyond a byte, orders without a static arrival slot)"] = leg(w4f, R, 0, 2, {"VDS_DENSE_DFS": "0"})
             fallbacks["configs[3] lower-bound rounds (force_generic 3: visit sequences over 256 clusters, costs >= 2^15)"] = leg(w4f, R, 3, 2)
             fallbacks["configs[3] serial reference form (force_generic 1), 128 replicas"] = leg(w4f, 128, 1, 1)
         except Exception as e:       # (a reported extra)

@@ -71,9 +71,6 @@ def test_self_checking_walk_build():
     out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)])
     assert "k_dfs_dense" in out
     assert "check" not in out.replace("vds_debug_check", ""), out[-3000:]
-    # (the deferred-acceptance form has no walk that could count the evaluations a second time: its bounds checks only)
-    out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 5, 90, None)], VDS_WALK_DA="1")
-    assert "k_dfs_dense_da" in out and "check" not in out.replace("vds_debug_check", ""), out[-3000:]
     # the same on the wide layout (k_tick_rows in stamp mode + the committing walk)
     out = run_worker(lib, "+dbg", [(True, 0, 8, 40, None), (True, 0, 5, 90, None)], VDS_DENSE_DFS="0")
     assert "k_dfs_hybrid" in out and "check" not in out.replace("vds_debug_check", ""), out[-3000:]
@@ -85,10 +82,10 @@ def test_guarded_build_all_tick_paths():
              (False, 1, 5, 150, None), (False, 5, 37, 150, None), (True, 0, 9, 40, None), (True, 3, 6, 40, None), (True, 1, 3, 40, None)]
     out = run_worker(lib, "+canary", cases)
     assert out.count("ok ") == len(cases)
-    # the hybrid tick with the dry orders by deferred acceptance: scarce vehicles, most orders dry
+    # neighbour search with scarce vehicles - most orders dry - on both layouts
     da = [(True, 0, 9, 40, None), (True, 0, 37, 25, None), (True, 0, 5, 90, None)]
-    out = run_worker(lib, "+canary", da, VDS_WALK_DA="1")
-    assert out.count("ok ") == len(da) and out.count("k_dfs_dense_da") == len(da)
+    out = run_worker(lib, "+canary", da)
+    assert out.count("ok ") == len(da) and out.count("k_dfs_dense") == len(da)
     out = run_worker(lib, "+canary", da[:2], VDS_DENSE_DFS="0")
     assert out.count("ok ") == 2 and out.count("k_dfs_hybrid") == 2
 

@@ -23,20 +23,20 @@ def check(city, depth, V, O, oseed, R, init, pick=None, dele=None, kernel0="k_df
     off, idx = neighbors_to_csr(city.neighbors)
     results = {}
     import os
-    # mode 7: the dry orders served by deferred acceptance (VDS_WALK_DA=1, read when the orders are loaded); 8 / 9: the hybrid tick on the
-    # WIDE layout (VDS_DENSE_DFS=0, read when the static tables are loaded: k_tick_rows in stamp mode + the committing walk), serial / DA
-    switches = {7: {"VDS_WALK_DA": "1"}, 8: {"VDS_DENSE_DFS": "0"}, 9: {"VDS_DENSE_DFS": "0", "VDS_WALK_DA": "1"}}
-    extra = (7, 8, 9) if kernel0 == "k_dfs_dense" else ((7,) if kernel0 == "k_dfs_hybrid" else ())
+    # mode 8: the hybrid tick on the WIDE layout (VDS_DENSE_DFS=0, read when the static tables are loaded: k_tick_rows in stamp mode + the
+    # committing walk) - what the library keeps for order days per replica, costs beyond a byte, orders without a static arrival slot
+    switches = {8: {"VDS_DENSE_DFS": "0"}}
+    extra = (8,) if kernel0 == "k_dfs_dense" else ()
     for mode in (0, 3, 1) + extra:
         os.environ.update(switches.get(mode, {}))
         try:
             env = BatchedDispatchEnv(city.cost, city.node2cluster, off, idx, replicas=R, vehicles=V, depth_limit=depth,
-                                     neighbor_can_server=True, force_generic=0 if mode >= 7 else mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
+                                     neighbor_can_server=True, force_generic=0 if mode == 8 else mode, idle_cap=min(1024, max(64, V)), ring_cap=max(64, V), far_cap=max(64, V), **kw)
             env.load_orders(rel, pick, dele)
         finally:
             for k in switches.get(mode, {}):
                 os.environ.pop(k, None)
-        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs", 7: kernel0 + "_da", 8: "k_dfs_hybrid", 9: "k_dfs_hybrid_da"}[mode]
+        assert env.main_kernel() == {0: kernel0, 3: "k_tick_replica2", 1: "k_match_dfs", 8: "k_dfs_hybrid"}[mode]
         env.reset(init)
         env.run(env.T)
         results[mode] = (env.orders(), env.counters(), env.obs(), [env.lists(r) for r in range(R)])

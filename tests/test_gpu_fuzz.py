@@ -107,17 +107,17 @@ def run_case(seed, case, idle_cap=None):
     fg, kw = cfg["force_generic"], {}
     if fg == 0:
         kw["dense_debug"] = (int(lr.choice([16, 8])), int(lr.choice([0, 0, 8, 24, 40])), int(lr.choice([0, 0, 2, 5])), int(lr.random() < 0.1) | (2 if lr.random() < 0.3 else 0))
-    env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
-                             tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
-                             force_generic=fg, idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V), **kw)
-    # half of the cases with neighbour search on the default kernels: the hybrid tick's dry orders by deferred acceptance (VDS_WALK_DA=1,
-    # read when the orders are loaded) instead of the serial walk
-    if fg == 0 and cfg["neighbor"] and lr.random() < 0.5:
-        os.environ["VDS_WALK_DA"] = "1"
+    # a third of the cases with neighbour search on the default kernels keep the WIDE layout (VDS_DENSE_DFS=0, read when the static tables
+    # are loaded: k_tick_rows in stamp mode + the committing walk) instead of the dense layout's stamp form
+    if fg == 0 and cfg["neighbor"] and lr.random() < 0.34:
+        os.environ["VDS_DENSE_DFS"] = "0"
     try:
+        env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
+                                 tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
+                                 force_generic=fg, idle_cap=idle_cap or max(64, V), ring_cap=max(16, V), far_cap=max(64, V), **kw)
         env.load_orders(rel, pick, dele)
     finally:
-        os.environ.pop("VDS_WALK_DA", None)
+        os.environ.pop("VDS_DENSE_DFS", None)
     env.reset(init)
     oracles = []
     for r in range(R):

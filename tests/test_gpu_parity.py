@@ -19,7 +19,7 @@ TINY = golden_names("tiny_")
 
 def make_env(g, R, **kw):
     environ = kw.pop("environ", None)
-    if environ:       # library switches read when the order tables are loaded (e.g. VDS_WALK_DA=0: the serial walk of rounds 2-4)
+    if environ:       # library switches read when the order tables are loaded (e.g. VDS_DENSE_DFS=0: neighbour search on the wide layout)
         import os
         saved = {k: os.environ.get(k) for k in environ}
         os.environ.update(environ)
@@ -163,12 +163,10 @@ MODES = {
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
     "dfs_v2": {"force_generic": 3},          # neighbour search by lower-bound rounds (k_tick_replica2: what the hybrid tick falls back to)
-    "dfs_da": {"environ": {"VDS_WALK_DA": "1"}},        # the dry orders served by deferred acceptance instead of the serial walk
     # neighbour search on the WIDE layout (k_tick_rows in stamp mode + the committing k_dfs_walk of rounds 2-5): what the library keeps for
     # order days per replica, costs beyond a byte, orders without a static arrival slot; the default since round 6 is the dense layout
     # (k_tick_dense in stamp form + the walk writing only what moved: "fast" on a searching fixture)
     "dfs_wide": {"environ": {"VDS_DENSE_DFS": "0"}},
-    "dfs_wide_da": {"environ": {"VDS_DENSE_DFS": "0", "VDS_WALK_DA": "1"}},
     # dense tick (k_tick_dense: the default without neighbour search; 8 lanes per replica by default) - 16 lanes per replica; tiny fast-path tables
     # (buckets that outgrow them take dense_bucket_slow); slow path only; far tables.  With neighbour search or a live pickup
     # window the library keeps the wide layout (these fixtures then repeat the default run).
@@ -195,7 +193,7 @@ DENSE = [m for m in MODES if m.startswith("dense")]
 # every mode on a representative handful of fixtures; the default kernels, the generic kernels and the far path on all of them
 # (the full product was 17 modes x 19 fixtures: most of the GPU suite's run time for pairs that add no new path)
 ALL_MODES_ON = ("tiny_kmeans", "tiny_grid", "tiny_dispatch", "tiny_sort_ties", "tiny_fraccost", "tiny_kmeans_dfs2", "tiny_dispatch_dfs2", "tiny_window4_dfs2")
-BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dfs_da", "dfs_wide", "dense16", "ring64")
+BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dfs_wide", "dense16", "ring64")
 
 
 def _applies(name, mode):

@@ -610,8 +610,8 @@ void vds_config_init(vds_config *cfg) {
 const char *vds_main_kernel(const vds_handle *h) {
     if (!h || !h->have_orders) return "";
     if (!h->dfs_mode) return h->S.dense ? "k_tick_dense" : (h->S.fast_ok ? "k_tick_rows" : "k_tick");
-    if (h->hybrid_ok && h->cfg.force_generic == 0 && h->S.dense_st) return h->S.walk_da ? "k_dfs_dense_da" : "k_dfs_dense";      // (k_tick_dense in stamp form + k_dfs_walk on the dense layout)
-    if (h->hybrid_ok && h->cfg.force_generic == 0) return h->S.walk_da ? "k_dfs_hybrid_da" : "k_dfs_hybrid";      // (deferred acceptance / the serial walk)
+    if (h->hybrid_ok && h->cfg.force_generic == 0 && h->S.dense_st) return "k_dfs_dense";       // (k_tick_dense in stamp form + k_dfs_walk on the dense layout)
+    if (h->hybrid_ok && h->cfg.force_generic == 0) return "k_dfs_hybrid";                        // (k_tick_rows in stamp mode + the committing k_dfs_walk)
     if (h->dfs2_ok && h->cfg.force_generic != 1) return "k_tick_replica2";
     return "k_match_dfs";
 }
@@ -1542,9 +1542,6 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
         // hybrid tick: the fast kernel's preconditions (packed keys, no live pickup window, every cost block in LDS), one
         // order day per workgroup, 16-bit ranks / positions / columns, the walk's LDS footprint
         h->S.walk_pool = 0; h->S.walk_pool = dfs_walk_pool(h->S);
-        // the dry orders of the hybrid tick: served by the serial walk (default) or by deferred acceptance (VDS_WALK_DA=1: exact,
-        // measured 3 % slower at configs[3] - DESIGN.md 8.5 says why - and kept as a second, independent statement for the tests)
-        { const char *v = getenv("VDS_WALK_DA"); h->S.walk_da = (v && *v == '1') ? 1 : 0; }
         h->hybrid_ok = h->dfs_mode && h->cfg.force_generic == 0 && Z.fast_ok && Z.max_nc * Z.max_nc <= h->lds_ints &&
                        Z.max_tick_orders < 65535 && Z.V < 65536 && Z.max_nc <= 2047 &&
                        Z.N <= 65534 && Z.C <= 65535 && Z.idle_cap <= 16384 && h->cost_max < (1 << 15) && h->max_seq <= 256 &&

@@ -127,8 +127,6 @@ struct Static {
     const int *ord_q;                // [Oq] processed orders in id order -> q
     const int *so_pnode;             // [Oq] pickup NODE of each sorted order (row of the cost matrix the DFS scans)
     int walk_pool;                   // scan records in k_dfs_walk's LDS pool (8..32)
-    int walk_da;                     // 1 (VDS_WALK_DA=1 at vds_load_orders*): k_dfs_walk serves the dry orders by deferred acceptance, all wavefronts
-                                     // proposing (round 5: exact, 3 % slower at configs[3]); 0 (default): the serial walk of rounds 2-4
     const unsigned *so_vis;          // [Oq][seq_pad] j-th cluster of the sorted order's visit sequence | orders of that cluster of the same slot with a smaller id << 16 (0xFFFFFFFF past the end; nullable)
     const unsigned char *so_lb;      // [Oq][seq_pad] lbc[pickup node of the sorted order][j-th cluster of its visit sequence] (nullable)
     int seq_pad;                     // longest visit sequence, rounded up to a multiple of 64

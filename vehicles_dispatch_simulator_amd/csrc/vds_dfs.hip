@@ -1116,14 +1116,15 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
 }
 
 // JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
-// DA: the dry orders are served by DEFERRED ACCEPTANCE (round 5) instead of the serial walk: see the branch below.
+// (Round 5's deferred-acceptance form of the walk - exact, never faster; round 6's form of it with eight scans per wavefront likewise -
+// left the library in round 6: profiles/r05/, profiles/r06/gs_experiment.md hold the measurements and the last source.)
 // DN: neighbour search on the DENSE layout (round 6; Static.dense_st).  The first half is k_tick_dense in stamp form, which - unlike
 //     k_tick_rows' - COMMITS what it does: results with vehicle ids, static arrival slots, counters, the entries' stamps in HBM
 //     (State.stamp); nothing is left for a per-replica commit.  This kernel then returns at once unless a searching bucket of the
 //     replica ran dry (State.dry); otherwise it loads the stamps, serves the dry orders as before and writes out only what MOVED:
 //     the served dry orders and the own-cluster orders whose vehicle was stolen (result, arrival slot / ring post, stamp, counter
 //     deltas, the lists' alive counts).  The lists themselves are packed by the next slot's tick (or k_dense_flush).
-template <bool U8, int JB, bool DA = false, bool DN = false>
+template <bool U8, int JB, bool DN = false>
 __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S, State D, int t) {
     extern __shared__ int lds_dyn[];
     const char *blk_b = U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk);
@@ -1263,311 +1264,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     //      records are made by wavefronts 1..3, which scan the dry orders up to WK_NS ahead of the walk, in rank order, claiming
     //      them through s_cursor (dfs_scan: why a scan against a moving state is exact).  Wavefront 0 scans itself only when
     //      every kept candidate has died, or when a redo made an order dry that the cursor had already passed.
-    if constexpr (DA) {
-    // ---- DEFERRED ACCEPTANCE instead of the walk.  MatchFunction (:900-975) is a serial dictatorship: orders in id order, each takes
-    //      its favourite among the vehicles still idle - own cluster first (:924-933), the visit sequence of
-    //      FindServerVehicleFunction (:978-996) only once the own cluster is empty (:936).  Every vehicle "ranks" the orders the
-    //      same way (by id), so that outcome is the UNIQUE stable matching, and order-proposing deferred acceptance reaches it
-    //      whatever the order of the proposals (profiles/r05/da_prototype.py: checked against the oracle tick by tick):
-    //        stamp[e]   = lowest rank that has proposed to entry e so far (it only ever decreases);
-    //        an order   proposes to the first entry of its preference list with stamp > its rank (one LDS compare-and-swap); the
-    //                   holder it displaces - a later order - proposes again: an own-cluster order to the next entry of its cluster
-    //                   alive for it (own_chain; exhausted in a searching cluster: it turns dry), a dry order after a new scan.
-    //      The stamp-mode kernel left exactly such an intermediate state (own matches as if nothing were stolen; the dry orders
-    //      have not proposed yet).  So there is NO serial chain any more: all four wavefronts take dry orders (lowest rank first,
-    //      the bucket's next dry order with it: one scan for both), scan, propose, and run the displaced holder's re-pick chain
-    //      inline; nothing is written to HBM meanwhile - when no order is left without an answer, the moved orders' results and the
-    //      steal log are read off the final stamps (one pass over the entries).
-    unsigned *scn_bits = clm_bits;                                                    // dry orders waiting for a scan
-    unsigned *recs_l = slot_l;                                                        // WK_WAVES x WK_G records: each wavefront's own
-    unsigned *chg_bits = DN ? mov_bits : slot_l + WK_WAVES * WK_G * WK_REC;           // own-cluster orders that proposed again
-    __shared__ int s_busy;                                                            // wavefronts inside a task
-    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) { scn_bits[w] = dry_bits[w]; chg_bits[w] = 0u; }
-    if (threadIdx.x == 0) s_busy = 0;
-    __syncthreads();
     {
-        // one lane: stamp[idx] = min(stamp[idx], rank) on the u16 inside its 32-bit word; the previous stamp if that lowered it, else -1
-        auto cas_min = [&](int idx, int rank) -> int {
-            unsigned *wp = reinterpret_cast<unsigned *>(st_l) + (idx >> 1);
-            const int sh = (idx & 1) << 4;
-            unsigned old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (true) {
-                const int f = (int)((old >> sh) & 0xFFFFu);
-                if (f <= rank) return -1;
-                const unsigned nw = (old & ~(0xFFFFu << sh)) | ((unsigned)rank << sh);
-                if (__hip_atomic_compare_exchange_strong(wp, &old, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return f;
-            }
-        };
-        auto bit_of = [&](const unsigned *bits, int rk) -> bool { return ((unsigned)lds_load(reinterpret_cast<const int *>(&bits[rk >> 5])) >> (rk & 31)) & 1u; };
-        // own-cluster order a of bucket wcl lost its vehicle to an earlier order: it picks again among the entries alive for it
-        // (stamp > a); if that entry was held by a later own-cluster order, that one picks again, ... until a free entry is taken,
-        // a dry holder is displaced (it scans again) or the list is exhausted - then the order turns dry (searching cluster) or is
-        // rejected, and the bucket has one own match less (what the evaluation pass reads from ls_l)
-        auto own_chain = [&](int a, int wcl) {
-            const int cda = cdA_l[wcl];
-            const int nc = cda & 2047;
-            const bool capable = (cda & CAPABLE) != 0;
-            const int4 cd = S.cdesc[wcl];
-            const int boff = U8 ? cd.z : cd.y;
-            const int m0 = m0_l[wcl], mo = moff_l[wcl];
-            const size_t ibase = ((size_t)wcl * S.R + r) * S.idle_cap;
-            unsigned yv0 = 0u;
-            if (m0 <= WAVE && lane < m0) yv0 = idle_loc<DN>(D, ibase + lane);          // (travels together with the order's record below)
-            int pick = -1;
-            while (true) {
-                if (pick < 0) {
-                    if (lane == 0) atomicOr(&chg_bits[a >> 5], 1u << (a & 31));
-                    pick = S.so_rec[tq0 + (int)qr_l[a]].y & 0xFFFF;
-                }
-                int lc = IMAX, lp = -1;
-                if (m0 <= WAVE) {
-                    if (lane < m0 && (int)st_l[mo + lane] > a) { lc = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + (int)(yv0 & 0xFFFF))); lp = lane; }
-                } else {
-                    for (int base = 0; base < m0; base += WAVE) {
-                        const int ii = base + lane;
-                        if (ii < m0 && (int)st_l[mo + ii] > a) {
-                            const int lo2 = (int)idle_loc<DN>(D, ibase + ii);
-                            const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
-                            if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
-                        }
-                    }
-                }
-                const int minc = wave_min_i32(lp >= 0 ? lc : IMAX);
-                if (minc == IMAX) {
-                    if (lane == 0) {
-                        atomicAdd(&ls_l[wcl], -(1 << 16));
-                        if (capable) { atomicOr(&dry_bits[a >> 5], 1u << (a & 31)); wg_order(); atomicOr(&scn_bits[a >> 5], 1u << (a & 31)); }
-                    }
-                    break;
-                }
-                const int minp = wave_min_i32((lp >= 0 && lc == minc) ? lp : IMAX);
-                int f = 0;
-                if (lane == 0) f = cas_min(mo + minp, a);
-                f = __builtin_amdgcn_readfirstlane(f);
-                if (f < 0) continue;                                   // an earlier order took it meanwhile: look again
-                if (f == (int)WK_FREE) break;
-                if (bit_of(dry_bits, f)) {                             // a thief from another cluster held it: it scans again
-                    if (lane == 0) atomicOr(&scn_bits[f >> 5], 1u << (f & 31));
-                    break;
-                }
-                a = f; pick = -1;                                      // a later own-cluster order of this bucket: its turn
-            }
-        };
-        unsigned *myrec = recs_l + wave * (WK_G * WK_REC);
-#ifdef VDS_PROF
-        unsigned long long d_idle = 0, d_chain = 0, d_scan = 0, d_prop = 0, d_claim = 0, d_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned long long d_nscan = 0, d_nord = 0, d_nreq = 0, d_nchain = 0, d_nbump = 0, d_ts = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-#define DSEG(acc) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - d_ts; d_ts = t_; } } while (0)
-#define DCNT(c) do { c += 1; } while (0)
-#define DADD(c, n) do { c += (n); } while (0)
-#define DA_PACC , prof ? d_acc : nullptr
-#else
-#define DSEG(acc) do { } while (0)
-#define DCNT(c) do { } while (0)
-#define DADD(c, n) do { } while (0)
-#define DA_PACC
-#endif
-        while (true) {
-            // the dry order of the lowest rank that waits for a scan
-            int b = IMAX;
-            for (int w0 = 0; w0 < nwords && b == IMAX; w0 += WAVE) {
-                const int w = w0 + lane;
-                const unsigned bits = w < nwords ? (unsigned)lds_load(reinterpret_cast<const int *>(&scn_bits[w])) : 0u;
-                const unsigned long long nz = ballot(bits != 0u);
-                if (nz != 0ull) { const int l = __ffsll((long long)nz) - 1; b = (w0 + l) * 32 + __ffs(rdlane((int)bits, l)) - 1; }
-            }
-            if (b == IMAX) {
-                // nothing waits: done once no wavefront is inside a task either (a task publishes what it spawns BEFORE it
-                // leaves - s_busy is raised before the order's bit is cleared, lowered after the last bit is set - so "no bit set,
-                // nobody busy, still no bit set" is final)
-                if (lds_acquire(&s_busy) == 0) {
-                    bool any = false;
-                    for (int w = lane; w < nwords; w += WAVE) any |= lds_load(reinterpret_cast<const int *>(&scn_bits[w])) != 0;
-                    if (ballot(any) == 0ull) break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                DSEG(d_idle);
-                continue;
-            }
-            int won = 0;
-            if (lane == 0) {
-                atomicAdd(&s_busy, 1);
-                wg_order();
-                won = (int)((atomicAnd(&scn_bits[b >> 5], ~(1u << (b & 31))) >> (b & 31)) & 1u);
-                if (!won) atomicAdd(&s_busy, -1);
-            }
-            won = __builtin_amdgcn_readfirstlane(won);
-            if (!won) continue;
-            const int q = tq0 + (int)qr_l[b];
-            // the bucket's next orders (consecutive sorted positions, ascending ranks; dry as well if they wait) share the scan
-            int rk[WK_G], pn[WK_G];
-            int g = 1;
-            rk[0] = b;
-#pragma unroll
-            for (int o = 0; o < WK_G; ++o) pn[o] = S.so_pnode[min(q + o, tq1 - 1)];      // (first needed by the cost gathers: in flight under the visit rows)
-            int qe = tq1;                           // end of the order's bucket: the smallest qend_l above q (no HBM round trip)
-            for (int cb = 0; cb < C; cb += WAVE) {
-                const int ce = cb + lane < C ? qend_l[cb + lane] : IMAX;
-                qe = min(qe, wave_min_i32(ce > q ? ce : IMAX));
-            }
-#pragma unroll
-            for (int o = 1; o < WK_G; ++o) {
-                rk[o] = -1;
-                if (g == o && q + o < qe) {
-                    const int r2 = (int)rq_l[q + o - tq0];
-                    int won2 = 0;
-                    if (lane == 0) won2 = (int)((atomicAnd(&scn_bits[r2 >> 5], ~(1u << (r2 & 31))) >> (r2 & 31)) & 1u);
-                    if (__builtin_amdgcn_readfirstlane(won2)) { rk[o] = r2; g = o + 1; }
-                }
-            }
-#if WK_G >= 3
-            if (g == 3) {
-                const int rho3[3] = {rk[0], rk[1], rk[2]}, pn3[3] = {pn[0], pn[1], pn[2]};
-                unsigned *const rec3[3] = {myrec, myrec + WK_REC, myrec + 2 * WK_REC};
-                DSEG(d_claim);
-                dfs_scan<U8, JB, 3, false, DN>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 DA_PACC);
-            } else
-#endif
-#if WK_G >= 2
-            if (g == 2) {
-                const int rho2[2] = {rk[0], rk[1]}, pn2[2] = {pn[0], pn[1]};
-                unsigned *const rec2[2] = {myrec, myrec + WK_REC};
-                DSEG(d_claim);
-                dfs_scan<U8, JB, 2, false, DN>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 DA_PACC);
-            } else
-#endif
-            {
-                const int rho1[1] = {rk[0]}, pn1[1] = {pn[0]};
-                unsigned *const rec1[1] = {myrec};
-                DSEG(d_claim);
-                dfs_scan<U8, JB, 1, false, DN>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec1 DA_PACC);
-            }
-            wg_order();
-            DSEG(d_scan); DCNT(d_nscan); DADD(d_nord, g);
-            // the proposals, earlier order first
-#pragma unroll
-            for (int o = 0; o < WK_G; ++o) {
-                if (o >= g) break;
-                const int rho = rk[o];
-                const unsigned *rec = myrec + o * WK_REC;
-                int4 e = make_int4(IMAX, 0, 0, 0);
-                if (lane < WK_K) e = reinterpret_cast<const int4 *>(rec)[lane];
-                const int nl = (int)rec[4 * WK_K];
-                while (nl > 0) {                    // (no candidate at all: nothing was alive - rejected for good, alive sets only shrink)
-                    const int stv = lane < nl ? (int)st_l[e.y] : -1;
-                    const unsigned long long okb = ballot(stv > rho);
-                    if (okb == 0ull) {              // every kept candidate has been taken since: scan again, on the state as it is then
-                        if (lane == 0) atomicOr(&scn_bits[rho >> 5], 1u << (rho & 31));
-                        DCNT(d_nreq);
-                        break;
-                    }
-                    const int first = __ffsll((long long)okb) - 1;
-                    const int idx = rdlane(e.y, first), wcl = rdlane(e.z, first) & 0xFFFF;
-                    int f = 0;
-                    if (lane == 0) f = cas_min(idx, rho);
-                    f = __builtin_amdgcn_readfirstlane(f);
-                    if (f < 0) continue;            // lost it to an earlier order in the meantime: the next candidate
-                    if (f != (int)WK_FREE) {
-                        if (bit_of(dry_bits, f)) { if (lane == 0) atomicOr(&scn_bits[f >> 5], 1u << (f & 31)); DCNT(d_nbump); }      // a later dry order held it: it scans again
-                        else { DSEG(d_prop); own_chain(f, wcl); DSEG(d_chain); DCNT(d_nchain); }
-                    }
-                    break;
-                }
-            }
-            wg_order();
-            if (lane == 0) atomicAdd(&s_busy, -1);
-            DSEG(d_prop);
-        }
-#ifdef VDS_PROF
-        if (prof && lane == 0) {
-            unsigned long long *gp = g_prof + (size_t)pwave * PROF_SLOTS;
-            gp[8] += d_idle; gp[9] += d_chain; gp[10] += d_scan; gp[11] += d_nscan; gp[12] += d_claim; gp[13] += d_prop;
-            gp[2] += d_nord; gp[3] += d_nchain; gp[4] += d_nreq; gp[6] += d_nbump;
-            for (int i = 0; i < 8; ++i) gp[16 + i] += d_acc[i];
-        }
-#endif
-    }
-    __syncthreads();
-    PROF_STAMP(1);
-    if constexpr (!DN) {
-    // ---- what moved, read off the final stamps.  (1) every order that proposed during the phase above (the dry ones, the own-cluster
-    //      orders that picked again) gets "no vehicle"; (2) one pass over the idle entries: an entry held by such an order is its
-    //      result - a dry holder is a steal: log entry {rank, victim cluster | orders of that cluster before the thief << 16,
-    //      cluster << 16 | position, cost} (the evaluation pass and the commit read the log as they did after the walk)
-    for (int w = threadIdx.x; w < nwords; w += WK_THREADS) {
-        unsigned bits = dry_bits[w] | chg_bits[w];
-        while (bits) { const int rk0 = w * 32 + __ffs((int)bits) - 1; bits &= bits - 1u; out_r[tq0 + (int)qr_l[rk0]] = make_int2(-1, -1); }
-    }
-    __syncthreads();
-    {
-        int4 *slog_w = D.slog + (size_t)r * mto;
-        const int total = moff_l[C];
-        // (a thread first finds up to four entries of its stride that moved, then issues their loads together: the entries are few -
-        // ~75 of ~7000 at configs[3] - and every one costs three dependent loads)
-        int i = (int)threadIdx.x;
-        while (i < total) {
-            int mi[4], msv[4];
-            int nm = 0;
-            for (; i < total && nm < 4; i += WK_THREADS) {
-                const int sv = (int)st_l[i];
-                if (sv == (int)WK_FREE) continue;
-                if (!(((dry_bits[sv >> 5] | chg_bits[sv >> 5]) >> (sv & 31)) & 1u)) continue;
-                mi[nm] = i; msv[nm] = sv; ++nm;
-            }
-            int mc[4], mpos[4], my[4], mlo[4], mx[4];
-            bool mdry[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                mc[u] = 0; mpos[u] = 0; my[u] = tq0; mlo[u] = 0; mx[u] = 0; mdry[u] = false;
-                if (u < nm) {
-                    int lo = 0, hi = C;                          // cluster of stamp index i: the last c with moff_l[c] <= i
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (moff_l[mid] <= mi[u]) lo = mid; else hi = mid; }
-                    mc[u] = lo; mpos[u] = mi[u] - moff_l[lo];
-                    my[u] = tq0 + (int)qr_l[msv[u]];
-                    mdry[u] = (dry_bits[msv[u] >> 5] >> (msv[u] & 31)) & 1u;
-                    mlo[u] = (int)(D.idle[((size_t)mc[u] * S.R + r) * S.idle_cap + mpos[u]].y & 0xFFFF);
-                    mx[u] = mdry[u] ? S.so_pnode[my[u]] : (S.so_rec[my[u]].y & 0xFFFF);      // pickup node / pickup node inside its cluster
-                }
-            }
-            int mcst[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                mcst[u] = 0;
-                if (u < nm) {
-                    const int cda = cdA_l[mc[u]];
-                    if (mdry[u]) {
-                        const char *crow = U8 ? reinterpret_cast<const char *>(S.cost8 + (size_t)mx[u] * S.N) : reinterpret_cast<const char *>(S.cost + (size_t)mx[u] * S.N);
-                        mcst[u] = cost_elem<U8>(crow, (unsigned)(((cda >> 11) & 0xFFFF) + mlo[u]));
-                    } else {
-                        const int4 cd = S.cdesc[mc[u]];
-                        mcst[u] = cost_elem<U8>(blk_b, (unsigned)((U8 ? cd.z : cd.y) + mx[u] * (cda & 2047) + mlo[u]));
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u >= nm) continue;
-                const int c = mc[u], sv = msv[u];
-                if (mdry[u]) {
-                    // orders of bucket c with a smaller rank (ranks ascend with the sorted position inside a bucket)
-                    const int qa0 = (c == 0 ? tq0 : qend_l[c - 1]) - tq0;
-                    int a0 = qa0, a1 = qend_l[c] - tq0;
-                    while (a0 < a1) { const int mid = (a0 + a1) >> 1; if ((int)rq_l[mid] < sv) a0 = mid + 1; else a1 = mid; }
-                    const int n = atomicAdd(&s_nlog, 1);
-                    slog_w[n] = make_int4(sv, c | ((a0 - qa0) << 16), (int)(((unsigned)c << 16) | (unsigned)mpos[u]), mcst[u]);
-                    atomicAdd(&ls_l[c], 1);
-                } else {
-                    out_r[my[u]] = make_int2((int)(((unsigned)c << 16) | (unsigned)mpos[u]), mcst[u]);
-                }
-            }
-        }
-    }
-    }
-#ifdef WKDEBUG
-    if (threadIdx.x == 0) s_dbg = 0x7FFFFFFF;            // (no walk to count the dry orders' evaluations a second time)
-#endif
-    PROF_STAMP(14);
-    } else {
     auto next_dry = [&](int from) -> int {       // (the words ascend with the lanes: the first lane with a bit set holds the minimum)
         for (int w0 = from >> 5; w0 < nwords; w0 += WAVE) {
             const int w = w0 + lane;
@@ -1921,9 +1618,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
         }
 #endif
     }
-    }   // (walk / deferred acceptance)
+    }   // (the walk)
     __syncthreads();
-    if constexpr (!DA) { PROF_STAMP(1); }
+    PROF_STAMP(1);
     __shared__ int s_dw, s_dv, s_drej;            // (DN) what the moved orders change in the replica's counters: wait, value, rejects
     if constexpr (DN) {
     // ---- dense layout: what MOVED, read off the final stamps.  k_tick_dense has committed every order as if nothing were stolen
@@ -1937,7 +1634,6 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     if (threadIdx.x == 0) { s_dw = 0; s_dv = 0; s_drej = 0; }
     __syncthreads();
     {
-        int4 *slog_w = D.slog + (size_t)r * mto;
         const unsigned *idle32 = reinterpret_cast<const unsigned *>(D.idle);
         const int total = moff_l[C];
         int dw = 0, dv = 0, drej = 0;
@@ -1996,16 +1692,6 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 if (u >= nm) continue;
                 const int c = mc[u], sv = msv[u];
                 const int veh = (int)(ment[u] >> 8), cst = mcst[u];
-                if (DA && mdry[u]) {
-                    // (deferred acceptance keeps no log while it runs: the steal's entry {rank, victim cluster | orders of that cluster
-                    // before the thief << 16, ..} for the evaluation pass)
-                    const int qa0 = (c == 0 ? tq0 : qend_l[c - 1]) - tq0;
-                    int a0 = qa0, a1 = qend_l[c] - tq0;
-                    while (a0 < a1) { const int mid = (a0 + a1) >> 1; if ((int)rq_l[mid] < sv) a0 = mid + 1; else a1 = mid; }
-                    const int n = atomicAdd(&s_nlog, 1);
-                    slog_w[n] = make_int4(sv, c | ((a0 - qa0) << 16), (int)(((unsigned)c << 16) | (unsigned)mpos[u]), cst);
-                    atomicAdd(&ls_l[c], 1);
-                }
                 out_r[my[u]] = make_int2(veh, cst);
                 D.stamp[((size_t)c * S.R + r) * S.idle_cap + mpos[u]] = (unsigned short)sv;
                 const int rel = cst + mrec[u].w;
@@ -2405,18 +2091,9 @@ void emit_hybrid_walk(const Emit &e, const Static &S0, const State &D, int t, in
     Static S = S0;
     S.r_lo = r_lo;
     const dim3 grid(r_n > 0 ? r_n : S.R);
-    // Static.walk_da: the dry orders by deferred acceptance (VDS_WALK_DA=1; its wavefronts' records and the bitmap of the
-    // own-cluster orders that moved live where the walk keeps its record pool)
-    const bool da = S.walk_da != 0 && (size_t)(1 + S.walk_pool) * WK_REC >= (size_t)WK_WAVES * WK_G * WK_REC + (size_t)(S.max_tick_orders + 31) / 32 + 1;
     if (S.dense_st) {
         // the dense layout's walk (byte costs: vds_api.hip grants the stamp form only then)
-        if (da) emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, true, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, true, true> : k_dfs_walk<true, 4, true, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
-        else emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, false, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, false, true> : k_dfs_walk<true, 4, false, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
-        return;
-    }
-    if (da) {
-        if (S.u8_ok) emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, true> : k_dfs_walk<true, 4, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
-        else emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<false, 1, true> : (S.seq_pad <= 128 ? k_dfs_walk<false, 2, true> : k_dfs_walk<false, 4, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
+        emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1, true> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2, true> : k_dfs_walk<true, 4, true>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);
         return;
     }
     if (S.u8_ok) emit_walk(e, S.seq_pad <= 64 ? k_dfs_walk<true, 1> : (S.seq_pad <= 128 ? k_dfs_walk<true, 2> : k_dfs_walk<true, 4>), grid, dim3(WK_THREADS), dfs_walk_lds(S), S, D, t);

@@ -103,11 +103,7 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 // a full HBM round trip per use - nothing waits for the global loads / stores in flight (the ISA shows at most
 // s_waitcnt lgkmcnt(0)).  wave_order(): between accesses of different lanes of ONE wavefront to its own scratch;
 // wg_order(): between the wavefronts of a workgroup (k_dfs_walk's flags, records and stamps).
-#ifdef EXP_WO
-__device__ __forceinline__ void wave_order() { __builtin_amdgcn_sched_barrier(0); }
-#else
 __device__ __forceinline__ void wave_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
-#endif
 __device__ __forceinline__ void wg_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); }
 
 // ---------------------------------------------------------------------------------------

@@ -796,19 +796,14 @@ __device__ __forceinline__ void rows_body(const Static &S, const State &D, int t
             if (a * 16 < Amax) {           // wave-uniform: usually only the first 16 arrival slots exist
                 if (idx < A) e[a] = (a == 0 && pf_ring) ? pf_ring[grow * 16 + l16] : ring[idx];
                 key[a] = entry_key(e[a].y, e[a].w);
-#ifdef EXP_KEYMERGE
-                if (idx < A) key_row[idx] = key[a];
-#endif
             }
         }
-#ifndef EXP_KEYMERGE
         wave_order();            // (the prefetched entries sit in the key scratch: every row has read its own before keys are written)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int idx = a * 16 + l16;
             if (a * 16 < Amax && idx < A) key_row[idx] = key[a];
         }
-#endif
         wave_order();
         int rank[4] = {0, 0, 0, 0};
         if (Amax <= 16) {           // common case: one arrival per lane
@@ -986,12 +981,10 @@ __global__ __launch_bounds__(ROWS_WAVES * WAVE, DM == 2 ? ROWS_PD_MIN_WAVES : ((
         D.work[2 + (size_t)p * S.C * S.R + slot] = (int)((unsigned)b | WORK_FULL);
     }
     const unsigned long long badrows = blk_in_lds ? ballot(bad && l16 == 0) : 0ull;
-#ifndef EXP_NOCNT
     {   // buckets that leave the fast path (set aside / deferred): err[2], reported by vds_read_work
         const unsigned long long offp = ballot(bad && l16 == 0);
         if (offp != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(offp));
     }
-#endif
     if (bad) { rowvalid = false; m = 0; A = 0; }
     const bool any = ballot(rowvalid) != 0;
     const bool big = ballot(m + A > 64) != 0;

@@ -1226,11 +1226,6 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     if (stage && (int)threadIdx.x < n4 && !(DN_ABL & 1024)) sblk = blk4[threadIdx.x];
     if (mine) { srec = S.so_rec[q0 + threadIdx.x]; if (PULL) sslot = S.so_slot[q0 + threadIdx.x]; if (ST) srank = S.so_rank[q0 + threadIdx.x]; }
     if (dmine) sdrec = S.d_rec[clo + threadIdx.x];
-#ifdef DN_PREFETCH
-    // the head of the idle list (read after the barrier, once its length is known) touched now: lane lg one word of every 64 bytes
-    unsigned pfw = 0u;
-    if (rowvalid && k > 0 && lg * 16 < S.idle_cap) pfw = D.idle[b * S.idle_cap + lg * 16];
-#endif
     int Ac = 0;
     if (PULL && wg_ok) {
         // the candidates' raw entries; those that say "slot t" are parked in the row's table, packed in candidate order (position
@@ -1258,9 +1253,6 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
             }
         }
     }
-#ifdef DN_PREFETCH
-    asm volatile("" :: "v"(pfw));
-#endif
     asm volatile("" : "+v"(rcw));       // (keeps the mask below out of the branch that issued the load: there it would wait for the word)
     int Aring = rcw & 0xFFFF;
     A = Aring + Ac;           // arrivals of the slot: candidates whose entry says "slot t" + ring entries (dispatched vehicles)
