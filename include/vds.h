@@ -282,6 +282,20 @@ int vds_obs_device_planes(vds_handle *h, int32_t planes, void **dev_ptr);
  * (vds_load_orders* with other sizes, vds_set_idle_cap, vds_set_replica_days, vds_destroy). */
 int vds_obs_inplace(vds_handle *h, int32_t plane, void **dev_ptr, int64_t *stride_replica, int64_t *stride_cluster);
 
+/* SupplyExpect (simulator.py:880-891) in place (round 6; dense layout, one shared order day).  The tick kernels keep, per
+ * (cluster, replica), a ring of `*planes` (32) counters by ARRIVAL SLOT: the bucket that matches an order bumps the counter of the
+ * slot its vehicle will arrive in (a no-return atomic next to the arrival post), the destination's own tick clears the counter of the
+ * slot it has just taken in.  After the tick of slot t, plane (t + 1) % 32 IS SupplyExpect of slot t - the reference's
+ * `len([v for v in cluster.VehiclesArrivetime if arrive <= RealExpTime + TimePeriods and len(v.Orders)])` - with no pass over the
+ * arrival tables.  `*ring`: int32 device memory, element (plane p, replica r, cluster c) at p * *stride_plane + r * *stride_replica +
+ * c * *stride_cluster (in elements); `*slot_word`: one int32 on the device holding the plane index of the slot stepped last (written
+ * by every tick launch).  Both addresses stay fixed until the next vds_load_orders* / vds_set_idle_cap: a policy captured as a graph
+ * reads ring[*slot_word] every slot (vds_run_hooked).  VDS_ESTATE on the wide layout and with order days per replica.
+ * ON REQUEST: the first call switches the planes on (a hook-less day does not pay for their atomics - 8 % of a configs[1] day) and
+ * ends the episode in progress, which has none: vds_reset / vds_reset_again / vds_reset_random must follow.  VDS_SUPPLY_INPLACE=1 in the
+ * environment switches them on from the start. */
+int vds_supply_inplace(vds_handle *h, void **ring, int64_t *stride_plane, int64_t *stride_replica, int64_t *stride_cluster, void **slot_word, int32_t *planes);
+
 /* counters: int64 [R * VDS_NUM_COUNTERS]. */
 int vds_read_counters(vds_handle *h, int64_t *out);
 /* Sum over replicas, int64 [VDS_NUM_COUNTERS], left on the device at *dev_ptr (for an RCCL

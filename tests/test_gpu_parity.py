@@ -76,7 +76,16 @@ def run_day(g, R, same_init, list_every=1, device_dispatch=False, **kw):
     init[0] = g["veh_node"]
     for r in range(1, R):
         init[r] = g["veh_node"] if same_init else synth.init_vehicle_nodes(random.Random(1000 + r), N, V, valid)
+    # SupplyExpect kept in place (vds_supply_inplace: dense layout, switched on by the first request - before the reset): in the
+    # modes that say so and in every dense-tick variant; the other runs take their `supply` plane from the arrival tables
+    want_sup = kw.pop("supply_inplace", "dense_debug" in kw)
     env = make_env(g, R, **kw)
+    sup_ring = None
+    if want_sup:
+        try:
+            sup_ring, sup_slot = env.supply_inplace_torch()
+        except Exception as e:      # (the library keeps the wide layout for this fixture / mode)
+            assert "dense layout only" in str(e), e
     env.reset(init)
     oracles = []
     for r in range(R):
@@ -93,6 +102,8 @@ def run_day(g, R, same_init, list_every=1, device_dispatch=False, **kw):
             o.begin_tick()
         ob = env.obs()
         cn = env.counters()
+        if sup_ring is not None:
+            np.testing.assert_array_equal(sup_ring[int(sup_slot.item())].cpu().numpy(), ob["supply"], err_msg="tick %d supply in place" % t)
         for r, o in enumerate(oracles):
             oo, oc = o.obs(), o.counters()
             for a, b in (("idle_pre", "idle_pre"), ("idle_now", "idle_post"), ("supply", "supply"), ("cl_orders", "cl_orders"), ("inflight", "inflight")):
@@ -158,7 +169,8 @@ def run_day(g, R, same_init, list_every=1, device_dispatch=False, **kw):
 
 
 MODES = {
-    "fast": {},                              # row-mapped kernel (where the cost range allows) + arrival ring
+    "fast": {},                              # the default kernels
+    "fast_sup": {"supply_inplace": True},    # ... with SupplyExpect kept in place (per-arrival-slot counters bumped at match time)
     "generic": {"force_generic": True},      # one wavefront per bucket
     "far": {"ring_ticks": 2},                # nearly every trip outlives the ring: far tables + migration
     "far_generic": {"ring_ticks": 4, "force_generic": True},
@@ -193,7 +205,7 @@ DENSE = [m for m in MODES if m.startswith("dense")]
 # every mode on a representative handful of fixtures; the default kernels, the generic kernels and the far path on all of them
 # (the full product was 17 modes x 19 fixtures: most of the GPU suite's run time for pairs that add no new path)
 ALL_MODES_ON = ("tiny_kmeans", "tiny_grid", "tiny_dispatch", "tiny_sort_ties", "tiny_fraccost", "tiny_kmeans_dfs2", "tiny_dispatch_dfs2", "tiny_window4_dfs2")
-BASE_MODES = ("fast", "generic", "far", "dfs_v2", "dfs_wide", "dense16", "ring64")
+BASE_MODES = ("fast", "fast_sup", "generic", "far", "dfs_v2", "dfs_wide", "dense16", "ring64")
 
 
 def _applies(name, mode):

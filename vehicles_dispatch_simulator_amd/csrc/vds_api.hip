@@ -163,6 +163,7 @@ struct vds_handle {
     // dense layout (k_tick_dense): static preconditions, the layout the state tables were allocated for
     bool dense_static_ok = false;
     bool dense_dfs_static_ok = false;        // ... of the dense layout for the neighbour-search tick (stamp form, Static.dense_st; round 6)
+    bool want_sup = false;                   // SupplyExpect kept in place (State.sup): on request (vds_supply_inplace) - the hook-less day pays 8 % for the planes' atomics
     bool nodes_valid = false;                // d_veh_node holds the start nodes of the last vds_reset* (false once the state tables were re-allocated)
     int alloc_dense = -1, alloc_st = -1;
     int seq_tick0 = 0;                       // dispatch_seq at the first dispatch call of the current slot (dense keys carry the sequence number inside the slot)
@@ -1000,6 +1001,9 @@ static int alloc_state(vds_handle *h, int O) {
     }
     D.dry = nullptr;
     if (S.dense_st && (rc = dev_alloc(h, &D.dry, (size_t)R))) return rc;
+    D.sup = nullptr; D.sup_slot = nullptr;           // SupplyExpect kept in place (dense layout): planes by arrival slot + the current plane's index
+    if (getenv("VDS_SUPPLY_INPLACE") && getenv("VDS_SUPPLY_INPLACE")[0] == '1') h->want_sup = true;
+    if (S.dense && h->want_sup && ((rc = dev_alloc(h, &D.sup, (size_t)VDS_SUP_PLANES * B)) || (rc = dev_alloc(h, &D.sup_slot, (size_t)1)))) return rc;
     if ((rc = dev_alloc(h, &D.ring, S.dense ? ((size_t)H * B * ring_cap + 1) / 2 : (size_t)H * B * ring_cap))) return rc;      // (dense: 8-byte entries)
     D.ring_min = nullptr;
     if (S.dense && (rc = dev_alloc(h, &D.ring_min, (size_t)H * B * ring_cap))) return rc;
@@ -1649,6 +1653,10 @@ static int reset_device(vds_handle *h) {
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 16 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
+    if (h->D.sup) {
+        HIPCHK(h, hipMemsetAsync(h->D.sup, 0, (size_t)VDS_SUP_PLANES * S.C * S.R * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->D.sup_slot, 0, sizeof(int), h->stream));
+    }
     if (S.dense_st) {     // stamp form: every entry free, no replica with a dry bucket (the reset kernels write HDR_RAW = 0: compact lists)
         HIPCHK(h, hipMemsetAsync(h->D.stamp, 0xFF, (size_t)S.C * S.R * S.idle_cap * sizeof(unsigned short), h->stream));
         HIPCHK(h, hipMemsetAsync(h->D.dry, 0, (size_t)S.R * sizeof(int), h->stream));
@@ -2429,6 +2437,36 @@ static void finish_counters(const vds_handle *h, int r, const long long *raw, in
     // :1095-1100 sums OrderValue over every order whose ArriveInfo != "Reject": matched + not (yet) processed
     out[VDS_CNT_VALUE_SUM] = raw[CNT_VALUE] + unprocessed_value(h, r);
     out[VDS_CNT_EVALS] = raw[CNT_EVALS];
+}
+
+// SupplyExpect (:880-891) where the tick kernels keep it (dense layout, one shared order day): the ring of planes [32][C][R] by arrival
+// slot and the device word that says which plane is SupplyExpect of the slot stepped last - both at fixed addresses, so a policy
+// captured once as a graph reads ring[*slot] every slot.  No observation pass.
+int vds_supply_inplace(vds_handle *h, void **ring, int64_t *stride_plane, int64_t *stride_replica, int64_t *stride_cluster, void **slot_word, int32_t *planes) {
+    if (!h || !h->have_orders) return fail(h, VDS_EINVAL, "vds_supply_inplace: load orders first (the state tables are made by the load)");
+    if (!ring || !stride_plane || !stride_replica || !stride_cluster || !slot_word || !planes) return fail(h, VDS_EINVAL, "vds_supply_inplace: null output pointer");
+    if (!h->S.dense) return fail(h, VDS_ESTATE, "vds_supply_inplace: SupplyExpect is kept in place on the dense layout only (this handle runs the wide layout: vds_obs_device_planes)");
+    if (h->S.n_days > 1 || h->S.int2ext != nullptr || h->S.rperm != nullptr || h->S.R != h->R_ext)
+        return fail(h, VDS_ESTATE, "vds_supply_inplace: order days per replica (replicas whose day is over stand still at their own slot; the storage may be regrouped): use vds_obs_device_planes");
+    if (!h->D.sup) {
+        // the first request switches the planes on: the tick kernels maintain them from the next episode on (a hook-less day does
+        // not pay for them: 8 % of the headline, profiles/r06/supply_inplace_ab.txt).  The episode in progress has no planes: reset.
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->want_sup = true;
+        int rc;
+        struct Sink { vds_handle *h; std::vector<void *> *old; ~Sink() { h->alloc_sink = old; } } sink{h, h->alloc_sink};
+        h->alloc_sink = &h->state_allocs;
+        if ((rc = dev_alloc(h, &h->D.sup, (size_t)VDS_SUP_PLANES * h->S.C * h->S.R)) || (rc = dev_alloc(h, &h->D.sup_slot, (size_t)1))) { h->D.sup = nullptr; h->D.sup_slot = nullptr; return rc; }
+        HIPCHK(h, hipMemsetAsync(h->D.sup, 0, (size_t)VDS_SUP_PLANES * h->S.C * h->S.R * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->D.sup_slot, 0, sizeof(int), h->stream));
+        { h->run_stale = true; h->tables_gen++; }
+        h->have_reset = false;                      // vds_reset / vds_reset_again / vds_reset_random must follow
+        h->t = 0; h->last_stepped = -1; h->dispatch_seq = 0; h->seq_tick = -1;
+    }
+    *ring = h->D.sup; *slot_word = h->D.sup_slot; *planes = VDS_SUP_PLANES;
+    *stride_plane = (int64_t)h->S.C * h->S.R; *stride_cluster = h->S.R; *stride_replica = 1;
+    return VDS_OK;
 }
 
 int vds_counters_device(vds_handle *h, void **dev_ptr) {

@@ -190,6 +190,10 @@ struct State {
                          // the slot - of the order that took it during the last slot; valid for positions below the list's raw length
     int *dry;            // dense neighbour-search tick: [R] buckets of the replica whose orders outran the list in a searching cluster
                          // during this slot (k_tick_dense adds, k_dfs_walk reads and clears: 0 = nothing to walk)
+    int *sup;            // dense layout: [VDS_SUP_PLANES][C][R] SupplyExpect kept in place (:880-891) - plane a & 31 counts the order-carrying vehicles that
+                         // will arrive in (cluster, replica) at slot a: bumped by a no-return atomic where the arrival is posted (match time), cleared
+                         // by the bucket's own tick at slot a.  After the tick of slot t, plane (t + 1) & 31 IS SupplyExpect of slot t
+    int *sup_slot;       // [1] (t + 1) & 31 of the last tick launched: which plane a device-side policy reads (vds_supply_inplace)
     int *ring_min;       // dense layout: [H][C][R][ring_cap] arrival minute of a DISPATCHED vehicle's entry (order-carrying entries: recomputed
                          // from the order's result on the read side); written by the dispatch kernels only, never read by a tick
 };
@@ -212,6 +216,8 @@ struct State {
 // tables) and takes those whose arrival-slot byte is t's (every candidate was processed less than 128 slots ago).  Dict insertion order = the orders' (insert tick, id) keys (static, d_rec).  Dispatched
 // vehicles (hooks) and orders whose trip may outlive the ring horizon keep the ring / far path.  Used when W <= DENSE_PULL_WMAX.
 #define DENSE_PULL_WMAX 3
+#define VDS_SUP_PLANES 32           // arrival slots ahead the supply planes hold (>= the ring horizon of the dense layout, H <= 32)
+__host__ __device__ inline size_t sup_index(int C, int R, int slot, int c, int r) { return ((size_t)(slot & (VDS_SUP_PLANES - 1)) * C + c) * R + r; }
 // D.arr is [arr_slots][R] u32: the candidates of a bucket are consecutive slots, a workgroup (16 / 32 consecutive replicas) reads
 // and writes 64 / 128 contiguous bytes per slot, and the 4 KB of one slot's R = 1024 replicas are read by the cluster's workgroups
 // at about the same time.  (Blocked by 32 replicas - [R / 32][arr_slots][32], every workgroup streaming its own contiguous run of

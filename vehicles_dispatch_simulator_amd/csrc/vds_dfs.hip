@@ -1698,8 +1698,16 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
                 const int dmin = mrec[u].w <= 0 ? 1 : ticks_until<true>(S, mrec[u].w);
                 const int dl = (int)((unsigned)mrec[u].y >> 16);
-                if (mslot[u] >= 0 && d - dmin <= S.pull_W) D.arr[arr_index(S.R, mslot[u], r)] = pull_entry(veh, t + d);
-                else {
+                // (SupplyExpect in place, State.sup: the committed arrival leaves its plane, the new one enters its own - post_arrival bumps
+                // the plane itself)
+                if (D.sup != nullptr && mold[u].x != -1) {
+                    const int relo = mold[u].y + mrec[u].w;
+                    atomicSub(&D.sup[sup_index(S.C, S.R, t + (relo <= 0 ? 1 : ticks_until<true>(S, relo)), mrec[u].z & 0xFFFF, r)], 1);
+                }
+                if (mslot[u] >= 0 && d - dmin <= S.pull_W) {
+                    D.arr[arr_index(S.R, mslot[u], r)] = pull_entry(veh, t + d);
+                    if (D.sup != nullptr) atomicAdd(&D.sup[sup_index(S.C, S.R, t + d, mrec[u].z & 0xFFFF, r)], 1);
+                } else {
                     if (mslot[u] >= 0) D.arr[arr_index(S.R, mslot[u], r)] = pull_reject(t);
                     post_arrival<true, true>(S, D, mrec[u].z & 0xFFFF, r, t, now, veh, mrec[u].x, now + rel, 0, dl);
                 }
@@ -1720,6 +1728,10 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             const int slot = S.so_slot[y];
             out_r[y] = make_int2(-1, -1);
             if (slot >= 0) D.arr[arr_index(S.R, slot, r)] = pull_reject(t);
+            if (D.sup != nullptr) {
+                const int relo = old.y + rec.w;
+                atomicSub(&D.sup[sup_index(S.C, S.R, t + (relo <= 0 ? 1 : ticks_until<true>(S, relo)), rec.z & 0xFFFF, r)], 1);
+            }
             drej += 1; dw -= old.y; dv -= rec.w;
         }
         if (dw) atomicAdd(&s_dw, dw);

@@ -116,6 +116,7 @@ __device__ __forceinline__ void ring_post(const Static &S, const State &D, int d
     const size_t i = ((size_t)(tick & (S.H - 1)) * S.C + dc) * S.R + r;
     const int old = atomicAdd(&D.ring_cnt[i], meta_is_dispatch(e.w) ? 1 : 0x10001);   // high half: carries an order (:889)
     const int pos = old & 0xFFFF;
+    if (LT && D.sup != nullptr && !meta_is_dispatch(e.w)) atomicAdd(&D.sup[sup_index(S.C, S.R, tick, dc, r)], 1);      // (SupplyExpect in place)
     if (pos >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
     else if (LT && S.dense) {
         // dense layout: {veh << 8 | dest_local, key}; the arrival minute of a dispatched vehicle goes to ring_min (read side only)

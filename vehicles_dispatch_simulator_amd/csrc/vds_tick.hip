@@ -1209,7 +1209,10 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                 for (int s = 0; s < S.H; ++s) infl += D.ring_cnt[(size_t)s * RC + b] & 0xFFFF;
             // SupplyExpect (:880-891): order-carrying vehicles due by the next slot
             int supply = (int)((unsigned)D.ring_cnt[(size_t)((tr + 1) & (S.H - 1)) * RC + b] >> 16);
-            if (S.pull && stepped && (planes & (4 | 16))) {       // (neither supply nor inflight wanted: the arrival slots are not read)
+            // (dense layout: SupplyExpect is kept in place - State.sup, plane of slot tr + 1; the arrival slots are walked only for `inflight`)
+            const bool sup_inplace = D.sup != nullptr && stepped;
+            if (sup_inplace) supply = D.sup[sup_index(S.C, S.R, tr + 1, c, r)];
+            if (S.pull && stepped && (planes & ((sup_inplace ? 0 : 4) | 16))) {       // (neither supply nor inflight wanted: the arrival slots are not read)
                 // static arrival slots (vds_device.h): the orders to this cluster that are on their way sit in D.arr, not in the ring -
                 // processed (insert tick <= tr), matched, arrival slot a0 + delta behind tr; due by the next slot: a0 + delta == tr + 1
                 const int4 d2 = S.n_days <= 1 ? make_int4(0, 0, 0x7FFFFFFF, 0) : S.replica_desc2[r];
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_pack_obs(Static S, State D, int t, int 
                         const bool live = i0 + u < hi && tins <= tr && !pull_is_reject(e[u]);
                         const int ahead = pull_slots_ahead(e[u], tr);
                         infl += (live && ahead > 0) ? 1 : 0;
-                        supply += (live && ahead == 1) ? 1 : 0;
+                        supply += (!sup_inplace && live && ahead == 1) ? 1 : 0;
                     }
                 }
             }

@@ -89,6 +89,7 @@ struct DenseArgs {
     const int4 *tdesc;               // (one shared day) per-bucket descriptors, Static.tdesc
     // stamp form (ST: neighbour search on the dense layout, vds_device.h Static.dense_st)
     unsigned short *stamp; int *dry; const int *so_rank;
+    int *sup, *sup_slot;             // SupplyExpect in place (State.sup): planes by arrival slot
     const Static *Sdev; const State *Ddev;
 };
 __device__ __forceinline__ uint2 *ring2(const DenseArgs &D) { return D.ring; }
@@ -236,6 +237,7 @@ __device__ int dense_match_wave(const Static &S, const State &D, int r, int t, i
                 const int rel = wait + rec.w;
                 const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
                 D.arr[arr_index(S.R, slot, r)] = matched ? pull_entry(vid, t + d) : pull_reject(t);
+                if (D.sup != nullptr && matched) atomicAdd(&D.sup[sup_index(S.C, S.R, t + d, rec.z & 0xFFFF, r)], 1);
             } else if (matched) post_arrival<true, true>(S, D, rec.z & 0xFFFF, r, t, now, vid, rec.x, now + wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
         wait_sum += wave_sum_i32(matched ? wait : 0);
@@ -400,8 +402,10 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
             const int4 e = pending_load(fl, inb, f, P, idx);
             const bool valid = idx < P;
             const bool keep = valid && e.z > now;
-            if (keep && !meta_is_dispatch(e.w) && e.z <= now + S.tick_minutes)
+            if (keep && !meta_is_dispatch(e.w) && e.z <= now + S.tick_minutes) {
                 atomicAdd(&D.ring_cnt[(size_t)((t + 1) & (S.H - 1)) * S.C * S.R + b], 0x10000);
+                if (D.sup != nullptr) atomicAdd(&D.sup[sup_index(S.C, S.R, t + 1, c, r)], 1);
+            }
             const unsigned long long kb = ballot(keep);
             wave_fence();
             if (keep) {
@@ -484,6 +488,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
                 const int rel = res_wait + rec.w;
                 const int d = rel <= 0 ? 1 : ticks_until<true>(S, rel);
                 D.arr[arr_index(S.R, slot, r)] = res_veh >= 0 ? pull_entry(res_veh, t + d) : pull_reject(t);
+                if (D.sup != nullptr && res_veh >= 0) atomicAdd(&D.sup[sup_index(S.C, S.R, t + d, rec.z & 0xFFFF, r)], 1);
             } else if (res_veh >= 0) post_arrival<false, true>(S, D, rec.z & 0xFFFF, r, t, now, res_veh, rec.x, now + res_wait + rec.w, 0, (int)((unsigned)rec.y >> 16));
         }
     }
@@ -503,6 +508,7 @@ __device__ void dense_bucket_slow(const Static &S, const State &D, int c, int r,
         }
         m = newm;
     }
+    if (lane == 0 && D.sup != nullptr) D.sup[sup_index(S.C, S.R, t, c, r)] = 0;
     if (lane == 0) {
         hdr[HDR_IDLE] = ST ? navail : m;
         hdr[HDR_FL] = newf;
@@ -789,6 +795,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
                 if (lg == 0 && (PULL ? Aring : A) > 0) D.ring_cnt[si] = 0;
             }
         }
+        if (rowvalid && lg == 2 && D.sup != nullptr) D.sup[(size_t)(t & (VDS_SUP_PLANES - 1)) * S.C * S.R + b] = 0;      // (this slot's arrivals are in the list now)
         if (rowvalid) {
             if (REC && ST) store_record<true>(D.hdr + b * HDR_WORDS, lg, hw, mnew, mnew, 0, 0, 0, 0, 0, A, 0);
             else if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mnew, mnew, 0, 0, 0, 0, 0, A);
@@ -993,6 +1000,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             const int rel = wait + rr.w;
             const int d = rel <= 0 ? 1 : ticks_until_fast(S, rel);
             if (has && !(abl & 1)) D.arr[arr_index(S.R, slot, r)] = matched ? pull_entry(vid, t + d) : pull_reject(t);
+            if (D.sup != nullptr && matched && !(abl & 1)) atomicAdd(&D.sup[sup_index(S.C, S.R, t + d, rr.z & 0xFFFF, r)], 1);      // SupplyExpect of slot t + d - 1 (:880-891)
 #ifdef VDS_PROF
             if (has && (abl & 65536)) reinterpret_cast<unsigned *>(D.ring_min)[arr_index(S.R, slot, r)] = (unsigned)vid;      // the slot store once more (shadow table)
 #endif
@@ -1004,6 +1012,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
             if (d < S.H) {
                 const size_t i = ((size_t)(((t + d) & (S.H - 1)) * S.C + dc)) * S.R + r;
                 int pos = (rr.x & 7);
+                if (D.sup != nullptr) atomicAdd(&D.sup[sup_index(S.C, S.R, t + d, dc, r)], 1);
                 if (!(abl & 64)) pos = atomicAdd(&D.ring_cnt[i], (abl & 32) ? 0 : 0x10001) & 0xFFFF;          // high half: carries an order (:889)
                 if (pos >= S.ring_cap) atomicOr(&D.err[0], ERR_RING_CAP);
                 else if (!(abl & 32)) ring2(D)[i * S.ring_cap + pos] = make_uint2(dense_pack((unsigned)vid, (unsigned)rr.y >> 16), dense_key(t, 0, rr.x));
@@ -1048,7 +1057,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
         }
         if (rowvalid && lg == 0 && capable && k > mnew) atomicAdd(&D.dry[r], 1);
     }
-    // 8. header, counters
+    // 8. header, counters; the supply plane of this slot is spent
+    if (rowvalid && lg == 2 && D.sup != nullptr) D.sup[(size_t)(t & (VDS_SUP_PLANES - 1)) * S.C * S.R + b] = 0;
     if (rowvalid && !(abl & 16)) {
         if (REC && ST) store_record<true>(D.hdr + b * HDR_WORDS, lg, hw, mfin, mnew, k, rej, wsum, vsum, evals, A, mfin != mnew ? mnew + 1 : 0);
         else if (REC) store_record(D.hdr + b * HDR_WORDS, lg, hw, mfin, mnew, k, rej, wsum, vsum, evals, A);
@@ -1099,6 +1109,7 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     struct SpanEnd { int i; __device__ ~SpanEnd() { if ((g_ablate & 1048576) && threadIdx.x == 0) atomicMax(&g_span[i + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } span_end{span_i};
 #endif
     if (DN_ABL & 512) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.sup_slot != nullptr) P.sup_slot[0] = (t + 1) & (VDS_SUP_PLANES - 1);
     typedef typename std::conditional<U8, unsigned char, int>::type CT;
     constexpr int RPW = WAVE / LPR;             // rows per wavefront
     constexpr int NTHR = ROWS * LPR;
@@ -1424,7 +1435,7 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     P.r_lo = r_lo; P.r_hi = r_lo + (r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo); P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
     P.Sdev = S.self_dev; P.Ddev = S.state_dev; P.ring_min = D.ring_min;
     P.tdesc = S.tdesc;
-    P.stamp = D.stamp; P.dry = D.dry; P.so_rank = S.so_rank;
+    P.stamp = D.stamp; P.dry = D.dry; P.so_rank = S.so_rank; P.sup = D.sup; P.sup_slot = D.sup_slot;
     P.arr = D.arr; P.so_slot = S.so_slot; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
     const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo;
     const bool t256 = dense_tab256(S);

@@ -315,6 +315,28 @@ class BatchedDispatchEnv:
             out[name] = torch.as_tensor(blk, device=torch.device("cuda", self.device))
         return out
 
+    def supply_inplace_torch(self):
+        """``SupplyExpect`` (``simulator.py:880-891``) where the tick kernels keep it (``vds_supply_inplace``; dense layout, one shared
+        order day): ``(ring, slot)`` - ``ring`` a zero-copy int32 view ``[32, R, C]`` of the per-arrival-slot counters, ``slot`` a
+        device int32 tensor ``[1]`` holding the plane of the slot stepped last.  ``ring[slot]`` (``ring.index_select(0, slot)[0]``) is
+        ``SupplyExpect`` of that slot; both tensors keep their addresses, so a policy captured as a graph may read them every slot."""
+        import torch
+
+        ring, slot, planes = C.c_void_p(), C.c_void_p(), C.c_int32()
+        sp, sr, sc = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._lib.vds_supply_inplace(self._h, C.byref(ring), C.byref(sp), C.byref(sr), C.byref(sc), C.byref(slot), C.byref(planes)))
+
+        class _Block:
+            pass
+
+        blk = _Block()
+        blk.__cuda_array_interface__ = {"shape": (planes.value, self.R, self.C), "typestr": "<i4", "data": (ring.value, False), "version": 2,
+                                        "strides": (4 * sp.value, 4 * sr.value, 4 * sc.value)}
+        sw = _Block()
+        sw.__cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (slot.value, False), "version": 2}
+        dev = torch.device("cuda", self.device)
+        return torch.as_tensor(blk, device=dev), torch.as_tensor(sw, device=dev)
+
     def counters_torch(self):
         """Per-replica counters as a zero-copy ``torch`` int64 tensor ``[R, 8]`` on the GPU, in device order
         ``(orders, rejects, wait_sum, matched_value_sum, evals, arrivals, dispatch_num, dispatch_cost)``;
