@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
 
-def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 2048):
+def cpu_baseline(w, init_rows, budget_s: float = 10.0, max_days: int = 2048):
     """The oracle (kind "port": C restatement of the reference's Python loop) on this host, one
     thread, whole days of single replicas of the same workload until ~budget_s of CPU work."""
     from oracle.oracle import Oracle
@@ -64,7 +64,7 @@ def cpu_baseline(w, init_rows, budget_s: float = 12.0, max_days: int = 2048):
     return out
 
 
-def cpu_baseline_all_cores(w, init_rows, budget_s: float = 8.0, max_procs: int = 256):
+def cpu_baseline_all_cores(w, init_rows, budget_s: float = 5.0, max_procs: int = 256):
     """the same oracle as independent single-replica processes on every host core (the reference is
     single-threaded; multi-core = independent replica processes).  Fresh interpreters, no GPU state shared."""
     import shutil
@@ -112,6 +112,36 @@ def cpu_baseline_all_cores(w, init_rows, budget_s: float = 8.0, max_procs: int =
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def leg_roofline(env_x, workload_key, replicas, stream, build_id):
+    """The roofline object of a side leg (neighbour search, stress): one HIP event pair on the kernels' stream around a hook-less day in
+    the leg's timed mode / launches = time per tick; HBM-side bytes per tick from the committed PMC passes of the SAME kernel build
+    (profiles/traffic.json: read requests by size + WRITE_SIZE; null when the build differs); the VALU-issue floor from the same passes."""
+    import torch
+    T_x = env_x.T
+    env_x.reset_again(); env_x.run(T_x); env_x.reset_again()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream); env_x.run(T_x); ev1.record(stream); ev1.synchronize()
+    day_ms = ev0.elapsed_time(ev1)
+    kern = env_x.main_kernel()
+    from vehicles_dispatch_simulator_amd import workloads as _w
+    side = _w.profile_side_data(ROOT, workload_key, replicas, kern)
+    traffic, tb = side.get("hbm_bytes_per_launch"), side.get("traffic_build")
+    same = traffic is not None and tb is not None and tb.split("+")[0] == build_id.split("+")[0]
+    tick_s = day_ms * 1e-3 / T_x
+    out = {"bound": "hbm", "kernel": kern, "ticks": T_x, "day_kernel_ms": day_ms, "avg_launch_ms": tick_s * 1e3, "run_groups": env_x.run_groups(),
+           "traffic": traffic if same else None, "traffic_build": tb, "traffic_build_matches": bool(same), "traffic_source": side.get("traffic_source"),
+           "achieved": (traffic / tick_s / 1e9) if same else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": (traffic / tick_s / 1e9 / HBM_PEAK_GBS) if same else None}
+    lim = side.get("limiter")
+    if lim and (lim.get("build") or "").split("+")[0] == build_id.split("+")[0]:
+        floor_s = lim["valu_insts_per_launch"] * lim["cycles_per_valu_inst"] / (lim["simds"] * lim["clock_hz"])
+        out["limiter"] = {"valu_insts_per_launch": lim["valu_insts_per_launch"], "valu_floor_ms": floor_s * 1e3, "valu_frac": floor_s / tick_s,
+                          "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source")}
+        if out["frac"] is not None and out["limiter"]["valu_frac"] > out["frac"]:
+            out["bound"] = "valu-issue" if out["limiter"]["valu_frac"] > 0.5 else "latency (per-replica chain of dry orders: neither HBM nor VALU issue is busy)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +157,11 @@ def main():
     ap.add_argument("--distinct-all-days", type=int, default=128, help="distinct days of that leg (replica r replays day r %% N)")
     ap.add_argument("--no-hooked-leg", dest="hooked", action="store_false", help="skip the hooked-slot leg (step -> obs -> policy -> dispatch -> advance)")
     ap.add_argument("--no-fallbacks-leg", dest="fallbacks", action="store_false", help="skip the leg that times the documented fallback tick paths")
+    ap.add_argument("--no-stress-leg", dest="stress", action="store_false", help="skip the configs[4] leg (2048 clusters / 100k vehicles / 2M orders, 128 replicas)")
     a = ap.parse_args()
+    marks = [("start", time.perf_counter())]          # wall clock of the legs (leg_seconds in the line)
+    def mark(name):
+        marks.append((name, time.perf_counter()))
 
     import torch
     from vehicles_dispatch_simulator_amd import dist as vdist
@@ -236,6 +270,7 @@ def main():
                     "first_replica_nodes_crc32": [int(x) for x in allt[:, 3]], "allreduce_us": ar_us, "allreduce_timing": ar_how}
         elapsed = vdist.max_over_ranks(elapsed, device="cuda")
     agg = totals.cpu().numpy()
+    mark("import, workload, handle, warm-up, timed days")
 
     # ---- roofline pass (rank 0): per-launch duration of the dominant kernel, HIP events on its stream.  The day is
     #      stepped slot by slot so that the packed observations (device tensors) give the exact number of idle-list
@@ -345,6 +380,7 @@ def main():
     # ---- per-replica order days (rank 0, N = 1): the headline replays ONE day in every replica, which lets 16 replicas
     #      share staged order records and keeps per-order control flow wave-uniform.  The same workload with D distinct
     #      days (replica r replays day r % D; vds_load_order_days, k_tick_rows' per-row variant) is timed next to it.
+    mark("roofline passes")
     per_days = None
     if rank == 0 and world == 1 and a.distinct_days > 1 and a.workload != "cfg5":
         days = workloads.distinct_days(w, a.distinct_days)
@@ -396,6 +432,7 @@ def main():
 
     # ---- neighbour-search mode (rank 0, N = 1, only next to the headline workload): BASELINE configs[3] - the same city with
     #      NeighborCanServer and a 2000 m service radius (DFS depth 2) - a few days, so that the line also shows the second tick path
+    mark("per_replica_days")
     nbr = None
     if rank == 0 and world == 1 and a.workload == "cfg2" and not a.no_neighbour_leg:
         w4 = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
@@ -414,14 +451,49 @@ def main():
         nbr = {"workload": "configs[3]: %d replicas/GPU x 192 clusters with neighbour DFS depth 2, 10k vehicles, 200k orders/day" % R,
                "value": T4 * R * nd4 / dt4, "unit": "env-steps*replicas/s", "ms_per_step": dt4 / nd4 * 1e3, "steps": nd4,
                "kernel": env4.main_kernel(), "run_groups": env4.run_groups(),
-               "evidence": "profiles/r04_cfg4_hybrid (bench.py --workload cfg4 --check: roofline, parity)"}
+               "slow_path_buckets_last_day": int(env4.work().get("slow_path_buckets", 0)),
+               "roofline": leg_roofline(env4, "cfg4", R, stream, build_id),
+               "evidence": "profiles/r06_cfg4 (rocprofv3 stats + PMC + per-tick trace of both kernels; bench.py --workload cfg4 --check: parity)"}
         env4.close()
+
+    # ---- configs[4] (rank 0, N = 1, next to the headline): the stress city - 2048 clusters, 16384 nodes, 100k vehicles, 2M orders per replica
+    #      and day - at 128 replicas on one GPU, three days
+    mark("neighbour_search")
+    stress = None
+    if rank == 0 and world == 1 and a.workload == "cfg2" and a.stress:
+        try:
+            w5 = workloads.stress()
+            R5 = 128
+            env5 = w5.make_env(R5, device=local_rank, stream=stream.cuda_stream)
+            env5.reset(w5.vehicle_nodes(R5))
+            T5 = env5.T
+            for _ in range(3):            # (the handle settles on 16 lanes per replica after the first episodes: DESIGN.md 4)
+                env5.reset_again(); env5.run(T5)
+            torch.cuda.synchronize()
+            nd5 = 3
+            t1 = time.perf_counter()
+            for _ in range(nd5):
+                env5.reset_again(); env5.run(T5)
+            torch.cuda.synchronize()
+            dt5 = time.perf_counter() - t1
+            env5.sync()
+            wk5 = env5.work()
+            stress = {"workload": "configs[4] (stress): %d replicas/GPU x 2048 clusters, 16384 nodes, 100k vehicles, 2M synthetic orders/day" % R5,
+                      "value": T5 * R5 * nd5 / dt5, "unit": "env-steps*replicas/s", "ms_per_step": dt5 / nd5 * 1e3, "steps": nd5, "replicas": R5,
+                      "kernel": env5.main_kernel(), "run_groups": env5.run_groups(), "match_evals_per_s": wk5["evals"] / (dt5 / nd5),
+                      "slow_path_buckets_last_day": int(wk5.get("slow_path_buckets", 0)),
+                      "roofline": leg_roofline(env5, "cfg5", R5, stream, build_id),
+                      "evidence": "profiles/r06_cfg5 (rocprofv3 stats + PMC); tests/test_gpu_stress_config.py: every replica against the oracle at R = 8"}
+            env5.close()
+        except Exception as e:       # (a reported extra)
+            stress = {"error": repr(e)}
 
     # ---- the hooked slot (rank 0, N = 1): what an RL loop over R cities costs per slot - the reference's hook order
     #      (simulator.py:1057-1087: Match -> Reward / state hooks -> SupplyExpect -> DispatchFunction :893-898 -> next Update) with
     #      observations, policy and actions on the device: step -> obs_torch -> a small torch policy -> apply_dispatch_torch (K = 8
     #      moves per city and slot) -> advance.  Timed next to the same loop without the hook (step -> advance) and the hook-less
     #      vds_run above.
+    mark("stress")
     hooked = None
     if rank == 0 and world == 1 and a.hooked and a.workload == "cfg2":
         K = 8
@@ -474,13 +546,19 @@ def main():
 
         # the same with the observations read IN PLACE (vds_obs_inplace: idle_now / cl_orders are words of the bucket records, strided
         # views - no k_pack_obs per slot; a policy that does not need SupplyExpect): surplus = idle - demand
-        pol_inplace, inplace_error = None, None
+        # ... and SupplyExpect from the per-arrival-slot counters the tick kernels keep on request (vds_supply_inplace: ring[slot], both at
+        # fixed addresses) - the SAME policy as above (surplus = idle + supply - demand), on a second handle: the planes cost the tick an
+        # atomic per match, which the headline handle does not pay
+        pol_inplace, inplace_error, env_s = None, None, None
         try:
-            views = env.obs_inplace_torch()
+            env_s = w.make_env(R, device=local_rank, stream=stream.cuda_stream)
+            sup_ring, sup_slot = env_s.supply_inplace_torch()
+            env_s.reset(init)
+            views = env_s.obs_inplace_torch()
 
             def policy_inplace():
                 idle, demand = views["idle_now"], views["cl_orders"]
-                surplus = idle - demand
+                surplus = idle + sup_ring.index_select(0, sup_slot)[0] - demand
                 src = torch.topk(surplus, K, dim=1).indices
                 dst = torch.topk(surplus, K, dim=1, largest=False).indices
                 ok = (idle.gather(1, src) > 0) & (surplus.gather(1, src) - surplus.gather(1, dst) > 4)
@@ -500,13 +578,16 @@ def main():
             inplace_error = repr(e)
 
         def hooked_day(kind):
+            if kind.endswith("_inplace") or kind.endswith("_planes"):
+                env_s.reset_again()
+                if kind == "fixed_day_graph_inplace":         # tick -> k_dispatch_dense per slot: no observation pass (all four planes a policy reads are in place)
+                    env_s.run_hooked(T, actions=fixed_both, idle_pre=False, idle_now=False, supply=False, cl_orders=False, inflight=False)
+                elif kind == "policy_day_graph_inplace":
+                    env_s.run_hooked(T, actions=actions_static, policy_graph=pol_inplace, idle_pre=False, idle_now=False, supply=False, cl_orders=False, inflight=False)
+                else:                                         # packed planes as in fixed_day_graph, k_pack_obs taking `supply` from the counters
+                    env_s.run_hooked(T, actions=fixed_both, inflight=False)
+                return
             env.reset_again()
-            if kind == "fixed_day_graph_inplace":         # tick -> k_dispatch_dense per slot: no observation pass
-                env.run_hooked(T, actions=fixed_both, idle_pre=False, idle_now=False, supply=False, cl_orders=False, inflight=False)
-                return
-            if kind == "policy_day_graph_inplace":
-                env.run_hooked(T, actions=actions_static, policy_graph=pol_inplace, idle_pre=False, idle_now=False, supply=False, cl_orders=False, inflight=False)
-                return
             if kind == "fixed_day_graph":         # one graph launch: T x (tick -> k_pack_obs -> k_dispatch_dense), replica groups as branches
                 env.run_hooked(T, actions=fixed_both, inflight=False)
                 return
@@ -531,11 +612,11 @@ def main():
 
         hook_errors = []
 
-        def sync_skipping_refused_moves():
+        def sync_skipping_refused_moves(e=None):
             # a move from an empty list is skipped and reported once (VDS_ESTATE, "... the action was skipped"): not an error of
             # this leg.  Anything else (capacity overflows: vehicles were lost) makes the timing meaningless: recorded, the leg says INVALID
             try:
-                env.sync()
+                (e or env).sync()
             except Exception as e:
                 if "the action was skipped" not in str(e):
                     hook_errors.append(str(e))
@@ -543,11 +624,12 @@ def main():
         res = {}
         kinds = ([("step_advance_only", "none"), ("engine_hook_fixed_actions", "fixed"), ("engine_hook_fixed_actions_both_moves", "fixed_both"), ("engine_hook_day_graph", "fixed_day_graph")]
                  + ([("torch_policy_graph", "graph")] if pol_graph is not None else []) + ([("torch_policy_day_graph", "policy_day_graph")] if pol_graph_keep is not None else [])
-                 + [("engine_hook_day_graph_obs_in_place", "fixed_day_graph_inplace")] + ([("torch_policy_day_graph_obs_in_place", "policy_day_graph_inplace")] if pol_inplace is not None else [])
+                 + ([("engine_hook_day_graph_obs_in_place", "fixed_day_graph_inplace"), ("engine_hook_day_graph_supply_planes", "fixed_day_graph_planes")] if env_s is not None else [])
+                 + ([("torch_policy_day_graph_obs_in_place", "policy_day_graph_inplace")] if pol_inplace is not None else [])
                  + [("torch_policy_eager", "eager")])
         for label, kind in kinds:
             hooked_day(kind); torch.cuda.synchronize()            # warm
-            sync_skipping_refused_moves()
+            sync_skipping_refused_moves(env_s if (kind.endswith("_inplace") or kind.endswith("_planes")) else env)
             nd = 2
             t1 = time.perf_counter()
             for _ in range(nd):
@@ -555,9 +637,10 @@ def main():
             t_issue = time.perf_counter() - t1                    # host time to ISSUE the days (the stream runs behind)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            sync_skipping_refused_moves()
+            e_used = env_s if (kind.endswith("_inplace") or kind.endswith("_planes")) else env
+            sync_skipping_refused_moves(e_used)
             res[label] = {"slot_us": dt / (nd * T) * 1e6, "host_issue_us_per_slot": t_issue / (nd * T) * 1e6, "value": T * R * nd / dt,
-                          "dispatches_last_day": int(env.work().get("dispatches", 0))}
+                          "dispatches_last_day": int(e_used.work().get("dispatches", 0))}
         hookless_us = elapsed / a.steps / T * 1e6
         best = "torch_policy_day_graph" if "torch_policy_day_graph" in res else ("torch_policy_graph" if "torch_policy_graph" in res else "torch_policy_eager")
         hooked = {"unit": "env-steps*replicas/s", "value": res[best]["value"], "K": K, "days": 2, "policy": best,
@@ -566,8 +649,10 @@ def main():
                   # replica groups as parallel branches) against the hook-less day graph of the headline
                   "engine_hook_vs_hookless_tick": res["engine_hook_day_graph"]["slot_us"] / hookless_us,
                   "engine_hook_call_by_call_vs_hookless_tick": res["engine_hook_fixed_actions"]["slot_us"] / hookless_us,
-                  # observations read in place (vds_obs_inplace: no k_pack_obs; policies that do not need supply / inflight)
-                  "engine_hook_obs_in_place_vs_hookless_tick": res["engine_hook_day_graph_obs_in_place"]["slot_us"] / hookless_us,
+                  # observations read in place (vds_obs_inplace + vds_supply_inplace: idle_pre / idle_now / cl_orders / SupplyExpect with no
+                  # k_pack_obs node; the supply counters cost the tick one atomic per match) and packed planes with `supply` taken from those counters
+                  "engine_hook_obs_in_place_vs_hookless_tick": (res["engine_hook_day_graph_obs_in_place"]["slot_us"] / hookless_us) if "engine_hook_day_graph_obs_in_place" in res else None,
+                  "engine_hook_supply_planes_vs_hookless_tick": (res["engine_hook_day_graph_supply_planes"]["slot_us"] / hookless_us) if "engine_hook_day_graph_supply_planes" in res else None,
                   "policy_slot_vs_hookless_tick": res[best]["slot_us"] / hookless_us,
                   "host_issue_us_per_slot": res[best]["host_issue_us_per_slot"],
                   "variants": res,
@@ -580,10 +665,13 @@ def main():
             hooked["obs_in_place_error"] = inplace_error
         if hook_errors:
             hooked["INVALID"] = "engine errors during the hooked days (timings are not those of a valid run): " + " | ".join(sorted(set(hook_errors)))
+        if env_s is not None:
+            env_s.close()
 
     # ---- the episode reset three ways (rank 0, N = 1): start nodes resident (vds_reset_again: what the timed steps use), drawn on
     #      the device per episode (vds_reset_random: one random.Random(seed) stream per replica, the reference's InitVehiclesIntoCluster
     #      draws bit for bit), generated on the host and uploaded (vds_reset: what an RL loop with fresh start nodes paid before)
+    mark("hooked_slot")
     episode_reset = None
     if rank == 0 and world == 1 and a.hooked and a.workload in ("cfg2", "cfg5"):
         try:
@@ -607,6 +695,7 @@ def main():
 
     # ---- the documented fallbacks (rank 0, N = 1): every tick path a configuration can end up on has a number next to the default's
     #      (DESIGN.md 5).  A few days each; the serial reference form of the neighbour search on 128 replicas (it takes seconds per day)
+    mark("episode_reset")
     fallbacks = None
     if rank == 0 and world == 1 and a.fallbacks and a.workload == "cfg2":
         fallbacks = {"unit": "env-steps*replicas/s", "note": "same workload and replica count as the headline unless said; vds_config.force_generic selects the path"}
@@ -645,6 +734,7 @@ def main():
     #      simulator.py:130-212).  (a) another replica -> day map over resident days (vds_set_replica_days: nothing rebuilt),
     #      (b) a new day on a loaded handle (vds_load_orders: host tables by counting sorts, the neighbour search's visit rows built
     #      on the device), (c) 16 new days (vds_load_order_days: the days built by worker threads)
+    mark("fallbacks")
     episode_turnover = None
     if rank == 0 and world == 1 and a.hooked and a.workload in ("cfg2", "cfg4"):
         try:
@@ -676,6 +766,7 @@ def main():
         finally:
             env.reset(init)
 
+    mark("episode_turnover")
     check = None
     if a.check and rank == 0:
         from oracle.oracle import Oracle
@@ -697,9 +788,12 @@ def main():
         cpu = cpu_baseline(w, init[: min(R, 16)])
         cpu_all = cpu_baseline_all_cores(w, init[: min(R, 64)])
 
+    mark("check, cpu_baseline")
     if rank == 0:
         env_steps = T * R * world * a.steps
         out = {
+            # (first: survives a truncated record of the line)
+            "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
             "metric": "env-steps x replicas / sec (192-cluster, 10k vehicles)" if a.workload != "cfg5" else "env-steps x replicas / sec (2048-cluster, 100k vehicles stress)",
             "value": env_steps / elapsed, "unit": "env-steps*replicas/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -709,7 +803,6 @@ def main():
                        "parallelism": "replica-sharded x%d, RCCL all-reduce of int64[8] metrics per day" % world},
             "match_evals_per_s": float(work["evals"]) * world * a.steps / elapsed if work["evals"] else None,
             "slow_path_buckets_last_day": int(work.get("slow_path_buckets", 0)),      # buckets the fast kernel handed to a slower path (rank 0)
-            "aggregate_counters_last_day": {"order_num": int(agg[0]), "reject_num": int(agg[1]), "wait_sum": int(agg[2]), "evals": int(agg[4])},
             "roofline": roofline, "cpu_baseline": cpu, "build": build_id,
         }
         if dist is not None:
@@ -723,6 +816,8 @@ def main():
             out["per_replica_days"] = per_days
         if nbr is not None:
             out["neighbour_search"] = nbr
+        if stress is not None:
+            out["stress"] = stress
         if hooked is not None:
             out["hooked_slot"] = hooked
         if episode_reset is not None:
@@ -733,6 +828,7 @@ def main():
             out["fallbacks"] = fallbacks
         if check is not None:
             out["parity_check_vs_oracle"] = check
+        out["leg_seconds"] = {marks[i][0]: round(marks[i][1] - marks[i - 1][1], 2) for i in range(1, len(marks))}
         print(json.dumps(out))
     env.close()
     if dist is not None:
