@@ -89,13 +89,17 @@ def test_medium_city_matches_oracle(seed):
     run_case(seed, medium_case(seed), idle_cap=1024)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "90")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VDS_FUZZ_N", "48")))))
 def test_random_city_matches_oracle(seed):
     run_case(seed, random_case(seed))
 
 
-def run_case(seed, case, idle_cap=None):
+def run_case(seed, case, idle_cap=None, whole_day=False):
+    """whole_day: no hooks - the day as one vds_run (the day graph, replica groups as branches), every replica's final results,
+    counters, observations and containers against the oracle's; the volume form (test_fuzz_volume_in_worker_processes)."""
     cost, n2c, nbr, V, rel, pick, dele, valid_nodes, cfg = case
+    if whole_day:
+        cfg = dict(cfg, dispatch=False)
     off, idx = neighbors_to_csr(nbr)
     R, N = cfg["R"], cost.shape[0]
     rng = np.random.default_rng(1000 + seed)
@@ -125,7 +129,15 @@ def run_case(seed, case, idle_cap=None):
         o.reset(init[r])
         oracles.append(o)
     assert env.T == oracles[0].num_ticks
-    for t in range(env.T):
+    if whole_day:
+        env.run(env.T)
+        ob = env.obs()
+        for r, o in enumerate(oracles):
+            o.run_day()
+            oo = o.obs()
+            for k in ("supply", "idle_now", "inflight"):
+                np.testing.assert_array_equal(ob[k][r], oo[k], err_msg="seed %d replica %d %s cfg %s" % (seed, r, k, cfg))
+    for t in range(0 if whole_day else env.T):
         env.step()
         for o in oracles:
             o.begin_tick()
@@ -177,6 +189,23 @@ def run_case(seed, case, idle_cap=None):
         for k in ("idle_off", "idle_veh", "arr_off", "arr_veh", "arr_min"):
             np.testing.assert_array_equal(G[k], L[k], err_msg="seed %d replica %d %s" % (seed, r, k))
     env.close()
+
+
+def test_fuzz_volume_in_worker_processes():
+    """Volume: VDS_FUZZ_VOLUME (default 4000) more random cities and 128 medium ones, whole days without hooks (run_case(whole_day=True):
+    final per-order results, counters, observations and containers of every replica against the oracle), dealt to eight worker
+    processes (tests/fuzz_worker.py) - the per-case cost is host work (city, oracle, comparisons), which the processes share."""
+    import subprocess, sys
+    n_random, n_medium, nproc = int(os.environ.get("VDS_FUZZ_VOLUME", "4000")), int(os.environ.get("VDS_FUZZ_VOLUME_MEDIUM", "128")), 8
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "fuzz_worker.py"), str(i), str(nproc), str(n_random), str(n_medium)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(nproc)]
+    done = 0
+    for i, p in enumerate(procs):
+        out, _ = p.communicate(timeout=1500)
+        assert p.returncode == 0 and "WORKER DONE" in out, "worker %d:\n%s" % (i, out[-3000:])
+        done += int(out.split("WORKER DONE")[1].split()[0])
+    assert done == n_random + n_medium
 
 
 def days_case(seed):

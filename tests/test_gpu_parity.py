@@ -208,13 +208,14 @@ ALL_MODES_ON = ("tiny_kmeans", "tiny_grid", "tiny_dispatch", "tiny_sort_ties", "
 BASE_MODES = ("fast", "fast_sup", "generic", "far", "dfs_v2", "dfs_wide", "dense16", "ring64")
 
 
-def _applies(name, mode):
+def _applies(name, mode, every_pair=False):
     """Mode x fixture pairs that would only repeat the default run are left out: the dense-tick variants (and the explicit
     row-mapped kernel) on fixtures with neighbour search or a live pickup window (the library keeps its own choice there),
-    the fallback neighbour-search kernel on fixtures without neighbour search."""
+    the fallback neighbour-search kernel on fixtures without neighbour search.  every_pair: also the pairs the parametrised test
+    leaves to test_remaining_mode_fixture_pairs_in_worker_processes."""
     g = load_golden(name)
     searching = bool(g["neighbor_can_server"]) and int(g["depth_limit"]) > 0
-    if name not in ALL_MODES_ON and mode not in BASE_MODES:
+    if name not in ALL_MODES_ON and mode not in BASE_MODES and not every_pair:
         return False
     if mode.startswith("dense_ring") or mode.startswith("rows"):
         return not searching and "window" not in name
@@ -225,10 +226,38 @@ def _applies(name, mode):
     return True
 
 
-@pytest.mark.parametrize("name,mode", [(n, m) for n in TINY for m in MODES if _applies(n, m)])
+# in this process: the default kernels (without / with SupplyExpect in place) and the generic kernels on every fixture; every other
+# applicable (fixture, mode) pair - the whole product - runs in test_mode_fixture_product_in_worker_processes
+IN_PROCESS_MODES = ("fast", "fast_sup", "generic")
+RAGGED = [(n, m) for n in ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid"] for m in ["fast", "generic", "rows"] + DENSE
+          if _applies(n, m) and (n != "tiny_grid" or m in ("fast", "dense16", "dense_tiny", "dense_slow"))]
+RAGGED_IN_PROCESS = ("fast", "dense16")
+
+
+@pytest.mark.parametrize("name,mode", [(n, m) for n in TINY for m in IN_PROCESS_MODES if _applies(n, m, every_pair=True)])
 def test_tiny_golden_per_tick(name, mode):
     g = load_golden(name)
     run_day(g, R=3, same_init=bool(len(g["dispatch_log"])), **MODES[mode])
+
+
+def test_mode_fixture_product_in_worker_processes():
+    """The rest of the mode x fixture product - every engine mode on every tiny fixture it applies to, per tick incl. container order
+    (run_day, as test_tiny_golden_per_tick) - and the ragged 37-replica days of the modes test_many_replicas_ragged leaves out, dealt
+    to twelve worker processes (tests/parity_worker.py): a day's cost is host work (oracle steps, container comparisons per tick)."""
+    import json, os, subprocess, sys
+    pairs = [(n, m, "tick") for n in TINY for m in MODES if _applies(n, m, every_pair=True) and m not in IN_PROCESS_MODES]
+    pairs += [(n, m, "ragged") for n, m in RAGGED if m not in RAGGED_IN_PROCESS]
+    pairs.sort(key=lambda x: x[2] != "ragged")        # (the long items first)
+    nproc = 12
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "parity_worker.py"), json.dumps(pairs[i::nproc])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for i in range(nproc)]
+    done = 0
+    for i, p in enumerate(procs):
+        out, _ = p.communicate(timeout=1500)
+        assert p.returncode == 0 and "WORKER DONE" in out, "worker %d:\n%s" % (i, out[-3000:])
+        done += int(out.split("WORKER DONE")[1].split()[0])
+    assert done == len(pairs) and len(pairs) > 200
 
 
 @pytest.mark.parametrize("name", ["tiny_dispatch", "tiny_dispatch_dfs2"])
@@ -238,7 +267,7 @@ def test_device_resident_dispatch_tensor(name):
     run_day(g, R=5, same_init=True, device_dispatch=True)
 
 
-@pytest.mark.parametrize("name,mode", [(n, m) for n in ["tiny_kmeans", "tiny_kmeans_dfs2", "tiny_grid"] for m in ["fast", "generic", "rows"] + DENSE if _applies(n, m) and (n != "tiny_grid" or m in ("fast", "dense16", "dense_tiny", "dense_slow"))])
+@pytest.mark.parametrize("name,mode", [(n, m) for n, m in RAGGED if m in RAGGED_IN_PROCESS])
 def test_many_replicas_ragged(name, mode):
     """R not a multiple of the workgroup's replica run; every replica its own vehicle seed."""
     g = load_golden(name)

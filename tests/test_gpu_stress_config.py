@@ -82,7 +82,7 @@ def test_bench_under_torch_distributed_run_one_rank():
     the int64[8] counter all-reduce and the max-over-ranks timing all execute over RCCL on this box."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--replicas", "128", "--no-cpu-baseline", "--check", "--no-neighbour-leg", "--distinct-days", "0", "--no-hooked-leg", "--no-fallbacks-leg"]
+           "--replicas", "128", "--no-cpu-baseline", "--check", "--no-neighbour-leg", "--distinct-days", "0", "--no-hooked-leg", "--no-fallbacks-leg", "--no-stress-leg"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
