@@ -229,6 +229,14 @@ int vds_run(vds_handle *h, int32_t n_ticks);
  * captured on, or ordered with it.  Errors of skipped actions surface at the next vds_sync as for vds_apply_dispatch_device. */
 int vds_run_hooked(vds_handle *h, int32_t n_ticks, int32_t planes, int32_t K, const void *dev_actions, void *policy_graph);
 
+/* The graph of vds_run_hooked is keyed by what it was built for: first slot, slot count, planes, K, the ADDRESSES of the action
+ * tensor and of the policy graph, the stream, the order tables.  Call it once per day or per fixed window: a call per slot
+ * (n_ticks = 1) starts at another slot every time and rebuilds / updates the graph every time (slower than vds_step + vds_obs_device
+ * + vds_apply_dispatch_device + vds_advance, which is what a per-slot host loop should use).  A policy re-captured into a graph
+ * that happens to live at the address of the one before is NOT noticed: vds_run_hooked_invalidate drops the built graph, the next
+ * vds_run_hooked embeds the policy again. */
+int vds_run_hooked_invalidate(vds_handle *h);
+
 /* Scheduling of vds_run (no reference counterpart, results do not depend on it): the replicas run as `groups` independent
  * groups (replicas never interact inside :1048-1091 without hooks) - in neighbour-search mode (hybrid tick) the stamp-mode
  * k_tick_rows of one group under the k_dfs_walk of the others, without neighbour search two chains of half-size k_tick_dense

@@ -73,6 +73,7 @@ SYMBOLS = {
     "vds_obs_device": (C.c_int, [_VP, C.POINTER(_VP)]),
     "vds_obs_device_planes": (C.c_int, [_VP, _I32, C.POINTER(_VP)]),
     "vds_obs_inplace": (C.c_int, [_VP, _I32, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vds_run_hooked_invalidate": (C.c_int, [_VP]),
     "vds_supply_inplace": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_VP), C.POINTER(_I32)]),
     "vds_counters_device": (C.c_int, [_VP, C.POINTER(_VP)]),
     "vds_read_counters": (C.c_int, [_VP, _VP]),

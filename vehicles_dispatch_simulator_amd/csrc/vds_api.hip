@@ -240,6 +240,7 @@ struct vds_handle {
     hipGraphExec_t run_exec = nullptr;
     int run_t0 = -1, run_n = 0, run_G = 1;
     unsigned long long run_shape = 0;        // graph_shape of run_exec (grouped graphs: the key it is parked under)
+    unsigned long long hook_shape = 0;       // ... of hook_exec (vds_run_hooked with replica groups)
     // k_tick_dense, one shared order day: 8 or 16 lanes per replica by what the last episode did (adapt_dense)
     int *pin_slow = nullptr;                 // pinned host word: buckets the last finished episode handed to the slow path
     hipEvent_t pin_ev = nullptr;             // recorded behind the copy into pin_slow
@@ -446,7 +447,7 @@ extern "C" int vds_debug_graph_pool_size() {      // executable graphs parked ri
 static void drop_hook_graph(vds_handle *h) {
     if (h->hook_exec) {
         (void)hipStreamSynchronize(h->hook_stream);
-        if (h->hook_G > 1) graph_pool_put(h->cfg.device, 0ull, h->hook_exec);     // (parallel branches: parked, never destroyed - see above)
+        if (h->hook_G > 1) graph_pool_put(h->cfg.device, h->hook_shape, h->hook_exec);     // (parallel branches: parked under its shape, never destroyed - see above)
         else (void)hipGraphExecDestroy(h->hook_exec);
         h->hook_exec = nullptr;
     }
@@ -504,7 +505,9 @@ static void for_each_day(int n_days, F &&fn) {
     std::atomic<int> next{0};
     auto work = [&] { for (int d = next.fetch_add(1); d < n_days; d = next.fetch_add(1)) fn(d); };
     std::vector<std::thread> th;
-    for (int i = 1; i < nt; ++i) th.emplace_back(work);
+    th.reserve((size_t)nt);
+    // (std::system_error from a thread limit: the workers already started keep going, the calling thread takes what is left)
+    try { for (int i = 1; i < nt; ++i) th.emplace_back(work); } catch (...) { }
     work();
     for (auto &t : th) t.join();
 }
@@ -1120,10 +1123,10 @@ static int alloc_results(vds_handle *h) {
     // the tables of the load before are kept when they are large enough (a Reload with another day of about the same size: freeing and
     // allocating 1.6 + 0.8 GB took 0.4 ms or 100 ms, whichever way the driver felt - profiles/r05/load_timing_results_tables.txt); none of
     // them needs its old contents cleared (every processed order writes its result and its arrival slot before either is read)
-    if (h->D.out != nullptr && need_out <= h->res_cap_out && need_arr <= h->res_cap_arr && need_slog <= h->res_cap_slog) {
-        if (need_arr == 0) { /* the table stays allocated, unused */ }
-        return VDS_OK;
-    }
+    // (kept while they are not more than four times what this load needs and no table is left that the layout does not use: a handle
+    // that once held a very large day does not keep its peak footprint)
+    auto fits = [](size_t need, size_t cap) { return need <= cap && (need == 0 ? cap == 0 : cap <= 4 * need + (1u << 20)); };
+    if (h->D.out != nullptr && fits(need_out, h->res_cap_out) && fits(need_arr, h->res_cap_arr) && fits(need_slog, h->res_cap_slog)) return VDS_OK;
     for (void *p : h->result_allocs) dev_free(p);
     h->result_allocs.clear();
     h->D.out = nullptr; h->D.arr = nullptr; h->D.slog = nullptr;
@@ -2267,14 +2270,29 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
             updated = hipGraphExecUpdate(h->hook_exec, g, &bad, &res) == hipSuccess;
             if (!updated) (void)hipGetLastError();
         }
+        // (grouped hooked graphs are parked under their shape - nodes, edges, first kernels - salted so that they never meet a vds_run
+        // graph, and taken back from the pool like those: a rebuild that an in-place update cannot cover does not leak an executable)
+        const unsigned long long shape = G > 1 ? (graph_shape(g, n_ticks, G) ^ 0x9E3779B97F4A7C15ull) | 1ull : 0ull;
         if (!updated) {
             drop_hook_graph(h);
-            const hipError_t ei = hipGraphInstantiate(&h->hook_exec, g, nullptr, nullptr, 0);
-            if (ei != hipSuccess) {
-                (void)hipGraphDestroy(g); h->hook_exec = nullptr; (void)hipGetLastError();
-                return run_hooked_eager(h, n_ticks, planes, K, dev_actions, policy_graph);
+            if (G > 1 && shape != 0) {
+                hipGraphExec_t parked = graph_pool_take(h->cfg.device, shape);
+                if (parked) {
+                    hipGraphNode_t bad = nullptr;
+                    hipGraphExecUpdateResult res;
+                    if (hipGraphExecUpdate(parked, g, &bad, &res) == hipSuccess) h->hook_exec = parked;
+                    else { (void)hipGetLastError(); graph_pool_put(h->cfg.device, shape, parked); }
+                }
+            }
+            if (!h->hook_exec) {
+                const hipError_t ei = hipGraphInstantiate(&h->hook_exec, g, nullptr, nullptr, 0);
+                if (ei != hipSuccess) {
+                    (void)hipGraphDestroy(g); h->hook_exec = nullptr; (void)hipGetLastError();
+                    return run_hooked_eager(h, n_ticks, planes, K, dev_actions, policy_graph);
+                }
             }
         }
+        h->hook_shape = shape;
         (void)hipGraphDestroy(g);
         h->hook_t0 = h->t; h->hook_n = n_ticks; h->hook_G = G; h->hook_planes = planes; h->hook_K = K; h->hook_actions = dev_actions;
         h->hook_policy = policy_graph; h->hook_stream = h->stream; h->hook_gen = h->tables_gen;
@@ -2288,6 +2306,13 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
 
 int vds_run_hooked(vds_handle *h, int32_t n_ticks, int32_t planes, int32_t K, const void *dev_actions, void *policy_graph) {
     return guarded(h, "vds_run_hooked", [&] { return run_hooked_impl(h, n_ticks, planes, K, dev_actions, policy_graph); });
+}
+
+int vds_run_hooked_invalidate(vds_handle *h) {
+    if (!h) return VDS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    drop_hook_graph(h);
+    return VDS_OK;
 }
 
 int vds_sync(vds_handle *h) {

@@ -247,6 +247,11 @@ class BatchedDispatchEnv:
             raw = policy_graph if isinstance(policy_graph, int) else int(policy_graph.raw_cuda_graph())
         self._chk(self._lib.vds_run_hooked(self._h, int(n_ticks), planes, K, ptr, C.c_void_p(raw) if raw is not None else None))
 
+    def run_hooked_invalidate(self):
+        """Drop the graph ``run_hooked`` built (``vds_run_hooked_invalidate``): needed after re-capturing a policy graph that may live at
+        the address of the one before - the graph is keyed by addresses."""
+        self._chk(self._lib.vds_run_hooked_invalidate(self._h))
+
     def set_run_groups(self, groups: int = 0, stagger: int = -1):
         """Scheduling of ``run`` (``vds_set_run_groups``): the replicas as ``groups`` independent chains of launches (parallel
         branches of the day graph); results do not depend on it.  ``groups <= 0`` / ``stagger < 0``: library default."""
