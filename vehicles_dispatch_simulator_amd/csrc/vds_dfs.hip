@@ -847,9 +847,10 @@ static_assert(WK_G >= 1 && WK_G <= 3, "dfs_scan is instantiated for 1, 2 and 3 o
 #endif
 
 __host__ __device__ inline size_t dfs_walk_lds_bytes(int C, int V, int mto, int ns = WK_NS, int dn = 0) {
-    const size_t ids = (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
+    // (dense layout: the rank tables are read from L2, their LDS holds the entries' node bytes: RankTab)
+    const size_t ids = dn ? 0 : (size_t)(mto + 2 > RCNT * C ? mto + 2 : RCNT * C);     // two u16 rank tables, later the resolve counters
     const size_t words = (size_t)(mto + 31) / 32 + 1;
-    return ((size_t)8 * C + 1 + ids + (dn ? 3 : 2) * words + (1 + ns) * WK_REC + 4 * WAVE + ((size_t)V + 1) / 2) * sizeof(int);
+    return ((size_t)8 * C + 1 + ids + (dn ? 3 : 2) * words + (1 + ns) * WK_REC + 4 * WAVE + ((size_t)V + 1) / 2 + (dn ? ((size_t)V + 3) / 4 : 0)) * sizeof(int);
 }
 
 template <bool U8>
@@ -903,6 +904,17 @@ __device__ __forceinline__ bool lds_cas(int *p, int expect, int v) {
 // reads, the vehicles it considers are a superset of those alive when the order's turn comes, and the list a sorted prefix of
 // that superset: its first entry still alive at that time IS the winner (none kept: nothing was alive, the order is rejected).
 // DN: the idle lists are the DENSE layout's packed entries {veh << 8 | loc_local} (neighbour search on the dense layout, round 6)
+// The slot's rank tables - rank of a sorted position, sorted position of a rank.  Wide layout: u16 copies in LDS (the walk's serving
+// wavefront reads them on its critical path).  Dense layout (DN): read where they are - they are static and the same for every replica
+// (L2) - and the LDS they took holds the node bytes of the replica's idle entries instead (the scans lose an HBM level each).
+template <bool DN>
+struct RankTab {
+    const unsigned short *rq_l, *qr_l;      // LDS copies (!DN)
+    const int *rank_g, *q_g;                // Static.so_rank + tq0, Static.ord_q + tick_off[t] (DN)
+    int tq0;
+    __device__ __forceinline__ int qr(int rk) const { return DN ? q_g[rk] - tq0 : (int)qr_l[rk]; }      // sorted position (relative to tq0) of a rank
+    __device__ __forceinline__ int rq(int i) const { return DN ? rank_g[i] : (int)rq_l[i]; }           // rank of a sorted position (relative)
+};
 template <bool DN>
 __device__ __forceinline__ unsigned idle_loc(const State &D, size_t elem) {
     if (DN) return reinterpret_cast<const unsigned *>(D.idle)[elem] & 0xFFu;
@@ -911,7 +923,7 @@ __device__ __forceinline__ unsigned idle_loc(const State &D, size_t elem) {
 template <bool U8, int JB, int G = 1, bool PRE = (WK_REDO_PRE != 0), bool DN = false>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, const int (&rho)[G], const int (&pnode)[G],
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
-                                         const unsigned short *st_l, const unsigned short *qr_l, int tq0, unsigned *const (&rec)[G], unsigned long long *pacc = nullptr) {
+                                         const unsigned short *st_l, const RankTab<DN> &RT, const unsigned char *loc_l, int tq0, unsigned *const (&rec)[G], unsigned long long *pacc = nullptr) {
     // G = 2: the dry orders at sorted positions q and q + 1 of ONE bucket (same visit sequence; rho[1] > rho[0], so whatever is
     // alive for the second is alive for the first) share the walk over the candidate lists: one set of stamp reads and node-word
     // loads, a cost gather and a pair of smallest keys per order.  A cluster scanned for either order counts as scanned for both.
@@ -1022,7 +1034,7 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                 for (int o = 0; o < G; ++o) in[o][k8] &= (st > rho[o] ? 1 : 0);
             }
 #pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) if (in[0][k8]) yv[k8] = idle_loc<DN>(D, ip[k8]);        // (alive for a later order = alive for the first)
+            for (int k8 = 0; k8 < 8; ++k8) if (in[0][k8]) yv[k8] = DN ? (unsigned)loc_l[sidx[k8]] : idle_loc<DN>(D, ip[k8]);        // (alive for a later order = alive for the first)
 #pragma unroll
             for (int o = 0; o < G; ++o) {
                 int cst[8];
@@ -1086,11 +1098,11 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
                     const int mow = moff_l[wcl];
                     const int4 cd = S.cdesc[wcl];
                     const int ncw = cda_l[wcl] & 2047;
-                    const int pick = S.so_rec[tq0 + (int)qr_l[a0]].y & 0xFFFF;
+                    const int pick = S.so_rec[tq0 + RT.qr(a0)].y & 0xFFFF;
                     const bool al = lane < m0w && (int)st_l[mow + min(lane, m0w - 1)] > a0;
                     int key = IMAX;
                     if (al) {
-                        const int lo2 = (int)idle_loc<DN>(D, ((size_t)wcl * S.R + r) * S.idle_cap + lane);
+                        const int lo2 = DN ? (int)loc_l[mow + lane] : (int)idle_loc<DN>(D, ((size_t)wcl * S.R + r) * S.idle_cap + lane);
                         key = (cost_elem<U8>(U8 ? reinterpret_cast<const char *>(S.blk8) : reinterpret_cast<const char *>(S.blk),
                                              (unsigned)((U8 ? cd.z : cd.y) + pick * ncw + lo2)) << 16) | lane;
                     }
@@ -1109,10 +1121,10 @@ __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r,
 template <bool U8, int JB, bool DN = false>
 __device__ __forceinline__ void dfs_scan(const Static &S, const State &D, int r, int q, int rho, int pnode,
                                          const int *m0_l, const int *moff_l, const int *ls_l, const int *cda_l,
-                                         const unsigned short *st_l, const unsigned short *qr_l, int tq0, unsigned *rec, unsigned long long *pacc = nullptr) {
+                                         const unsigned short *st_l, const RankTab<DN> &RT, const unsigned char *loc_l, int tq0, unsigned *rec, unsigned long long *pacc = nullptr) {
     const int rho1[1] = {rho}, pn1[1] = {pnode};
     unsigned *const rec1[1] = {rec};
-    dfs_scan<U8, JB, 1, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, qr_l, tq0, rec1, pacc);
+    dfs_scan<U8, JB, 1, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho1, pn1, m0_l, moff_l, ls_l, cda_l, st_l, RT, loc_l, tq0, rec1, pacc);
 }
 
 // JB: 64-cluster batches of the longest visit sequence (Static.seq_pad / 64: 1, 2 or 4).
@@ -1139,7 +1151,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     int *tk_l = ls_l + C;                 // [C] sum over the cluster's steals of min(orders of the bucket before the thief, own matches)
     int *cdA_l = tk_l + C;                // [C] n_c | first cost column << 11 | can search << 30
     int *tab_l = cdA_l + C;               // rank tables (u16), later the resolve counters
-    const int ids_n = mto + 2 > RCNT * C ? mto + 2 : RCNT * C;
+    const int ids_n = DN ? 0 : (mto + 2 > RCNT * C ? mto + 2 : RCNT * C);      // (dense layout: no LDS rank tables, no commit counters)
     unsigned short *rq_l = reinterpret_cast<unsigned short *>(tab_l);                 // [mto] rank of sorted position
     unsigned short *qr_l = rq_l + ((mto + 1) & ~1);                                   // [mto] sorted position of rank
     unsigned *dry_bits = reinterpret_cast<unsigned *>(tab_l + ids_n);
@@ -1152,6 +1164,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     const int ns = S.walk_pool;
     int *lg_l = reinterpret_cast<int *>(pool_l + ns * WK_REC);                        // [64][4] the steal log's current chunk
     unsigned short *st_l = reinterpret_cast<unsigned short *>(lg_l + 4 * WAVE);       // [V] stamps
+    unsigned char *loc_l = reinterpret_cast<unsigned char *>(st_l + 2 * ((S.V + 1) / 2));      // (DN) [V] node bytes of the idle entries (index inside the cluster)
     __shared__ int s_ev;                  // evaluations of the dry orders
     __shared__ int s_nlog;                // steals (entries of the replica's steal log)
     __shared__ int s_nmid;                // lists of 65 .. 128 entries to compact
@@ -1171,13 +1184,14 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     const int tq0 = bkt_off[(size_t)t * C], tq1 = bkt_off[(size_t)(t + 1) * C];
     const int nord = tq1 - tq0;
     int2 *out_r = D.out + (size_t)r * S.Oq - dv.q_base;
+    const RankTab<DN> RT{rq_l, qr_l, S.so_rank + tq0, S.ord_q + dv.tick_off[t], tq0};
 #ifdef VDS_PROF
     const bool prof = (g_ablate & 128) != 0;
     unsigned long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     const int pwave = (int)((blockIdx.x * WK_WAVES + wave) & (PROF_WAVES - 1));
 #endif
     // ---- tables
-    for (int i0 = threadIdx.x; i0 < nord; i0 += 6 * WK_THREADS) {       // (six loads in flight per thread)
+    for (int i0 = threadIdx.x; i0 < (DN ? 0 : nord); i0 += 6 * WK_THREADS) {       // (six loads in flight per thread)
         int rk[6];
 #pragma unroll
         for (int u = 0; u < 6; ++u) rk[u] = i0 + u * WK_THREADS < nord ? S.so_rank[tq0 + i0 + u * WK_THREADS] : 0;
@@ -1234,6 +1248,22 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                     }
                 }
             }
+            // ... and the entries' node bytes (the scans and the re-pick chains then read LDS only, apart from the cost byte)
+            const uint4 *ip4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned *>(D.idle) + ((size_t)c * S.R + r) * S.idle_cap);
+            for (int i0 = 0; i0 < m0; i0 += 32) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u] = make_uint4(0u, 0u, 0u, 0u); if (i0 + 4 * u < m0) v[u] = ip4[(i0 >> 2) + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = i0 + 4 * u + e;
+                        if (i < m0) loc_l[mo + i] = (unsigned char)(w4[e] & 0xFFu);
+                    }
+                }
+            }
         }
     } else {
     for (int i = threadIdx.x; i < (moff_l[C] + 1) / 2; i += WK_THREADS) reinterpret_cast<unsigned *>(st_l)[i] = 0xFFFFFFFFu;
@@ -1253,7 +1283,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
         if (!(cdA_l[c] & CAPABLE)) continue;
         const int qa = c == 0 ? tq0 : qend_l[c - 1];
         for (int q = qa + lm_l[c]; q < qend_l[c]; ++q) {
-            const int rk = rq_l[q - tq0];
+            const int rk = RT.rq(q - tq0);
             atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
         }
     }
@@ -1291,7 +1321,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
 #endif
         while (rho != IMAX) {
             // (the order's sorted position - an LDS round trip - only where a scan by this wavefront needs it)
-            auto q_of = [&]() -> int { return tq0 + (int)qr_l[rho]; };
+            auto q_of = [&]() -> int { return tq0 + RT.qr(rho); };
             // the order's record: in the pool (ready, or being filled), still to be claimed (wait), or passed over (scan here)
             const unsigned *rec = slot_l;
             int slot = -1;
@@ -1323,7 +1353,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 rec = pool_l + slot * WK_REC;
             } else {
                 const int q = q_of();
-                dfs_scan<U8, JB, DN>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
+                dfs_scan<U8, JB, DN>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, RT, loc_l, tq0, slot_l);
                 wg_order();
 #ifdef VDS_PROF
                 p_cnt[2] += 1;
@@ -1341,7 +1371,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             unsigned long long okb = ballot(stv > rho);
             if (nl > 0 && okb == 0ull) {           // every kept candidate has been taken since: scan again, on the state as it is
                 const int q = q_of();
-                dfs_scan<U8, JB, DN>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, slot_l);
+                dfs_scan<U8, JB, DN>(S, D, r, q, rho, S.so_pnode[q], m0_l, moff_l, ls_l, cdA_l, st_l, RT, loc_l, tq0, slot_l);
                 wg_order();
                 e = make_int4(IMAX, 0, 0, 0);
                 if (lane < WK_K) e = reinterpret_cast<const int4 *>(slot_l)[lane];
@@ -1419,7 +1449,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                             const int s1 = p1 >= 0 ? (int)st_l[mo + p1] : -1, s2 = p2 >= 0 ? (int)st_l[mo + p2] : -1;
                             const int pk = s1 > a ? p1 : (s2 > a ? p2 : -1);
                             if (pk >= 0) {
-                                const int y = tq0 + (int)qr_l[a];
+                                const int y = tq0 + RT.qr(a);
                                 const int bst = s1 > a ? s1 : s2;
                                 if (lane == 0) {
                                     st_l[mo + pk] = (unsigned short)a;
@@ -1429,7 +1459,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                                 wg_order();
                                 if (bst == (int)WK_FREE) chain = false; else a = bst;
                             } else if (rcomp) {
-                                const int y = tq0 + (int)qr_l[a];
+                                const int y = tq0 + RT.qr(a);
                                 exhausted = 1;
                                 if (lane == 0) {
                                     if (capable) atomicOr(&dry_bits[a >> 5], 1u << (a & 31));
@@ -1440,9 +1470,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                             }
                         }
                         unsigned yv0 = 0u;
-                        if (chain && m0 <= WAVE && lane < m0) yv0 = idle_loc<DN>(D, ibase + lane);
+                        if (chain && m0 <= WAVE && lane < m0) yv0 = DN ? (unsigned)loc_l[mo + lane] : idle_loc<DN>(D, ibase + lane);
                         while (chain) {
-                            const int y = tq0 + (int)qr_l[a];
+                            const int y = tq0 + RT.qr(a);
                             const int pick = S.so_rec[y].y & 0xFFFF;
                             int lc = IMAX, lp = -1;
                             if (m0 <= WAVE) {
@@ -1451,7 +1481,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                                 for (int base = 0; base < m0; base += WAVE) {
                                     const int ii = base + lane;
                                     if (ii < m0 && (int)st_l[mo + ii] > a) {
-                                        const int lo2 = (int)idle_loc<DN>(D, ibase + ii);
+                                        const int lo2 = DN ? (int)loc_l[mo + ii] : (int)idle_loc<DN>(D, ibase + ii);
                                         const int cst = cost_elem<U8>(blk_b, (unsigned)(boff + pick * nc + lo2));
                                         if (lp < 0 || cst < lc) { lc = cst; lp = ii; }
                                     }
@@ -1542,7 +1572,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             }
             won = __builtin_amdgcn_readfirstlane(won);
             if (!won) continue;
-            const int q = tq0 + (int)qr_l[b];
+            const int q = tq0 + RT.qr(b);
             // the next orders of the same bucket (dry as well: the dry orders of a bucket are its last ones; consecutive sorted
             // positions, ascending ranks) share the scan, up to WK_G of them, pool permitting (one free record is left to the others)
             int rk[WK_G], sl[WK_G], pn[WK_G];
@@ -1564,7 +1594,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                 for (int o = 1; o < WK_G; ++o) {
                     go = go && q + o < tq1 && bk[o] == (int)((unsigned)ra.z >> 16) && popc64(freem) >= 2;
                     if (go) {
-                        const int r2 = (int)rq_l[q + o - tq0];
+                        const int r2 = RT.rq(q + o - tq0);
                         const int s2 = __ffsll((long long)freem) - 1;
                         int won2 = 0;
                         if (lane == 0 && r2 - b <= WK_PAIR_SPAN && lds_cas(&s_slot[s2], 0, (r2 << 2) | 1)) {
@@ -1586,18 +1616,18 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
             if (g == 3) {
                 const int rho3[3] = {rk[0], rk[1], rk[2]}, pn3[3] = {pn[0], pn[1], pn[2]};
                 unsigned *const rec3[3] = {pool_l + sl[0] * WK_REC, pool_l + sl[1] * WK_REC, pool_l + sl[2] * WK_REC};
-                dfs_scan<U8, JB, 3, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec3 WK_PACC);
+                dfs_scan<U8, JB, 3, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho3, pn3, m0_l, moff_l, ls_l, cdA_l, st_l, RT, loc_l, tq0, rec3 WK_PACC);
             } else
 #endif
 #if WK_G >= 2
             if (g == 2) {
                 const int rho2[2] = {rk[0], rk[1]}, pn2[2] = {pn[0], pn[1]};
                 unsigned *const rec2[2] = {pool_l + sl[0] * WK_REC, pool_l + sl[1] * WK_REC};
-                dfs_scan<U8, JB, 2, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, rec2 WK_PACC);
+                dfs_scan<U8, JB, 2, (WK_REDO_PRE != 0), DN>(S, D, r, q, rho2, pn2, m0_l, moff_l, ls_l, cdA_l, st_l, RT, loc_l, tq0, rec2 WK_PACC);
             } else
 #endif
             {
-                dfs_scan<U8, JB, DN>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, qr_l, tq0, pool_l + slot * WK_REC WK_PACC);
+                dfs_scan<U8, JB, DN>(S, D, r, q, b, pn[0], m0_l, moff_l, ls_l, cdA_l, st_l, RT, loc_l, tq0, pool_l + slot * WK_REC WK_PACC);
             }
             wg_order();
             if (lane == 0) {
@@ -1660,7 +1690,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (moff_l[mid] <= mi[u]) lo = mid; else hi = mid; }
                     // (empty clusters share their start with the next one: the LAST cluster starting at or before i holds it)
                     mc[u] = lo; mpos[u] = mi[u] - moff_l[lo];
-                    my[u] = tq0 + (int)qr_l[msv[u]];
+                    my[u] = tq0 + RT.qr(msv[u]);
                     mdry[u] = (dry_bits[msv[u] >> 5] >> (msv[u] & 31)) & 1u;
                     ment[u] = idle32[((size_t)mc[u] * S.R + r) * S.idle_cap + mpos[u]];
                     mrec[u] = S.so_rec[my[u]];
@@ -1721,7 +1751,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
         for (int rk = (int)threadIdx.x; rk < nord; rk += WK_THREADS) {
             const unsigned w = (dry_bits[rk >> 5] | mov_bits[rk >> 5]) & ~got_bits[rk >> 5];
             if (!((w >> (rk & 31)) & 1u)) continue;
-            const int y = tq0 + (int)qr_l[rk];
+            const int y = tq0 + RT.qr(rk);
             const int2 old = out_r[y];
             if (old.x == -1) continue;              // (a dry order nobody could serve: committed as a reject already)
             const int4 rec = S.so_rec[y];
@@ -1755,7 +1785,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
         const int4 sl = slog[i];
         const int c = sl.y & 0xFFFF;
         atomicAdd(&tk_l[c], min((int)((unsigned)sl.y >> 16), lm_l[c]));
-        if (!DN) out_r[tq0 + (int)qr_l[sl.x]] = make_int2(sl.z, sl.w);          // the served dry order's result
+        if (!DN) out_r[tq0 + RT.qr(sl.x)] = make_int2(sl.z, sl.w);          // the served dry order's result
     }
     PROF_STAMP(29);
     {
@@ -1780,7 +1810,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
                         unsigned bits = (unsigned)rdlane((int)myw, hl);
                         for (int d = kx - rdlane(excl, hl); d > 0; --d) bits &= bits - 1u;
                         const int rk = (wb + hl) * 32 + __ffs((int)bits) - 1;
-                        const unsigned *vis = S.so_vis + (size_t)(tq0 + (int)qr_l[rk]) * S.seq_pad;
+                        const unsigned *vis = S.so_vis + (size_t)(tq0 + RT.qr(rk)) * S.seq_pad;
 #pragma unroll
                         for (int jb = 0; jb < JB; ++jb) vv[u][jb] = vis[jb * WAVE + lane];
                     }
@@ -1826,7 +1856,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const bool member = ((wd[u] >> (pcl & 31)) & 1u) != 0u;
-                        for (int qb = qd4[u]; qb < qe4[u]; ++qb) acc -= (member && prk < (int)rq_l[qb - tq0]) ? 1 : 0;
+                        for (int qb = qd4[u]; qb < qe4[u]; ++qb) acc -= (member && prk < RT.rq(qb - tq0)) ? 1 : 0;
                     }
                 }
             }
