@@ -1,4 +1,5 @@
-"""Per-section cycle attribution of k_tick_replica (instrumented build):  VDS_LIB=libvds_prof.so python profiles/sections_dfs.py [replicas]"""
+"""Per-section cycle attribution of the neighbour-search tick's second kernel (instrumented build: make -C vehicles_dispatch_simulator_amd/csrc prof):
+VDS_LIB=/root/repo/build/libvds_prof.so python profiles/sections_dfs.py [replicas] [first slot] [slots]"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -8,6 +9,12 @@ w = workloads.didi_day("cfg4", neighbor=True, service_m=2000.0)
 env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
 T = env.T
+t0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+T = int(sys.argv[3]) if len(sys.argv) > 3 else T - t0
+if t0:
+    env.run(t0)
+env.sync()
+print("slots %d .. %d" % (t0, t0 + T))
 buf = np.zeros(32, dtype=np.uint64)
 env._lib.vds_debug_read_prof(env._h, buf.ctypes.data)
 env._lib.vds_debug_ablate(env._h, 128)
@@ -21,7 +28,7 @@ if env.main_kernel() == "k_tick_replica3":
     names = ["0 update (drain + hdr)", "1 mirror build", "2 phase 1: own-cluster pass, every bucket once", "3 dry bitset", "4 per dry order: pick + row + candidate scan",
              "5 per dry order: barrier + winner (+ redo) + barrier", None, "7 evaluations + resolve + compaction + flush"]
     nw = R * 8
-if env.main_kernel() == "k_dfs_hybrid":
+if env.main_kernel() in ("k_dfs_hybrid", "k_dfs_dense"):
     # k_dfs_walk, 4 wavefronts per replica: cycles per wavefront and tick between the stamps (all wavefronts wait at the barriers)
     sec = [("tables (ranks, lengths) + barrier", 24), ("prefix of the list lengths + barrier", 25), ("stamps from the preliminary results", 26), ("dry bits + barrier", 0),
            ("the walk (wavefront 0 serves, 1-3 scan)", 1), ("steal log -> results, tk", 29), ("evaluations (a): dry orders' visit rows", 30),

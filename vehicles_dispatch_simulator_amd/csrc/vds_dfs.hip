@@ -1282,9 +1282,13 @@ __global__ __launch_bounds__(WK_THREADS, WK_MIN_WAVES) void k_dfs_walk(Static S,
     for (int c = threadIdx.x; c < C; c += WK_THREADS) {
         if (!(cdA_l[c] & CAPABLE)) continue;
         const int qa = c == 0 ? tq0 : qend_l[c - 1];
-        for (int q = qa + lm_l[c]; q < qend_l[c]; ++q) {
-            const int rk = RT.rq(q - tq0);
-            atomicOr(&dry_bits[rk >> 5], 1u << (rk & 31));
+        for (int q = qa + lm_l[c]; q < qend_l[c]; q += 8) {          // (eight ranks in flight: on the dense layout they come from L2)
+            int rk8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rk8[u] = q + u < qend_l[c] ? RT.rq(q + u - tq0) : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (rk8[u] >= 0) atomicOr(&dry_bits[rk8[u] >> 5], 1u << (rk8[u] & 31));
         }
     }
     __syncthreads();
