@@ -7,7 +7,7 @@ TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 python -c "from vehicles_dispatch_simulator_amd import _lib; print(_lib.load().vds_build_id().decode())" > $O/build_id.txt 2>/dev/null
-B="python bench.py --no-cpu-baseline --no-neighbour-leg --no-hooked-leg --no-fallbacks-leg --no-distinct-all --distinct-days ${DISTINCT:-0} $@"
+B="python bench.py --no-cpu-baseline --no-neighbour-leg --no-hooked-leg --no-fallbacks-leg --no-stress-leg --no-distinct-all --distinct-days ${DISTINCT:-0} $@"
 # The kernel BY ITSELF: one launch per tick over all replicas (VDS_RUN_GROUPS=1) - per-launch durations and counters mean what
 # they say.  The default vds_run (replica groups as parallel branches of the day graph: overlapping half-size launches) is
 # traced once more at the end (stats_groups: profiles/run_groups_trace.py turns it into durations + overlap).

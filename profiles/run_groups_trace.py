@@ -1,5 +1,5 @@
-"""Summarise a rocprofv3 --kernel-trace csv of a grouped run (plain or hybrid tick): the GROUP launches of k_tick_rows /
-k_dfs_walk (grid smaller than the kernel's largest grid in the trace = a launch over replicas / groups replicas), their mean
+"""Summarise a rocprofv3 --kernel-trace csv of a grouped run (plain or neighbour-search tick): the GROUP launches of k_tick_dense /
+k_tick_rows / k_dfs_walk (grid smaller than the kernel's largest grid in the trace = a launch over replicas / groups replicas), their mean
 duration, and inside the spans they cover (a gap of more than 1 ms ends a span: days are replayed back to back) how much of the
 time has 0 / 1 / 2+ of them in flight and the time per tick.
 
@@ -11,8 +11,9 @@ rows, queues = [], []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         n = r["Kernel_Name"]
-        if "k_tick_rows" in n or "k_dfs_walk" in n:
-            rows.append(("rows" if "k_tick_rows" in n else "walk", int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))))
+        # (the tick's first kernel - k_tick_dense on the dense layout, k_tick_rows on the wide one - is "rows" below)
+        if "k_tick_rows" in n or "k_tick_dense" in n or "k_dfs_walk" in n:
+            rows.append(("walk" if "k_dfs_walk" in n else "rows", int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))))
             queues.append(r.get("Queue_Id", "?"))
 gmax = collections.defaultdict(int)
 for k, s, e, g in rows: gmax[k] = max(gmax[k], g)
@@ -38,7 +39,10 @@ for sp in spans:
         tp = t; n[k] += dlt
     wall += ev[-1][0] - ev[0][0]; nl += len(sp)
 print("%d spans, %.2f ms covered by %d group launches" % (len(spans), wall / 1e6, nl))
-for key in sorted(hist): print("k_tick_rows in flight %d, k_dfs_walk in flight %d: %5.1f %%" % (key[0], key[1], 100.0 * hist[key] / max(1, wall)))
+for key in sorted(hist): print("k_tick_dense / k_tick_rows in flight %d, k_dfs_walk in flight %d: %5.1f %%" % (key[0], key[1], 100.0 * hist[key] / max(1, wall)))
+kinds = len({k for k, s, e, g in grp})
+groups = max(1, round(nl / max(1.0, len(spans) * T * kinds)))           # launches per tick and kernel = replica groups
+print("%d replica groups; time per tick as traced: %.1f us (a tracer serialises the queues more than a free run does)" % (groups, wall / 1e3 / max(1, len(spans) * T)))
 
 # gaps between consecutive group launches on the same hardware queue (a branch of the day graph runs on one queue): what a
 # dependent kernel boundary costs inside a chain
