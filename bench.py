@@ -138,7 +138,7 @@ def leg_roofline(env_x, workload_key, replicas, stream, build_id):
         out["limiter"] = {"valu_insts_per_launch": lim["valu_insts_per_launch"], "valu_floor_ms": floor_s * 1e3, "valu_frac": floor_s / tick_s,
                           "wave_wait_frac": lim.get("wave_wait_frac"), "source": lim.get("source")}
         if out["frac"] is not None and out["limiter"]["valu_frac"] > out["frac"]:
-            out["bound"] = "valu-issue" if out["limiter"]["valu_frac"] > 0.5 else "latency (per-replica chain of dry orders: neither HBM nor VALU issue is busy)"
+            out["bound"] = "valu-issue" if out["limiter"]["valu_frac"] > 0.6 else "latency (per-replica chain of dry orders: neither HBM nor VALU issue is busy)"
     return out
 
 

@@ -40,9 +40,8 @@ for sp in spans:
     wall += ev[-1][0] - ev[0][0]; nl += len(sp)
 print("%d spans, %.2f ms covered by %d group launches" % (len(spans), wall / 1e6, nl))
 for key in sorted(hist): print("k_tick_dense / k_tick_rows in flight %d, k_dfs_walk in flight %d: %5.1f %%" % (key[0], key[1], 100.0 * hist[key] / max(1, wall)))
-kinds = len({k for k, s, e, g in grp})
-groups = max(1, round(nl / max(1.0, len(spans) * T * kinds)))           # launches per tick and kernel = replica groups
-print("%d replica groups; time per tick as traced: %.1f us (a tracer serialises the queues more than a free run does)" % (groups, wall / 1e3 / max(1, len(spans) * T)))
+print("(a kernel tracer serialises the hardware queues far more than a free run does: how the chains overlap without one is in inflight.txt - "
+      "launch spans stamped on the device by the instrumented build, profiles/r04/inflight.py)")
 
 # gaps between consecutive group launches on the same hardware queue (a branch of the day graph runs on one queue): what a
 # dependent kernel boundary costs inside a chain
