@@ -204,6 +204,97 @@ class BatchedPolicySim(Simulation):
         return acts
 
 
+class GraphPolicySim(Simulation):
+    """``BatchedPolicy``: the dispatch policy as a pure device function - every slot each replica sends the head of the idle
+    lists of its two fullest clusters towards the cluster with the largest deficit (idle + expected arrivals against waiting
+    orders).  Its state (a slot counter and a log of the actions) lives in CUDA tensors updated in place, so it can be captured."""
+
+    def BatchedPolicy(self, ob):
+        import torch
+        idle, supply, demand = ob["idle_now"], ob["supply"], ob["cl_orders"]
+        R, C = idle.shape
+        K = 2
+        cnt, src = torch.topk(idle, K, dim=1)
+        deficit = demand - idle - supply + torch.arange(C, device=idle.device, dtype=torch.int32)[None, :] % 3
+        tgt_cluster = torch.argmax(deficit, dim=1)
+        tgt_node = self.first_node[tgt_cluster].to(torch.int32)
+        ok = (cnt >= 2) & (src != tgt_cluster[:, None])
+        acts = torch.stack([torch.where(ok, src, torch.full_like(src, -1)).to(torch.int32), torch.zeros((R, K), dtype=torch.int32, device=idle.device),
+                            tgt_node[:, None].expand(R, K)], dim=2).contiguous()
+        self.log.index_copy_(0, self.slot, acts[None])
+        self.slot += 1
+        return acts
+
+    def BatchedPolicyBegin(self):
+        self.slot.zero_()
+        self.log.fill_(-1)
+        self.begin_calls += 1
+
+
+def test_batched_policy_runs_as_one_day_graph_and_matches_oracle_replay():
+    """``BatchedHooks`` + ``BatchedPolicy``: the reference-API user reaches ``vds_run_hooked`` - the captured policy inside the day
+    graph, one launch per day.  Every replica equals a CPU oracle replaying the actions the policy logged on the device; the
+    slot-by-slot form of the same policy (``BatchedPolicyGraph = False``) gives the same day."""
+    import torch
+    g = load_golden("tiny_kmeans")
+    R = 32
+    n2c = g["node2cluster"]
+    C = int(g["C"])
+    first_node = torch.tensor([int(np.flatnonzero(n2c == c)[0]) if (n2c == c).any() else 0 for c in range(C)], device="cuda")
+    days = {}
+    for graph in (True, False):
+        sim = make_sim(g, GraphPolicySim, Replicas=R, VehicleSeed=977, BatchedHooks=True)
+        T = sim.env.T
+        sim.BatchedPolicyGraph = graph
+        sim.first_node, sim.begin_calls = first_node, 0
+        sim.slot = torch.zeros(1, dtype=torch.int64, device="cuda")
+        sim.log = torch.full((T + 4, R, 2, 3), -1, dtype=torch.int32, device="cuda")
+        init = sim._init_nodes.copy()
+        sim.SimCity()
+        assert sim.step == T and sim.begin_calls == 1
+        if graph:
+            assert sim.BatchedPolicyGraphError is None, sim.BatchedPolicyGraphError
+        assert int(sim.slot.item()) == T
+        log = sim.log.cpu().numpy()
+        assert (log[T:] == -1).all()
+        got, cn = sim.env.orders(), sim.env.counters()
+        days[graph] = (got, cn, log)
+        if graph:
+            n_dispatched = 0
+            for r in range(R):
+                o = make_oracle(g)
+                o.reset(init[r])
+                for t in range(T):
+                    o.begin_tick()
+                    L = o.lists()
+                    vehs, tgts = [], []
+                    for cl, pos, tg in log[t, r]:
+                        if cl >= 0:
+                            vehs.append(int(L["idle_veh"][L["idle_off"][cl] + pos])); tgts.append(int(tg))
+                    if vehs:
+                        o.dispatch(np.array(vehs), np.array(tgts))
+                        n_dispatched += len(vehs)
+                    o.end_tick()
+                exp, oc = o.orders(), o.counters()
+                for k in ("status", "vehicle", "wait"):
+                    np.testing.assert_array_equal(got[k][r], exp[k], err_msg="replica %d %s" % (r, k))
+                assert (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 4], cn[r, 5], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["dispatch_num"], oc["dispatch_cost"], oc["evals"]), r
+            assert n_dispatched > R * 20
+            assert sim.RejectNum == cn[0, 1] and sim.DispatchNum == cn[0, 4]
+            # a second episode on the same handle reuses the capture (and the library's day graph)
+            st = sim._bp_state
+            sim.Reset()
+            sim.SimCity()
+            assert sim._bp_state is st and sim.begin_calls == 2 and int(sim.slot.item()) == T and sim.step == T
+            cn2 = sim.env.counters()
+            assert (cn2[:, 0] == cn[:, 0]).all() and int(cn2[:, 4].sum()) > R * 20
+        sim.env.close()
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(days[True][0][k], days[False][0][k])
+    np.testing.assert_array_equal(days[True][1], days[False][1])
+    np.testing.assert_array_equal(days[True][2], days[False][2])
+
+
 def test_batched_hooks_policy_over_all_replicas_matches_oracle_replay():
     """``BatchedHooks``: hook order as SimCity's, observations / policy / actions on the device for 64 cities; every
     replica equals a CPU oracle that replays ITS action log (vehicle = head of the named idle list at that moment)."""

@@ -24,7 +24,10 @@ What a maintainer should know (also in INTEGRATION.md):
     ``inflight`` = len(VehiclesArrivetime)), ``self.BatchedCounters()`` the per-replica counters ``[Replicas, 8]``, and
     ``DispatchFunction`` may RETURN an int32 CUDA tensor ``[Replicas, K, 3]`` of ``(from_cluster, idle_pos, target_node)``
     actions (``from_cluster < 0``: none), applied on the device (``vds_apply_dispatch_device``) - nothing leaves the GPU.
-    The object views (``Clusters`` / ``Vehicles`` / ``Orders``) of replica ``Replica`` are refreshed once, after the day.
+    The object views (``Clusters`` / ``Vehicles`` / ``Orders``) of replica ``Replica`` are refreshed once, after the day;
+  * ``BatchedHooks=True`` with ``BatchedPolicy(obs)`` overridden (and no per-slot Python hook): the policy is captured ONCE as a
+    graph and the whole day - per slot Update + Match + SupplyExpect, observation planes, policy, dispatch, next slot
+    (:1048-1091) - is ONE graph launch (``vds_run_hooked``); see ``BatchedPolicy``.
 """
 from __future__ import annotations
 
@@ -579,6 +582,67 @@ class Simulation(object):
         rejects, wait_sum, matched_value_sum, evals, arrivals, dispatch_num, dispatch_cost); valid until the next call."""
         return self.env.counters_torch()
 
+    # ---- BatchedHooks, the dispatch policy as part of the day graph ------------------------------------------------
+    BatchedPolicyPlanes = ("idle_pre", "idle_now", "supply", "cl_orders")     # observation planes the policy reads (add "inflight" if it does)
+    BatchedPolicyGraph = True                                                  # False: call ``BatchedPolicy`` slot by slot (debugging, A/B)
+
+    def BatchedPolicy(self, obs):
+        """``BatchedHooks``: the body of a ``DispatchFunction`` (:893-898) for ALL replicas as a pure device function.  ``obs``: dict of
+        CUDA int32 tensors ``[Replicas, clusters]`` (``BatchedPolicyPlanes``) at fixed addresses; return a contiguous int32 CUDA
+        tensor ``[Replicas, K, 3]`` of ``(from_cluster, idle_pos, target_node)`` actions (``from_cluster < 0``: none) - always the
+        same shape.  Overridden, with none of the per-slot Python hooks (``RewardFunction`` ...) overridden, it is captured once
+        (``torch.cuda.graph``: torch ops on static shapes, no ``.item()`` / host branches on tensor values; state it keeps between
+        slots lives in CUDA tensors it updates in place) and embedded into the day graph: ``SimCity`` is then one graph launch per
+        day (``vds_run_hooked``) and the host is not involved per slot.  It is CALLED twice before the first day (warm-up, on the
+        observation block as it stands) and once under capture (nothing runs); ``BatchedPolicyBegin`` is called before every day,
+        after those calls: reset the policy's device state there."""
+        return None
+
+    def BatchedPolicyBegin(self):
+        """Called before each day of the ``BatchedPolicy`` form (after warm-up and capture)."""
+
+    def _policy_overridden(self):
+        return getattr(type(self), "BatchedPolicy") is not Simulation.BatchedPolicy
+
+    def _policy_obs(self):
+        planes = dict((k, k in self.BatchedPolicyPlanes) for k in ("idle_pre", "idle_now", "supply", "cl_orders", "inflight"))
+        blk = self.env.obs_torch(**planes)              # the library's block: fixed address, rewritten by every slot's observation pass
+        return {k: blk[i] for i, k in enumerate(("idle_pre", "idle_now", "supply", "cl_orders", "inflight")) if planes[k]}, planes
+
+    def _policy_day_graph(self):
+        """The captured policy for this handle (made on first use): (actions tensor, graph, planes) or None when it cannot be
+        captured (the reason is kept in ``self.BatchedPolicyGraphError``; the caller then runs slot by slot)."""
+        import torch
+        st = getattr(self, "_bp_state", None)
+        if st is not None and st["env"] is self.env:
+            return st
+        self.BatchedPolicyGraphError = None
+        obs, planes = self._policy_obs()
+        try:
+            cur = torch.cuda.current_stream(self.env.device)
+            side = torch.cuda.Stream(self.env.device)
+            side.wait_stream(cur)
+            acts = None
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    a = self.BatchedPolicy(obs)
+                    if acts is None:
+                        acts = torch.empty_like(a)
+                    acts.copy_(a)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.env.device)
+            if acts.dtype != torch.int32 or acts.dim() != 3 or acts.shape[0] != self.env.R or acts.shape[2] != 3:
+                raise Exception("BatchedPolicy must return an int32 tensor [Replicas, K, 3]")
+            g = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(g):
+                acts.copy_(self.BatchedPolicy(obs))
+        except Exception as e:
+            self.BatchedPolicyGraphError = repr(e)
+            self._bp_state = None
+            return None
+        self._bp_state = dict(env=self.env, obs=obs, planes=planes, actions=acts, graph=g)
+        return self._bp_state
+
     def _hooks_overridden(self):
         fused = [h for h in _FUSED if getattr(type(self), h, None) is not getattr(Simulation, h, None)]
         if fused:
@@ -586,7 +650,7 @@ class Simulation(object):
                             "launch for all replicas and cannot be replaced from Python - put the custom logic into "
                             "DispatchFunction / RewardFunction / GetNextStateFunction / LearningFunction / "
                             "DemandPredictFunction, or use the reference for this experiment" % ", ".join(fused))
-        return self.DispatchModule is not None or any(getattr(type(self), h) is not getattr(Simulation, h) for h in _HOOKS)
+        return self.DispatchModule is not None or self._policy_overridden() or any(getattr(type(self), h) is not getattr(Simulation, h) for h in _HOOKS)
 
     def FindServerVehicleFunction(self, *a, **k):
         raise Exception("FindServerVehicleFunction (simulator.py:978-996) runs inside the fused device launch")
@@ -668,10 +732,31 @@ class Simulation(object):
             self.step = T
             self.RealExpTime = self.RealExpTime + T * pd.Timedelta(minutes=tm)
             self.TotallyMatchTime += dt.datetime.now() - t0
+        elif (self.BatchedHooks and self.BatchedPolicyGraph and self._policy_overridden()
+              and not any(getattr(type(self), h) is not getattr(Simulation, h) for h in _HOOKS) and self._policy_day_graph() is not None):
+            # the slot loop (:1048-1091) of all replicas as ONE graph launch: tick -> observation planes -> the captured policy ->
+            # dispatch -> next slot (vds_run_hooked); the host comes back at the end of the day
+            st = self._policy_day_graph()
+            T = self.env.T
+            self.BatchedObs = st["obs"]
+            self.BatchedPolicyBegin()
+            t = dt.datetime.now()
+            self.env.run_hooked(T, actions=st["actions"], policy_graph=st["graph"], **st["planes"])
+            self.env.sync()
+            self.TotallyMatchTime += dt.datetime.now() - t
+            self.step += T
+            self.RealExpTime += T * self.TimePeriods
+            self._stepped_current = False
+            self._touch()
+            self._pull_counters()
+            self._rebuild_mirror_from_device()
+            self._refresh_containers()
         elif self.BatchedHooks:
             # the reference's slot loop (:1048-1091) for all replicas at once: observations, policy and actions stay on the GPU
             names = ("idle_pre", "idle_now", "supply", "cl_orders", "inflight")
             T = self.env.T
+            if self._policy_overridden():
+                self.BatchedPolicyBegin()
             for _ in range(T):
                 t = dt.datetime.now(); self.env.step(); self.TotallyMatchTime += dt.datetime.now() - t     # Update + Match + SupplyExpect
                 ob = self.env.obs_torch()
@@ -682,6 +767,8 @@ class Simulation(object):
                 t = dt.datetime.now(); self.DemandPredictFunction(); self.TotallyDemandPredictTime += dt.datetime.now() - t
                 t = dt.datetime.now()
                 acts = self.DispatchFunction()
+                if acts is None and self._policy_overridden():        # (the policy form, slot by slot: other hooks overridden, or no capture)
+                    acts = self.BatchedPolicy({k: self.BatchedObs[k] for k in self.BatchedPolicyPlanes})
                 if acts is not None:
                     self.env.apply_dispatch_torch(acts)
                 self.TotallyDispatchTime += dt.datetime.now() - t
