@@ -45,6 +45,10 @@ int vds_debug_poke_guard(vds_handle *h);
 /* executable day graphs parked in the process-wide pool right now (vds_run, tests/test_gpu_run_groups.py) */
 int vds_debug_graph_pool_size(void);
 
+/* k_tick_dense's per-slot form as the handle stands (vds_api.hip adapt_dense): out[t] = 1 where slot t runs 16 lanes per replica with
+ * 256-entry tables whatever the base form, 0 where it runs the base form; *n_out = slots written (0: no per-slot choice was made). */
+int vds_debug_tick_forms(vds_handle *h, uint8_t *out, int32_t cap, int32_t *n_out);
+
 /* DPP primitives of the kernels on nwaves x 64 int32 values (tests/test_gpu_primitives.py): out_wave [nwaves] wavefront
  * minima; out_rowmin / out_rowsum / out_rowscan [nwaves * 64] per-lane 16-lane-row minimum, row sum and inclusive row scan */
 int vds_selftest_dpp(vds_handle *h, const int32_t *in, int32_t *out_wave, int32_t *out_rowmin, int32_t *out_rowsum,

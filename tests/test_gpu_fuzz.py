@@ -115,6 +115,9 @@ def run_case(seed, case, idle_cap=None, whole_day=False):
     # are loaded: k_tick_rows in stamp mode + the committing walk) instead of the dense layout's stamp form
     if fg == 0 and cfg["neighbor"] and lr.random() < 0.34:
         os.environ["VDS_DENSE_DFS"] = "0"
+    # ... and a third of the dense-tick cases alternate its two forms slot by slot (what the per-slot choice mixes within a day)
+    if fg == 0 and np.random.default_rng(170_000 + seed).random() < 0.34:
+        os.environ["VDS_DENSE_TICK_FORMS"] = "alt"
     try:
         env = BatchedDispatchEnv(cost, n2c, off, idx, replicas=R, vehicles=V, depth_limit=cfg["depth"], neighbor_can_server=cfg["neighbor"],
                                  tick_minutes=cfg["tick"], reject_threshold=cfg["threshold"], ring_ticks=cfg["ring_ticks"],
@@ -122,6 +125,7 @@ def run_case(seed, case, idle_cap=None, whole_day=False):
         env.load_orders(rel, pick, dele)
     finally:
         os.environ.pop("VDS_DENSE_DFS", None)
+        os.environ.pop("VDS_DENSE_TICK_FORMS", None)
     env.reset(init)
     oracles = []
     for r in range(R):

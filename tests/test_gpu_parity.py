@@ -194,6 +194,10 @@ MODES = {
     "dense_ring8_tiny": {"dense_debug": (8, 12, 3, 2)},
     "dense_ring_slow": {"dense_debug": (16, 0, 0, 3)},
     "dense_ring_far": {"dense_debug": (8, 0, 0, 2), "ring_ticks": 2},
+    # the dense tick's two forms (8 lanes per replica / 16 lanes with 256-entry tables) alternating slot by slot: what the per-slot
+    # choice of adapt_dense mixes within a day
+    "dense_alt": {"environ": {"VDS_DENSE_TICK_FORMS": "alt"}},
+    "dense_alt_tiny8": {"dense_debug": (8, 12, 3, 0), "environ": {"VDS_DENSE_TICK_FORMS": "alt"}},
     "rows": {"force_generic": 5},            # wide layout + the row-mapped kernel where the dense tick is the default
     "rows_far": {"force_generic": 5, "ring_ticks": 2},
     # a ring horizon beyond the dense keys' 32 slots (any power of two is valid): the library keeps the wide layout and must not

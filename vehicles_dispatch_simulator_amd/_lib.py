@@ -93,7 +93,7 @@ SYMBOLS = {
     "vds_main_kernel": (C.c_char_p, [_VP]),
     "vds_dfs_sequences": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, C.c_int64]),
 }
-TEST_SYMBOLS = {"vds_debug_read_span": (C.c_int, [_VP, _VP, _I32]), "vds_debug_read_err": (C.c_int, [_VP, _VP]), "vds_debug_graph_pool_size": (C.c_int, []), "vds_debug_check_guards": (C.c_int, [_VP]), "vds_debug_poke_guard": (C.c_int, [_VP]), "vds_debug_dense": (C.c_int, [_VP, _I32, _I32, _I32, _I32]), "vds_debug_ablate": (C.c_int, [_VP, _I32]), "vds_debug_read_prof": (C.c_int, [_VP, _VP]), "vds_selftest_dpp": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32])}
+TEST_SYMBOLS = {"vds_debug_read_span": (C.c_int, [_VP, _VP, _I32]), "vds_debug_read_err": (C.c_int, [_VP, _VP]), "vds_debug_graph_pool_size": (C.c_int, []), "vds_debug_tick_forms": (C.c_int, [_VP, _VP, _I32, _VP]), "vds_debug_check_guards": (C.c_int, [_VP]), "vds_debug_poke_guard": (C.c_int, [_VP]), "vds_debug_dense": (C.c_int, [_VP, _I32, _I32, _I32, _I32]), "vds_debug_ablate": (C.c_int, [_VP, _I32]), "vds_debug_read_prof": (C.c_int, [_VP, _VP]), "vds_selftest_dpp": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32])}
 
 _lib = None
 

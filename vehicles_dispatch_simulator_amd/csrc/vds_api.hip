@@ -245,8 +245,14 @@ struct vds_handle {
     int *pin_slow = nullptr;                 // pinned host word: buckets the last finished episode handed to the slow path
     hipEvent_t pin_ev = nullptr;             // recorded behind the copy into pin_slow
     long long pin_bucket_ticks = 0;          // bucket-ticks of that episode (0: nothing copied yet)
+    int *pin_slow_tick = nullptr; int pin_slow_cap = 0;      // ... and per slot (State.slow_tick), when the episode ran the whole day in the base form
+    bool pin_ticks_valid = false;
+    int tick_mode = 1, tick_lim = -1;        // VDS_DENSE_TICK_FORMS (0 one form per day, 1 per slot, 2 alternating: tests), VDS_DENSE_TICK_LIM (buckets; < 0: the default rule) as read when the day was loaded
+    std::vector<unsigned char> tick_form;    // per slot: 1 = k_tick_dense with 16 lanes per replica and 256-entry tables whatever S.dense_lpr says (adapt_dense)
+    Static S_alt;                            // S with that form (tick_static)
     int dense_adapt = 0;                     // 0 undecided (8 lanes), 1 switched to 16 lanes / 256-entry tables; -1 fixed by the caller / environment
     unsigned tables_gen = 0;                 // bumped with run_stale: what a graph was built for (the hooked day graph keeps its own copy)
+    unsigned long long run_kshape = 0, hook_kshape = 0;      // graph_shape of the graphs run_exec / hook_exec were made from
     bool run_stale = false;                  // tables / capacities changed since the graph was built: same shape -> hipGraphExecUpdate
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
@@ -431,13 +437,24 @@ static unsigned long long graph_shape(hipGraph_t g, int n_ticks, int G) {
     mix(n); mix(n_edges); mix((unsigned long long)n_ticks); mix((unsigned long long)G);
     std::vector<hipGraphNode_t> nodes(n);
     if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const size_t first = std::min(n, (size_t)(2 * G));
-    for (size_t i = 0; i < first; ++i) {
+    // every kernel node's function and launch shape (the slots of a day may run different forms of k_tick_dense: adapt_dense)
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        mix((unsigned long long)ty);
+        if (ty != hipGraphNodeTypeKernel) continue;
         hipKernelNodeParams kp{};
         if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { (void)hipGetLastError(); return 0; }
         mix((unsigned long long)(uintptr_t)kp.func); mix(kp.blockDim.x); mix(kp.sharedMemBytes);
     }
     return hsh ? hsh : 1;
+}
+extern "C" int vds_debug_tick_forms(vds_handle *h, uint8_t *out, int32_t cap, int32_t *n_out) {
+    if (!h || !out || !n_out || cap < 0) return VDS_EINVAL;
+    const int n = (int)std::min<size_t>(h->tick_form.size(), (size_t)cap);
+    for (int i = 0; i < n; ++i) out[i] = h->tick_form[i];
+    *n_out = n;
+    return VDS_OK;
 }
 extern "C" int vds_debug_graph_pool_size() {      // executable graphs parked right now (tests)
     std::lock_guard<std::mutex> lk(g_graph_pool_mu);
@@ -656,6 +673,7 @@ int vds_destroy(vds_handle *h) {
     drop_run_graph(h);
     if (h->pin_ev) (void)hipEventDestroy(h->pin_ev);
     if (h->pin_slow) (void)hipHostFree(h->pin_slow);
+    if (h->pin_slow_tick) (void)hipHostFree(h->pin_slow_tick);
     if (h->d_S) (void)hipFree(h->d_S);
     if (h->d_D) (void)hipFree(h->d_D);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1002,6 +1020,8 @@ static int alloc_state(vds_handle *h, int O) {
         h->alloc_sink = keep;
         if (rc) return rc;
     }
+    D.slow_tick = nullptr;
+    if (S.dense && (rc = dev_alloc(h, &D.slow_tick, (size_t)std::max(S.T, 1)))) return rc;
     D.dry = nullptr;
     if (S.dense_st && (rc = dev_alloc(h, &D.dry, (size_t)R))) return rc;
     D.sup = nullptr; D.sup_slot = nullptr;           // SupplyExpect kept in place (dense layout): planes by arrival slot + the current plane's index
@@ -1402,7 +1422,8 @@ static int load_days_body(vds_handle *h, int32_t n_days, const int64_t *day_off,
         const int tab_max = (S.dense_lpr == 16 && S.blk8s != nullptr && env_int("VDS_DENSE_TAB256", 1) != 0) ? 256 : 128;
         // (another day on the handle: the choice between 8 and 16 lanes per replica is open again, unless the caller fixed it)
         h->dense_adapt = (h->dbg_dense_lpr > 0 || h->dbg_dense_tab > 0 || getenv("VDS_DENSE_LPR") || env_int("VDS_DENSE_ADAPT", 1) == 0) ? -1 : 0;
-        h->pin_bucket_ticks = 0;
+        h->pin_bucket_ticks = 0; h->pin_ticks_valid = false; h->tick_form.clear();
+        { const char *v = getenv("VDS_DENSE_TICK_FORMS"); h->tick_mode = !v || !*v ? 1 : (*v == '0' ? 0 : (*v == 'a' ? 2 : 1)); h->tick_lim = env_int("VDS_DENSE_TICK_LIM", -1); }
         S.dense_tab = h->dbg_dense_tab > 0 ? std::min(h->dbg_dense_tab, tab_max) : tab_max;
         S.dense_keys = h->dbg_dense_keys > 0 ? std::min(h->dbg_dense_keys, 64) : 64;
         S.dense_force_slow = h->dbg_dense_slow & 1;
@@ -1623,9 +1644,33 @@ int vds_num_ticks(const vds_handle *h, int32_t *T) {
 #ifndef DENSE_ADAPT_RATE
 #define DENSE_ADAPT_RATE 0.001
 #endif
+// ... and per SLOT: the lists are long in some hours of the day and short in others, and the days of a handle resemble each other -
+// a slot in which more than DENSE_TICK_RATE of the buckets left the fast path (State.slow_tick of an episode that ran the whole day
+// in the 8-lane form) runs the 16-lane form from then on, the others keep the 8-lane form (k_tick_dense per day, one chain: configs[1]
+// 7.13 -> 6.8 ms, configs[3] stamp form 9.56 -> 8.8 ms, configs[4] 10.5 ms either way; profiles/r06/tick_forms_*.txt).  VDS_DENSE_TICK_FORMS=0: one form for the whole day as before (the rule
+// above); =alt: the forms alternate slot by slot from the first episode on (tests: results do not depend on the form).
+#ifndef DENSE_TICK_RATE
+#define DENSE_TICK_RATE 0.00025         // (of the slot's buckets, at least DENSE_TICK_MIN of them: 49 at configs[1] / [3], 66 at configs[4] - tick_forms_*.txt
+#define DENSE_TICK_MIN 32               // list the day under rules from 16 to 384: flat between 32 and 96, configs[4] wants the low end)
+#endif
+static const Static &tick_static(vds_handle *h, int t) {
+    if (t < 0 || (size_t)t >= h->tick_form.size() || !h->tick_form[t]) return h->S;
+    h->S_alt = h->S;
+    h->S_alt.dense_lpr = 16; h->S_alt.dense_tab = 256;
+    return h->S_alt;
+}
 static void adapt_dense(vds_handle *h) {
     Static &S = h->S;
-    if (!S.dense || (h->dfs_mode && !S.dense_st) || S.n_days > 1 || h->dense_adapt != 0 || !S.blk8s) return;
+    if (!S.dense || (h->dfs_mode && !S.dense_st) || S.n_days > 1 || !S.blk8s) return;
+    if (h->tick_mode == 2) {          // (tests; also with the base form fixed by vds_debug_dense)
+        if (S.dense_lpr == 8 && h->tick_form.empty()) {
+            h->tick_form.assign((size_t)std::max(S.T, 1), 0);
+            for (size_t t = 1; t < h->tick_form.size(); t += 2) h->tick_form[t] = 1;
+            h->run_stale = true; h->tables_gen++;
+        }
+        return;
+    }
+    if (h->dense_adapt != 0) return;
     if (!h->pin_slow) {
         if (hipHostMalloc((void **)&h->pin_slow, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError(); h->dense_adapt = -1; return;
@@ -1633,6 +1678,17 @@ static void adapt_dense(vds_handle *h) {
         *h->pin_slow = 0;
     }
     if (h->pin_bucket_ticks > 0 && hipEventQuery(h->pin_ev) == hipSuccess) {
+        if (h->tick_mode == 1 && h->pin_ticks_valid && S.dense_lpr == 8) {
+            // per slot; decided once (the counters of the 16-lane form say nothing about the 8-lane form)
+            const double lim = h->tick_lim >= 0 ? (double)h->tick_lim : std::max((double)DENSE_TICK_MIN, DENSE_TICK_RATE * (double)S.R * (double)S.C);
+            size_t n16 = 0;
+            h->tick_form.assign((size_t)S.T, 0);
+            for (int t = 0; t < S.T; ++t) if ((double)h->pin_slow_tick[t] > lim) { h->tick_form[t] = 1; ++n16; }
+            h->dense_adapt = 1;
+            if (n16 > 0) { h->run_stale = true; h->tables_gen++; }           // the day graph holds the other kernel
+            else h->tick_form.clear();
+            return;
+        }
         if ((double)*h->pin_slow > DENSE_ADAPT_RATE * (double)h->pin_bucket_ticks) {
             const char *t256 = getenv("VDS_DENSE_TAB256");
             S.dense_lpr = 16; S.dense_tab = (t256 && *t256 == '0') ? 128 : 256;
@@ -1644,9 +1700,20 @@ static void adapt_dense(vds_handle *h) {
     (void)hipGetLastError();
     // the episode that ends here (h->t slots of it were run)
     if (h->have_reset && h->t > 0) {
-        if (hipMemcpyAsync(h->pin_slow, h->D.err + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipEventRecord(h->pin_ev, h->stream) == hipSuccess)
+        h->pin_ticks_valid = false;
+        bool ok = hipMemcpyAsync(h->pin_slow, h->D.err + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+        if (ok && h->tick_mode == 1 && h->D.slow_tick && h->t == S.T && S.T > 0) {
+            if (h->pin_slow_cap < S.T) {
+                if (h->pin_slow_tick) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->pin_slow_tick); h->pin_slow_tick = nullptr; h->pin_slow_cap = 0; }
+                if (hipHostMalloc((void **)&h->pin_slow_tick, (size_t)S.T * sizeof(int)) == hipSuccess) h->pin_slow_cap = S.T;
+                else { (void)hipGetLastError(); h->pin_slow_tick = nullptr; }
+            }
+            if (h->pin_slow_tick && hipMemcpyAsync(h->pin_slow_tick, h->D.slow_tick, (size_t)S.T * sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess)
+                h->pin_ticks_valid = true;
+        }
+        if (ok && hipEventRecord(h->pin_ev, h->stream) == hipSuccess)
             h->pin_bucket_ticks = (long long)h->t * S.R * S.C;
-        else { (void)hipGetLastError(); h->pin_bucket_ticks = 0; }
+        else { (void)hipGetLastError(); h->pin_bucket_ticks = 0; h->pin_ticks_valid = false; }
     }
 }
 
@@ -1655,6 +1722,7 @@ static int reset_device(vds_handle *h) {
     const Static &S = h->S;
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 16 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
+    if (h->D.slow_tick) HIPCHK(h, hipMemsetAsync(h->D.slow_tick, 0, (size_t)std::max(S.T, 1) * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
     if (h->D.sup) {
         HIPCHK(h, hipMemsetAsync(h->D.sup, 0, (size_t)VDS_SUP_PLANES * S.C * S.R * sizeof(int), h->stream));
@@ -1888,7 +1956,7 @@ static int step_impl(vds_handle *h, bool flush = true) {
         if (h->S.dense) {
             const int rcs = dev_copy_sync(h);
             if (rcs) return rcs;
-            Emit e; e.st = h->stream; emit_tick_dense(e, h->S, h->D, h->t, 0, 0);
+            Emit e; e.st = h->stream; emit_tick_dense(e, tick_static(h, h->t), h->D, h->t, 0, 0);
         }
         else launch_tick_main(h->S, h->D, h->t, h->lds_ints, h->stream);
         if (h->profiling) HIPCHK(h, hipEventRecord(b, h->stream));
@@ -1909,7 +1977,7 @@ static int step_impl(vds_handle *h, bool flush = true) {
             const int rcs = dev_copy_sync(h);
             if (rcs) return rcs;
             Emit e; e.st = h->stream;
-            emit_tick_dense(e, h->S, h->D, h->t, 0, 0);
+            emit_tick_dense(e, tick_static(h, h->t), h->D, h->t, 0, 0);
             emit_hybrid_walk(e, h->S, h->D, h->t, 0, 0);
             if (flush) emit_dense_flush(e, h->S, h->D, 0, 0);
         }
@@ -2021,14 +2089,14 @@ static int build_group_graph(vds_handle *h, int32_t n_ticks, int G, hipGraph_t *
             Emit e;
             e.graph = g; e.deps = deps; e.ndeps = nd; e.node = &rows; e.err = &err;
             if (!h->dfs_mode) {                 // plain tick: the row-mapped kernel is the whole tick
-                if (h->S.dense) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
+                if (h->S.dense) emit_tick_dense(e, tick_static(h, t), h->D, t, r_lo, r_n);
                 else emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
                 if (err != hipSuccess) break;
                 prev_rows = rows;
                 last[gi] = rows;
                 continue;
             }
-            if (h->S.dense_st) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);          // (stamp form)
+            if (h->S.dense_st) emit_tick_dense(e, tick_static(h, t), h->D, t, r_lo, r_n);          // (stamp form)
             else emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
             if (err != hipSuccess) break;
             prev_rows = rows;
@@ -2087,14 +2155,16 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
         // same shape as the graph at hand (new order tables, another first slot): its kernel parameters are replaced in place -
         // no destruction (see drop_run_graph for what that costs), no instantiation
         bool updated = false;
-        if (h->run_exec && h->run_n == n_ticks && h->run_G == G) {
+        const unsigned long long kshape = graph_shape(g, n_ticks, G);       // (kernels and launch shapes of all nodes: an update in place keeps them)
+        if (h->run_exec && h->run_n == n_ticks && h->run_G == G && kshape != 0 && kshape == h->run_kshape) {
             (void)hipStreamSynchronize(h->run_stream);          // (run_exec was launched there; nullptr = legacy default stream)
             hipGraphNode_t bad = nullptr;
             hipGraphExecUpdateResult res;
             updated = hipGraphExecUpdate(h->run_exec, g, &bad, &res) == hipSuccess;
             if (!updated) (void)hipGetLastError();
         }
-        const unsigned long long shape = G > 1 ? graph_shape(g, n_ticks, G) : 0ull;
+        const unsigned long long shape = G > 1 ? kshape : 0ull;
+        h->run_kshape = kshape;
         if (!updated) {
             drop_run_graph(h);
             // a parked executable graph of this shape (another handle's, or this handle's from before): re-targeted in place
@@ -2200,10 +2270,10 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
                 Emit e;
                 e.graph = g; e.deps = last[gi] ? &last[gi] : nullptr; e.ndeps = last[gi] ? 1 : 0; e.node = &n1; e.err = &err;
                 if (!h->dfs_mode) {
-                    if (h->S.dense) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
+                    if (h->S.dense) emit_tick_dense(e, tick_static(h, t), h->D, t, r_lo, r_n);
                     else emit_tick_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
                 } else {
-                    if (h->S.dense_st) emit_tick_dense(e, h->S, h->D, t, r_lo, r_n);
+                    if (h->S.dense_st) emit_tick_dense(e, tick_static(h, t), h->D, t, r_lo, r_n);
                     else emit_hybrid_rows(e, h->S, h->D, t, h->lds_ints, r_lo, r_n);
                     if (err != hipSuccess) break;
                     e.deps = &n1; e.ndeps = 1; e.node = &n2;
@@ -2263,7 +2333,9 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
             return fail(h, VDS_EHIP, "vds_run_hooked: building the day graph failed: %s", hipGetErrorString(err));
         }
         bool updated = false;
-        if (h->hook_exec && h->hook_n == n_ticks && h->hook_G == G && (h->hook_planes != 0) == (planes != 0) && (h->hook_K > 0) == (K > 0) && (h->hook_policy != nullptr) == (policy_graph != nullptr)) {
+        const unsigned long long kshape = graph_shape(g, n_ticks, G);
+        if (h->hook_exec && h->hook_n == n_ticks && h->hook_G == G && (h->hook_planes != 0) == (planes != 0) && (h->hook_K > 0) == (K > 0) && (h->hook_policy != nullptr) == (policy_graph != nullptr) &&
+            kshape != 0 && kshape == h->hook_kshape) {
             (void)hipStreamSynchronize(h->hook_stream);
             hipGraphNode_t bad = nullptr;
             hipGraphExecUpdateResult res;
@@ -2272,7 +2344,8 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
         }
         // (grouped hooked graphs are parked under their shape - nodes, edges, first kernels - salted so that they never meet a vds_run
         // graph, and taken back from the pool like those: a rebuild that an in-place update cannot cover does not leak an executable)
-        const unsigned long long shape = G > 1 ? (graph_shape(g, n_ticks, G) ^ 0x9E3779B97F4A7C15ull) | 1ull : 0ull;
+        const unsigned long long shape = G > 1 ? (kshape ^ 0x9E3779B97F4A7C15ull) | 1ull : 0ull;
+        h->hook_kshape = kshape;
         if (!updated) {
             drop_hook_graph(h);
             if (G > 1 && shape != 0) {

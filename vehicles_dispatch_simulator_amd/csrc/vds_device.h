@@ -188,6 +188,8 @@ struct State {
     unsigned *arr;       // dense layout with static arrival slots: [slots of the longest day][R] pull_entry / pull_reject (arr_index)
     unsigned short *stamp; // dense neighbour-search tick: [C][R][idle_cap] per idle entry 0xFFFF (alive) or the rank - position in id order inside
                          // the slot - of the order that took it during the last slot; valid for positions below the list's raw length
+    int *slow_tick;      // dense layout: [T] buckets that left k_tick_dense's fast path, per slot of the running episode (what the per-slot
+                         // choice between its two forms is made from: vds_api.hip adapt_dense)
     int *dry;            // dense neighbour-search tick: [R] buckets of the replica whose orders outran the list in a searching cluster
                          // during this slot (k_tick_dense adds, k_dfs_walk reads and clears: 0 = nothing to walk)
     int *sup;            // dense layout: [VDS_SUP_PLANES][C][R] SupplyExpect kept in place (:880-891) - plane a & 31 counts the order-carrying vehicles that

@@ -88,7 +88,7 @@ struct DenseArgs {
     unsigned *arr; const int *so_slot; const int2 *d_rec; const int *d_first; const int4 *replica_desc2; int pull_W;
     const int4 *tdesc;               // (one shared day) per-bucket descriptors, Static.tdesc
     // stamp form (ST: neighbour search on the dense layout, vds_device.h Static.dense_st)
-    unsigned short *stamp; int *dry; const int *so_rank;
+    unsigned short *stamp; int *dry; int *slow_tick; const int *so_rank;
     int *sup, *sup_slot;             // SupplyExpect in place (State.sup): planes by arrival slot
     const Static *Sdev; const State *Ddev;
 };
@@ -1312,7 +1312,10 @@ __global__ __launch_bounds__(ROWS * LPR, TABMAX > 128 ? DN_MIN_WAVES256 : (LPR =
     }
 #endif
     const unsigned long long badrows = ballot(bad && lg == 0);
-    if (badrows != 0ull && lane == 0) atomicAdd(&D.err[2], popc64(badrows));      // buckets that leave the fast path: vds_read_work
+    if (badrows != 0ull && lane == 0) {      // buckets that leave the fast path: vds_read_work; per slot: what the choice of this kernel's form is made from
+        atomicAdd(&D.err[2], popc64(badrows));
+        if (D.slow_tick != nullptr) atomicAdd(&D.slow_tick[t], popc64(badrows));
+    }
     if (bad) { rowvalid = false; m = 0; A = 0; Aring = 0; }
     if (!rowvalid) m_raw = 0;
     const bool any = ballot(rowvalid) != 0;
@@ -1435,7 +1438,7 @@ void emit_tick_dense(const Emit &e, const Static &S, const State &D, int t, int 
     P.r_lo = r_lo; P.r_hi = r_lo + (r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo); P.dense_tab = S.dense_tab; P.dense_keys = S.dense_keys; P.dense_force_slow = S.dense_force_slow;
     P.Sdev = S.self_dev; P.Ddev = S.state_dev; P.ring_min = D.ring_min;
     P.tdesc = S.tdesc;
-    P.stamp = D.stamp; P.dry = D.dry; P.so_rank = S.so_rank; P.sup = D.sup; P.sup_slot = D.sup_slot;
+    P.stamp = D.stamp; P.dry = D.dry; P.slow_tick = D.slow_tick; P.so_rank = S.so_rank; P.sup = D.sup; P.sup_slot = D.sup_slot;
     P.arr = D.arr; P.so_slot = S.so_slot; P.d_rec = S.d_rec; P.d_first = S.d_first; P.replica_desc2 = S.replica_desc2; P.pull_W = S.pull_W;
     const int slots = r_n > 0 ? r_n : (S.rperm != nullptr ? S.rslots : S.R) - r_lo;
     const bool t256 = dense_tab256(S);
