@@ -226,6 +226,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # settling (outside the W warm-up days, untimed): the library chooses k_tick_dense's form per slot from the per-slot counters of a
+    # whole episode, which reach the host without synchronisation (vds_api.hip adapt_dense) - episode 1 is counted, the start of
+    # episode 3 decides and rebuilds the day graph.  Synchronising between these days lets that happen here, not in the timed days.
+    for _ in range(3):
+        one_day()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         one_day()
     fence()
@@ -439,8 +445,9 @@ def main():
         env4 = w4.make_env(R, device=local_rank, stream=stream.cuda_stream)
         env4.reset(w4.vehicle_nodes(R))
         T4 = env4.T
-        env4.reset_again(); env4.run(T4)
-        torch.cuda.synchronize()
+        for _ in range(3):                # (settling: see the headline's)
+            env4.reset_again(); env4.run(T4)
+            torch.cuda.synchronize()
         nd4 = max(2, min(a.steps, 10))
         t1 = time.perf_counter()
         for _ in range(nd4):
@@ -467,9 +474,9 @@ def main():
             env5 = w5.make_env(R5, device=local_rank, stream=stream.cuda_stream)
             env5.reset(w5.vehicle_nodes(R5))
             T5 = env5.T
-            for _ in range(3):            # (the handle settles on 16 lanes per replica after the first episodes: DESIGN.md 4)
+            for _ in range(3):            # (the handle settles on its forms after the first episodes: DESIGN.md 4)
                 env5.reset_again(); env5.run(T5)
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
             nd5 = 3
             t1 = time.perf_counter()
             for _ in range(nd5):
@@ -554,6 +561,8 @@ def main():
             env_s = w.make_env(R, device=local_rank, stream=stream.cuda_stream)
             sup_ring, sup_slot = env_s.supply_inplace_torch()
             env_s.reset(init)
+            for _ in range(3):            # (settling, hook-less days: see the headline's)
+                env_s.run(env_s.T); torch.cuda.synchronize(); env_s.reset_again()
             views = env_s.obs_inplace_torch()
 
             def policy_inplace():

@@ -1650,9 +1650,8 @@ int vds_num_ticks(const vds_handle *h, int32_t *T) {
 // 7.13 -> 6.8 ms, configs[3] stamp form 9.56 -> 8.8 ms, configs[4] 10.5 ms either way; profiles/r06/tick_forms_*.txt).  VDS_DENSE_TICK_FORMS=0: one form for the whole day as before (the rule
 // above); =alt: the forms alternate slot by slot from the first episode on (tests: results do not depend on the form).
 #ifndef DENSE_TICK_RATE
-#define DENSE_TICK_RATE 0.00025         // (of the slot's buckets, at least DENSE_TICK_MIN of them: 49 at configs[1] / [3], 66 at configs[4] - tick_forms_*.txt
-#define DENSE_TICK_MIN 32               // list the day under rules from 16 to 384: flat between 32 and 96, configs[4] wants the low end)
-#endif
+#define DENSE_TICK_RATE 0.00025         // (of the slot's buckets: 49 at configs[1] / [3], 66 at configs[4] - profiles/r06/tick_forms_*.txt list the
+#endif                                  // day under rules from 16 to 384 buckets: flat between 32 and 96, configs[4] wants the low end)
 static const Static &tick_static(vds_handle *h, int t) {
     if (t < 0 || (size_t)t >= h->tick_form.size() || !h->tick_form[t]) return h->S;
     h->S_alt = h->S;
@@ -1680,7 +1679,7 @@ static void adapt_dense(vds_handle *h) {
     if (h->pin_bucket_ticks > 0 && hipEventQuery(h->pin_ev) == hipSuccess) {
         if (h->tick_mode == 1 && h->pin_ticks_valid && S.dense_lpr == 8) {
             // per slot; decided once (the counters of the 16-lane form say nothing about the 8-lane form)
-            const double lim = h->tick_lim >= 0 ? (double)h->tick_lim : std::max((double)DENSE_TICK_MIN, DENSE_TICK_RATE * (double)S.R * (double)S.C);
+            const double lim = h->tick_lim >= 0 ? (double)h->tick_lim : DENSE_TICK_RATE * (double)S.R * (double)S.C;
             size_t n16 = 0;
             h->tick_form.assign((size_t)S.T, 0);
             for (int t = 0; t < S.T; ++t) if ((double)h->pin_slow_tick[t] > lim) { h->tick_form[t] = 1; ++n16; }
