@@ -20,7 +20,14 @@ if D > 1:
 else:
     env = w.make_env(R, force_generic=FG)
 env.reset(init)
+# (three settling days: k_tick_dense's form per slot is chosen from the counters of a whole episode - vds_api.hip adapt_dense -, so the
+# checked day is the one a bench times; VDS_DENSE_TICK_FORMS=alt alternates the two forms from the first day on)
+import ctypes as C
+for _ in range(3):
+    env.run(env.T); env.sync(); env.reset_again()
 env.run(env.T)
+forms = np.zeros(env.T, dtype=np.uint8); nf = C.c_int32()
+env._lib.vds_debug_tick_forms(env._h, forms.ctypes.data_as(C.c_void_p), env.T, C.byref(nf))
 cn = env.counters()
 oracles = [Oracle(w.city.cost, w.city.node2cluster, w.nbr_off, w.nbr_idx, w.depth_limit, w.neighbor_can_server, d[0], d[1], d[2], w.vehicles) for d in days]
 t0 = time.time()
@@ -37,5 +44,5 @@ for r0 in range(0, R, 64):
             (cn[r, 0], cn[r, 1], cn[r, 3], cn[r, 6], cn[r, 7]) == (oc["order_num"], oc["reject_num"], oc["wait_sum"], oc["sum_order_value"], oc["evals"])
         bad += 0 if ok else 1
 print("%s (%d order day%s%s, %s): %d replicas checked against the oracle in %.0f s, mismatching replicas: %d" % (
-    wl, D, "s" if D > 1 else "", ", %s map" % mapping if D > 1 else "", env.main_kernel(), R, time.time() - t0, bad))
+    wl, D, "s" if D > 1 else "", ", %s map" % mapping if D > 1 else "", env.main_kernel() + ", %d of %d slots in the 16-lane form" % (int(forms[:nf.value].sum()), env.T), R, time.time() - t0, bad))
 assert bad == 0

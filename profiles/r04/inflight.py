@@ -13,6 +13,8 @@ env = w.make_env(R, stream=torch.cuda.current_stream().cuda_stream)
 env.reset(w.vehicle_nodes(R))
 T = env.T
 print(env.main_kernel(), env._lib.vds_build_id().decode(), "replicas", R)
+for _ in range(3):          # (the handle settles on its per-slot forms: vds_api.hip adapt_dense)
+    env.reset_again(); env.run(T); env.sync()
 for groups in (0, 1):
     env.set_run_groups(groups, -1 if groups == 0 else 0)
     G = env.run_groups()

@@ -5,6 +5,8 @@ cd $GRAFT_REPO_ROOT
 python -c "from vehicles_dispatch_simulator_amd import _lib; print('build', _lib.load().vds_build_id().decode())"
 python profiles/full_check.py cfg2 1024 2>&1 | tail -1
 python profiles/full_check.py cfg4 1024 2>&1 | tail -1
+VDS_DENSE_TICK_FORMS=alt python profiles/full_check.py cfg2 1024 2>&1 | tail -1
+VDS_DENSE_TICK_FORMS=alt python profiles/full_check.py cfg4 1024 2>&1 | tail -1
 VDS_DENSE_DFS=0 python profiles/full_check.py cfg4 1024 2>&1 | tail -1
 python profiles/full_check.py cfg4 1024 8 interleaved 2>&1 | tail -1
 python profiles/full_check.py cfg2 1024 16 interleaved 2>&1 | tail -1
