@@ -1684,6 +1684,9 @@ static void adapt_dense(vds_handle *h) {
             h->tick_form.assign((size_t)S.T, 0);
             for (int t = 0; t < S.T; ++t) if ((double)h->pin_slow_tick[t] > lim) { h->tick_form[t] = 1; ++n16; }
             h->dense_adapt = 1;
+            // (nearly every slot: the whole day - what is left for the 8-lane form are slots near the limit, where it wins and loses by
+            // turns: configs[4], 137 of 148 slots, profiles/r06/tick_forms_cfg5.txt)
+            if (n16 * 100 >= (size_t)S.T * 85) { std::fill(h->tick_form.begin(), h->tick_form.end(), (unsigned char)1); n16 = (size_t)S.T; }
             if (n16 > 0) { h->run_stale = true; h->tables_gen++; }           // the day graph holds the other kernel
             else h->tick_form.clear();
             return;
