@@ -247,12 +247,12 @@ def test_tiny_golden_per_tick(name, mode):
 def test_mode_fixture_product_in_worker_processes():
     """The rest of the mode x fixture product - every engine mode on every tiny fixture it applies to, per tick incl. container order
     (run_day, as test_tiny_golden_per_tick) - and the ragged 37-replica days of the modes test_many_replicas_ragged leaves out, dealt
-    to twelve worker processes (tests/parity_worker.py): a day's cost is host work (oracle steps, container comparisons per tick)."""
+    to sixteen worker processes (tests/parity_worker.py): a day's cost is host work (oracle steps, container comparisons per tick)."""
     import json, os, subprocess, sys
     pairs = [(n, m, "tick") for n in TINY for m in MODES if _applies(n, m, every_pair=True) and m not in IN_PROCESS_MODES]
     pairs += [(n, m, "ragged") for n, m in RAGGED if m not in RAGGED_IN_PROCESS]
     pairs.sort(key=lambda x: x[2] != "ragged")        # (the long items first)
-    nproc = 12
+    nproc = 16
     here = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "parity_worker.py"), json.dumps(pairs[i::nproc])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for i in range(nproc)]
