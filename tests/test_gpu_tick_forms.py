@@ -14,13 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r"""
-import sys, ctypes as C
+import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, %r)
 from oracle.oracle import Oracle
 from vehicles_dispatch_simulator_amd import workloads
 mode = %r
-for neighbor, veh, R, episodes in %r:
+for neighbor, veh, R, episodes, lim in %r:
+    if lim is not None:
+        os.environ["VDS_DENSE_TICK_LIM"] = str(lim)       # (read when the day is loaded)
     w = workloads.tiny(neighbor=neighbor, vehicles=veh, orders=4000)
     init = w.vehicle_nodes(R)
     env = w.make_env(R)
@@ -60,9 +62,10 @@ def run_worker(mode, cases, **environ):
 
 
 def test_forms_alternating_slot_by_slot():
-    run_worker("alt", [(False, 700, 96, 1), (True, 700, 96, 1)], VDS_DENSE_TICK_FORMS="alt")
+    run_worker("alt", [(False, 700, 96, 1, None), (True, 700, 96, 1, None)], VDS_DENSE_TICK_FORMS="alt")
 
 
 def test_per_slot_choice_adapts_and_keeps_results():
-    out = run_worker("adapt", [(False, 1000, 96, 4), (True, 1000, 96, 4)], VDS_DENSE_TICK_LIM="100")
+    # (limits chosen so that some slots, fewer than 85 % of them, switch: 114 / 87 of 148; nearly every slot would switch the whole day)
+    out = run_worker("adapt", [(False, 1000, 96, 4, 100), (True, 1000, 96, 4, 120)])
     assert out.count("ok adapt") == 2

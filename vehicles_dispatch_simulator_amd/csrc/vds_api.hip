@@ -252,7 +252,6 @@ struct vds_handle {
     Static S_alt;                            // S with that form (tick_static)
     int dense_adapt = 0;                     // 0 undecided (8 lanes), 1 switched to 16 lanes / 256-entry tables; -1 fixed by the caller / environment
     unsigned tables_gen = 0;                 // bumped with run_stale: what a graph was built for (the hooked day graph keeps its own copy)
-    unsigned long long run_kshape = 0, hook_kshape = 0;      // graph_shape of the graphs run_exec / hook_exec were made from
     bool run_stale = false;                  // tables / capacities changed since the graph was built: same shape -> hipGraphExecUpdate
     hipStream_t run_stream = nullptr;
     int use_graph = -1;                      // -1: ask VDS_RUN_GRAPH (default on)
@@ -437,12 +436,10 @@ static unsigned long long graph_shape(hipGraph_t g, int n_ticks, int G) {
     mix(n); mix(n_edges); mix((unsigned long long)n_ticks); mix((unsigned long long)G);
     std::vector<hipGraphNode_t> nodes(n);
     if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    // every kernel node's function and launch shape (the slots of a day may run different forms of k_tick_dense: adapt_dense)
-    for (size_t i = 0; i < n; ++i) {
-        hipGraphNodeType ty;
-        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        mix((unsigned long long)ty);
-        if (ty != hipGraphNodeTypeKernel) continue;
+    // (the slots of a day may run different forms of k_tick_dense - adapt_dense -: an update in place or of a parked graph then replaces
+    // kernel functions and launch shapes of some nodes, which hipGraphExecUpdate does, as it did when the whole day switched)
+    const size_t first = std::min(n, (size_t)(2 * G));
+    for (size_t i = 0; i < first; ++i) {
         hipKernelNodeParams kp{};
         if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { (void)hipGetLastError(); return 0; }
         mix((unsigned long long)(uintptr_t)kp.func); mix(kp.blockDim.x); mix(kp.sharedMemBytes);
@@ -2157,16 +2154,14 @@ int vds_run(vds_handle *h, int32_t n_ticks) {
         // same shape as the graph at hand (new order tables, another first slot): its kernel parameters are replaced in place -
         // no destruction (see drop_run_graph for what that costs), no instantiation
         bool updated = false;
-        const unsigned long long kshape = graph_shape(g, n_ticks, G);       // (kernels and launch shapes of all nodes: an update in place keeps them)
-        if (h->run_exec && h->run_n == n_ticks && h->run_G == G && kshape != 0 && kshape == h->run_kshape) {
+        if (h->run_exec && h->run_n == n_ticks && h->run_G == G) {
             (void)hipStreamSynchronize(h->run_stream);          // (run_exec was launched there; nullptr = legacy default stream)
             hipGraphNode_t bad = nullptr;
             hipGraphExecUpdateResult res;
             updated = hipGraphExecUpdate(h->run_exec, g, &bad, &res) == hipSuccess;
             if (!updated) (void)hipGetLastError();
         }
-        const unsigned long long shape = G > 1 ? kshape : 0ull;
-        h->run_kshape = kshape;
+        const unsigned long long shape = G > 1 ? graph_shape(g, n_ticks, G) : 0ull;
         if (!updated) {
             drop_run_graph(h);
             // a parked executable graph of this shape (another handle's, or this handle's from before): re-targeted in place
@@ -2335,9 +2330,7 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
             return fail(h, VDS_EHIP, "vds_run_hooked: building the day graph failed: %s", hipGetErrorString(err));
         }
         bool updated = false;
-        const unsigned long long kshape = graph_shape(g, n_ticks, G);
-        if (h->hook_exec && h->hook_n == n_ticks && h->hook_G == G && (h->hook_planes != 0) == (planes != 0) && (h->hook_K > 0) == (K > 0) && (h->hook_policy != nullptr) == (policy_graph != nullptr) &&
-            kshape != 0 && kshape == h->hook_kshape) {
+        if (h->hook_exec && h->hook_n == n_ticks && h->hook_G == G && (h->hook_planes != 0) == (planes != 0) && (h->hook_K > 0) == (K > 0) && (h->hook_policy != nullptr) == (policy_graph != nullptr)) {
             (void)hipStreamSynchronize(h->hook_stream);
             hipGraphNode_t bad = nullptr;
             hipGraphExecUpdateResult res;
@@ -2346,8 +2339,7 @@ static int run_hooked_impl(vds_handle *h, int32_t n_ticks, int32_t planes, int32
         }
         // (grouped hooked graphs are parked under their shape - nodes, edges, first kernels - salted so that they never meet a vds_run
         // graph, and taken back from the pool like those: a rebuild that an in-place update cannot cover does not leak an executable)
-        const unsigned long long shape = G > 1 ? (kshape ^ 0x9E3779B97F4A7C15ull) | 1ull : 0ull;
-        h->hook_kshape = kshape;
+        const unsigned long long shape = G > 1 ? (graph_shape(g, n_ticks, G) ^ 0x9E3779B97F4A7C15ull) | 1ull : 0ull;
         if (!updated) {
             drop_hook_graph(h);
             if (G > 1 && shape != 0) {
