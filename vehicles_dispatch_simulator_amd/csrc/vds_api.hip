@@ -19,6 +19,9 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 namespace vds {
 void launch_reset(const Static &, const State &, const int *, hipStream_t);
@@ -3064,7 +3067,25 @@ int vds_profile_read(vds_handle *h, float *ms, int32_t cap, int32_t *n) {
     return guarded(h, "vds_profile_read", [&] { return profile_read_impl(h, ms, cap, n); });
 }
 
+// (diagnostics, VDS_SEGV_TRACE=1: native frames of a SIGSEGV / SIGABRT on stderr before the default action)
+static void vds_segv_trace(int sig) {
+    void *fr[64];
+    const int n = backtrace(fr, 64);
+    const char msg[] = "\n[vds] fatal signal, native frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(fr, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
 int vds_create(const vds_config *cfg, vds_handle **out) {
+    {
+        static const bool once = [] {
+            const char *v = getenv("VDS_SEGV_TRACE");
+            if (v && *v == '1') { signal(SIGSEGV, vds_segv_trace); signal(SIGABRT, vds_segv_trace); }
+            return true;
+        }();
+        (void)once;
+    }
     return guarded(nullptr, "vds_create", [&] { return create_impl(cfg, out); });
 }
 
