@@ -250,6 +250,7 @@ struct vds_handle {
     long long pin_bucket_ticks = 0;          // bucket-ticks of that episode (0: nothing copied yet)
     int *pin_slow_tick = nullptr; int pin_slow_cap = 0;      // ... and per slot (State.slow_tick), when the episode ran the whole day in the base form
     bool pin_ticks_valid = false;
+    int slow_tick_cap = 1;                   // words of State.slow_tick
     int tick_mode = 1, tick_lim = -1;        // VDS_DENSE_TICK_FORMS (0 one form per day, 1 per slot, 2 alternating: tests), VDS_DENSE_TICK_LIM (buckets; < 0: the default rule) as read when the day was loaded
     std::vector<unsigned char> tick_form;    // per slot: 1 = k_tick_dense with 16 lanes per replica and 256-entry tables whatever S.dense_lpr says (adapt_dense)
     Static S_alt;                            // S with that form (tick_static)
@@ -1021,7 +1022,12 @@ static int alloc_state(vds_handle *h, int O) {
         if (rc) return rc;
     }
     D.slow_tick = nullptr;
-    if (S.dense && (rc = dev_alloc(h, &D.slow_tick, (size_t)std::max(S.T, 1)))) return rc;
+    {   // (one word per slot of the LONGEST resident day: another replica -> day map may lengthen the batch's day without coming back here)
+        int tcap = std::max(S.T, 1);
+        for (const auto &d : h->days) tcap = std::max(tcap, d.T);
+        h->slow_tick_cap = tcap;
+        if (S.dense && (rc = dev_alloc(h, &D.slow_tick, (size_t)tcap))) return rc;
+    }
     D.dry = nullptr;
     if (S.dense_st && (rc = dev_alloc(h, &D.dry, (size_t)R))) return rc;
     D.sup = nullptr; D.sup_slot = nullptr;           // SupplyExpect kept in place (dense layout): planes by arrival slot + the current plane's index
@@ -1724,7 +1730,7 @@ static int reset_device(vds_handle *h) {
     const Static &S = h->S;
     HIPCHK(h, hipMemsetAsync(h->D.err, 0, 16 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.work, 0, 2 * sizeof(int), h->stream));
-    if (h->D.slow_tick) HIPCHK(h, hipMemsetAsync(h->D.slow_tick, 0, (size_t)std::max(S.T, 1) * sizeof(int), h->stream));
+    if (h->D.slow_tick) HIPCHK(h, hipMemsetAsync(h->D.slow_tick, 0, (size_t)h->slow_tick_cap * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(h->D.ring_cnt, 0, (size_t)S.H * S.C * S.R * sizeof(int), h->stream));
     if (h->D.sup) {
         HIPCHK(h, hipMemsetAsync(h->D.sup, 0, (size_t)VDS_SUP_PLANES * S.C * S.R * sizeof(int), h->stream));
