@@ -128,7 +128,9 @@ def leg_roofline(env_x, workload_key, replicas, stream, build_id):
     traffic, tb = side.get("hbm_bytes_per_launch"), side.get("traffic_build")
     same = traffic is not None and tb is not None and tb.split("+")[0] == build_id.split("+")[0]
     tick_s = day_ms * 1e-3 / T_x
+    forms = env_x.tick_forms()
     out = {"bound": "hbm", "kernel": kern, "ticks": T_x, "day_kernel_ms": day_ms, "avg_launch_ms": tick_s * 1e3, "run_groups": env_x.run_groups(),
+           "slots_in_16_lane_form": int(forms.sum()) if forms.size else (0 if "dense" in kern else None),
            "traffic": traffic if same else None, "traffic_build": tb, "traffic_build_matches": bool(same), "traffic_source": side.get("traffic_source"),
            "achieved": (traffic / tick_s / 1e9) if same else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": (traffic / tick_s / 1e9 / HBM_PEAK_GBS) if same else None}
@@ -356,7 +358,7 @@ def main():
                         # event_pair_avg_launch_ms: ONE launch over all replicas by itself (the eager, profiled pass: an event pair
                         # per launch) - the figure rocprofv3 --stats of profiles/<tag>/kernel_stats.csv (VDS_RUN_GROUPS=1) shows
                         "avg_launch_ms": avg_s * 1e3, "launches": launches, "day_kernel_ms": day_ms,
-                        "run_groups": groups_default, "event_pair_avg_launch_ms": float(ms.mean()),
+                        "run_groups": groups_default, "slots_in_16_lane_form": int(env.tick_forms().sum()), "event_pair_avg_launch_ms": float(ms.mean()),
                         # one chain (one launch per tick over all replicas), one event pair around the day: the per-launch figure
                         # a kernel trace can confirm (profiles/<tag>/kernel_stats.csv: avg x launches <= this day)
                         "one_chain_day_kernel_ms": one_chain_day_ms, "one_chain_ms_per_tick": one_chain_day_ms / launches,

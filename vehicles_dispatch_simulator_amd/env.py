@@ -257,6 +257,14 @@ class BatchedDispatchEnv:
         branches of the day graph); results do not depend on it.  ``groups <= 0`` / ``stagger < 0``: library default."""
         self._chk(self._lib.vds_set_run_groups(self._h, int(groups), int(stagger)))
 
+    def tick_forms(self) -> np.ndarray:
+        """Per slot of the day: 1 where ``k_tick_dense`` runs its 16-lane form (256-entry tables), 0 where it runs the base form; empty
+        when the library has made no per-slot choice (``vds_debug_tick_forms``; the choice never changes results)."""
+        out = np.zeros(max(self.T, 1), dtype=np.uint8)
+        n = C.c_int32()
+        self._chk(self._lib.vds_debug_tick_forms(self._h, _p(out), int(out.size), C.byref(n)))
+        return out[:n.value].copy()
+
     def run_groups(self) -> int:
         """The group count ``run`` uses as the handle stands (1: one launch (pair) per tick over all replicas)."""
         return int(self._lib.vds_get_run_groups(self._h))
