@@ -19,9 +19,12 @@ CSRC = os.path.join(ROOT, "vehicles_dispatch_simulator_amd", "csrc")
 
 
 def build(target, name):
+    """The instrumented library, built here only when it is missing or was built from other sources: every library carries the content
+    hash of its sources (``vds_build_id``: ``src:<kernels>+<host>``, ``make srchash``), which is compared - not the files' times, which a
+    copy of the tree to another machine does not keep in order."""
     path = os.path.join(ROOT, "build", name)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "vds.h"), os.path.join(ROOT, "include", "vds_debug.h")]
-    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+    want = subprocess.check_output(["make", "-s", "-C", CSRC, "srchash"], text=True).strip().splitlines()[-1].encode()
+    if not os.path.exists(path) or want not in open(path, "rb").read():
         subprocess.check_call(["make", "-s", "-j8", "-C", CSRC, target])
     return path
 
