@@ -195,19 +195,24 @@ def run_case(seed, case, idle_cap=None, whole_day=False):
     env.close()
 
 
+def volume_worker_argvs():
+    import sys
+    n_random, n_medium, nproc = int(os.environ.get("VDS_FUZZ_VOLUME", "4000")), int(os.environ.get("VDS_FUZZ_VOLUME_MEDIUM", "128")), int(os.environ.get("VDS_FUZZ_PROCS", "4"))
+    here = os.path.dirname(os.path.abspath(__file__))
+    return [[sys.executable, os.path.join(here, "fuzz_worker.py"), str(i), str(nproc), str(n_random), str(n_medium)] for i in range(nproc)]
+
+
 def test_fuzz_volume_in_worker_processes():
     """Volume: VDS_FUZZ_VOLUME (default 4000) more random cities and 128 medium ones, whole days without hooks (run_case(whole_day=True):
-    final per-order results, counters, observations and containers of every replica against the oracle), dealt to eight worker
-    processes (tests/fuzz_worker.py) - the per-case cost is host work (city, oracle, comparisons), which the processes share."""
-    import subprocess, sys
-    n_random, n_medium, nproc = int(os.environ.get("VDS_FUZZ_VOLUME", "4000")), int(os.environ.get("VDS_FUZZ_VOLUME_MEDIUM", "128")), 8
-    here = os.path.dirname(os.path.abspath(__file__))
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "fuzz_worker.py"), str(i), str(nproc), str(n_random), str(n_medium)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(nproc)]
+    final per-order results, counters, observations and containers of every replica against the oracle), dealt to four worker
+    processes (VDS_FUZZ_PROCS; tests/fuzz_worker.py) - the per-case cost is host work (city, oracle, comparisons), which the processes share.  The
+    workers are started when the session's collection is final (tests/conftest.py) and run beside the tests before this one."""
+    import conftest
+    n_random, n_medium = int(os.environ.get("VDS_FUZZ_VOLUME", "4000")), int(os.environ.get("VDS_FUZZ_VOLUME_MEDIUM", "128"))
+    conftest.start_workers("fuzz_volume", volume_worker_argvs())
     done = 0
-    for i, p in enumerate(procs):
-        out, _ = p.communicate(timeout=1500)
-        assert p.returncode == 0 and "WORKER DONE" in out, "worker %d:\n%s" % (i, out[-3000:])
+    for i, (rc, out) in enumerate(conftest.collect_workers("fuzz_volume")):
+        assert rc == 0 and "WORKER DONE" in out, "worker %d:\n%s" % (i, out[-3000:])
         done += int(out.split("WORKER DONE")[1].split()[0])
     assert done == n_random + n_medium
 

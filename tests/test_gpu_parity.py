@@ -244,22 +244,34 @@ def test_tiny_golden_per_tick(name, mode):
     run_day(g, R=3, same_init=bool(len(g["dispatch_log"])), **MODES[mode])
 
 
-def test_mode_fixture_product_in_worker_processes():
-    """The rest of the mode x fixture product - every engine mode on every tiny fixture it applies to, per tick incl. container order
-    (run_day, as test_tiny_golden_per_tick) - and the ragged 37-replica days of the modes test_many_replicas_ragged leaves out, dealt
-    to sixteen worker processes (tests/parity_worker.py): a day's cost is host work (oracle steps, container comparisons per tick)."""
-    import json, os, subprocess, sys
+PRODUCT_NPROC = 8          # (beside the other tests on a 16-core box: more of them slow the pytest process itself down)
+
+
+def product_pairs():
     pairs = [(n, m, "tick") for n in TINY for m in MODES if _applies(n, m, every_pair=True) and m not in IN_PROCESS_MODES]
     pairs += [(n, m, "ragged") for n, m in RAGGED if m not in RAGGED_IN_PROCESS]
     pairs.sort(key=lambda x: x[2] != "ragged")        # (the long items first)
-    nproc = 16
+    return pairs
+
+
+def product_worker_argvs():
+    import json, os, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "parity_worker.py"), json.dumps(pairs[i::nproc])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for i in range(nproc)]
+    pairs = product_pairs()
+    return [[sys.executable, os.path.join(here, "parity_worker.py"), json.dumps(pairs[i::PRODUCT_NPROC])] for i in range(PRODUCT_NPROC)]
+
+
+def test_mode_fixture_product_in_worker_processes():
+    """The rest of the mode x fixture product - every engine mode on every tiny fixture it applies to, per tick incl. container order
+    (run_day, as test_tiny_golden_per_tick) - and the ragged 37-replica days of the modes test_many_replicas_ragged leaves out, dealt
+    to eight worker processes (tests/parity_worker.py): a day's cost is host work (oracle steps, container comparisons per tick).
+    The workers are started when the session's collection is final (tests/conftest.py) and run beside the tests before this one."""
+    import conftest
+    pairs = product_pairs()
+    conftest.start_workers("parity_product", product_worker_argvs())
     done = 0
-    for i, p in enumerate(procs):
-        out, _ = p.communicate(timeout=1500)
-        assert p.returncode == 0 and "WORKER DONE" in out, "worker %d:\n%s" % (i, out[-3000:])
+    for i, (rc, out) in enumerate(conftest.collect_workers("parity_product")):
+        assert rc == 0 and "WORKER DONE" in out, "worker %d:\n%s" % (i, out[-3000:])
         done += int(out.split("WORKER DONE")[1].split()[0])
     assert done == len(pairs) and len(pairs) > 200
 
