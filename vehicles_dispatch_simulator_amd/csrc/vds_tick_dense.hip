@@ -903,10 +903,19 @@ __device__ __forceinline__ void dense_body(const DenseArgs &S, const DenseArgs &
 #pragma unroll
             for (int i = 0; i < NL; ++i) L[i] = bfi(hi == i ? bm : 0u, ncrep, L[i]);
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(res[jj]) : "v"(res[jj]), "v"(rmin), "s"(jmask));      // res[jj] = lg == ji ? rmin : res[jj]
-            const bool hit = active && (rmin >> PB) != DEAD;
-            evals += active ? navail : 0;
-            navail -= hit ? 1 : 0;
+            if (DM == 2 || sizeof(CT) != 1) {       // (per step only where a row may sit a step out, or a cost may really reject)
+                const bool hit = active && (rmin >> PB) != DEAD;
+                evals += active ? navail : 0;
+                navail -= hit ? 1 : 0;
+            }
         }
+    }
+    if (DM != 2 && sizeof(CT) == 1 && !(abl & 4)) {
+        // one order stream for the wavefront's rows and byte costs (never above the pickup window): an order finds a vehicle while one is
+        // left, so the k steps saw mnew, mnew - 1, ... entries - the evaluations (:929) and the entries left in closed form
+        const int h = min(kmax, mnew);
+        evals = h * mnew - ((h * (h - 1)) >> 1);
+        navail = mnew - h;
     }
     PROF_STAMP(6);          // match loop
     // 6. order-preserving compaction of the survivors (:963) through the row's table, written back with whole-chunk stores from
