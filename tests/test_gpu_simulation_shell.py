@@ -295,6 +295,46 @@ def test_batched_policy_runs_as_one_day_graph_and_matches_oracle_replay():
     np.testing.assert_array_equal(days[True][2], days[False][2])
 
 
+class UncapturablePolicySim(GraphPolicySim):
+    """The same policy with a host synchronisation inside (``.item()``): it cannot be captured."""
+
+    def BatchedPolicy(self, ob):
+        acts = GraphPolicySim.BatchedPolicy(self, ob)
+        self.host_reads += int(ob["idle_now"].sum().item() >= 0)
+        return acts
+
+
+def test_batched_policy_that_cannot_be_captured_runs_slot_by_slot():
+    """A ``BatchedPolicy`` the graph capture refuses: the reason is kept (``BatchedPolicyGraphError``) and the day runs slot by slot with
+    the same results as the captured form of the same policy."""
+    import torch
+    g = load_golden("tiny_kmeans")
+    R = 16
+    n2c = g["node2cluster"]
+    C = int(g["C"])
+    first_node = torch.tensor([int(np.flatnonzero(n2c == c)[0]) if (n2c == c).any() else 0 for c in range(C)], device="cuda")
+    out = {}
+    for cls in (GraphPolicySim, UncapturablePolicySim):
+        sim = make_sim(g, cls, Replicas=R, VehicleSeed=31, BatchedHooks=True)
+        T = sim.env.T
+        sim.first_node, sim.begin_calls, sim.host_reads = first_node, 0, 0
+        sim.slot = torch.zeros(1, dtype=torch.int64, device="cuda")
+        sim.log = torch.full((T + 4, R, 2, 3), -1, dtype=torch.int32, device="cuda")
+        sim.SimCity()
+        assert sim.step == T and int(sim.slot.item()) == T
+        if cls is UncapturablePolicySim:
+            assert sim.BatchedPolicyGraphError is not None and sim.host_reads >= T
+        else:
+            assert sim.BatchedPolicyGraphError is None
+        out[cls] = (sim.env.orders(), sim.env.counters(), sim.log.cpu().numpy())
+        sim.env.close()
+    a, b = out[GraphPolicySim], out[UncapturablePolicySim]
+    for k in ("status", "vehicle", "wait"):
+        np.testing.assert_array_equal(a[0][k], b[0][k])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2][:T], b[2][:T])
+
+
 def test_batched_hooks_policy_over_all_replicas_matches_oracle_replay():
     """``BatchedHooks``: hook order as SimCity's, observations / policy / actions on the device for 64 cities; every
     replica equals a CPU oracle that replays ITS action log (vehicle = head of the named idle list at that moment)."""

@@ -615,7 +615,7 @@ class Simulation(object):
         import torch
         st = getattr(self, "_bp_state", None)
         if st is not None and st["env"] is self.env:
-            return st
+            return st if st["graph"] is not None else None        # (a capture that failed on this handle is not tried again)
         self.BatchedPolicyGraphError = None
         obs, planes = self._policy_obs()
         try:
@@ -638,7 +638,7 @@ class Simulation(object):
                 acts.copy_(self.BatchedPolicy(obs))
         except Exception as e:
             self.BatchedPolicyGraphError = repr(e)
-            self._bp_state = None
+            self._bp_state = dict(env=self.env, graph=None)
             return None
         self._bp_state = dict(env=self.env, obs=obs, planes=planes, actions=acts, graph=g)
         return self._bp_state
